@@ -1,0 +1,122 @@
+"""Python face of the host side (host/scene.hpp, host/hdr_sampling.hpp): scene + environment preparation.
+
+Mirrors the reference call order SampleExample::loadScene / loadEnvironmentHdr / updateUniformBuffer
+(src/sample_example.cpp:82-106, 164-173) without Vulkan.
+"""
+import ctypes as C
+import os
+import numpy as np
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HOST_LIB_PATH = os.path.join(_HERE, "host", "librestir_host.so")
+_lib = None
+
+def host_lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise RuntimeError(f"{HOST_LIB_PATH} missing: run __graft_entry__.build() first")
+        L = C.CDLL(HOST_LIB_PATH)
+        L.rth_scene_create.restype = C.c_void_p
+        L.rth_env_create.restype = C.c_void_p
+        L.rth_env_integral.restype = C.c_float
+        L.rth_env_average.restype = C.c_float
+        for name, args in {
+            "rth_scene_destroy": [C.c_void_p], "rth_scene_load": [C.c_void_p, C.c_char_p],
+            "rth_scene_make_procedural": [C.c_void_p, C.c_int, C.c_float, C.c_uint32],
+            "rth_scene_set_camera": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float],
+            "rth_scene_get_camera_pose": [C.c_void_p, C.c_void_p], "rth_scene_update_camera": [C.c_void_p, C.c_int, C.c_int],
+            "rth_scene_get_camera": [C.c_void_p, C.c_void_p], "rth_scene_light_weights": [C.c_void_p, C.c_void_p, C.c_void_p],
+            "rth_scene_stats": [C.c_void_p, C.c_void_p], "rth_scene_desc": [C.c_void_p, C.c_void_p, C.c_void_p],
+            "rth_env_destroy": [C.c_void_p], "rth_env_load": [C.c_void_p, C.c_char_p], "rth_env_set": [C.c_void_p, C.c_void_p, C.c_int, C.c_int],
+            "rth_env_make_sky": [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_uint32], "rth_env_integral": [C.c_void_p], "rth_env_average": [C.c_void_p],
+            "rth_env_width": [C.c_void_p], "rth_env_height": [C.c_void_p], "rth_env_get_accel": [C.c_void_p, C.c_void_p],
+            "rth_default_state": [C.c_void_p], "rth_alias_table": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
+        }.items():
+            getattr(L, name).argtypes = args
+        _lib = L
+    return _lib
+
+
+class HdrSampling:
+    """hdr_sampling.hpp:38-66 (data products only)."""
+    def __init__(self):
+        self._h = host_lib().rth_env_create()
+    def __del__(self):
+        if getattr(self, "_h", None):
+            host_lib().rth_env_destroy(self._h); self._h = None
+    def loadEnvironment(self, path):
+        return host_lib().rth_env_load(self._h, path.encode()) == 0
+    def setEnvironment(self, rgba):
+        a = np.ascontiguousarray(rgba, dtype=np.float32)
+        host_lib().rth_env_set(self._h, a.ctypes.data, a.shape[1], a.shape[0])
+    def makeSyntheticSky(self, w, h, sun_peak=5e4, seed=7):
+        host_lib().rth_env_make_sky(self._h, w, h, sun_peak, seed)
+    def getIntegral(self): return host_lib().rth_env_integral(self._h)
+    def getAverage(self): return host_lib().rth_env_average(self._h)
+    @property
+    def size(self): return host_lib().rth_env_width(self._h), host_lib().rth_env_height(self._h)
+    def accel(self):
+        w, h = self.size
+        a = np.zeros(w * h, dtype=np.dtype([("alias", "<i4"), ("q", "<f4"), ("pdf", "<f4"), ("aliasPdf", "<f4")]))
+        host_lib().rth_env_get_accel(self._h, a.ctypes.data)
+        return a
+
+
+class Scene:
+    """scene.hpp:59-80: setup / load / updateCamera / getCamera / getStat + light weights."""
+    STAT_NAMES = ["triangles", "instancedTriangles", "vertices", "primMeshes", "nodes", "materials", "textures", "puncLights", "trigLights"]
+    def __init__(self):
+        self._h = host_lib().rth_scene_create()
+    def __del__(self):
+        if getattr(self, "_h", None):
+            host_lib().rth_scene_destroy(self._h); self._h = None
+    def load(self, filename):
+        return host_lib().rth_scene_load(self._h, filename.encode()) == 0
+    def makeProcedural(self, kind, scale=1.0, seed=1):
+        if host_lib().rth_scene_make_procedural(self._h, kind, scale, seed) != 0:
+            raise RuntimeError("procedural scene generation failed")
+        return self
+    def setCamera(self, eye, center, up=(0, 1, 0), fov=45.0):
+        e, c, u = (np.asarray(v, dtype=np.float32) for v in (eye, center, up))
+        host_lib().rth_scene_set_camera(self._h, e.ctypes.data, c.ctypes.data, u.ctypes.data, fov)
+    def cameraPose(self):
+        out = np.zeros(10, dtype=np.float32)
+        host_lib().rth_scene_get_camera_pose(self._h, out.ctypes.data)
+        return out[0:3].copy(), out[3:6].copy(), out[6:9].copy(), float(out[9])
+    def updateCamera(self, width, height):
+        host_lib().rth_scene_update_camera(self._h, width, height)
+    def getCamera(self):
+        cam = abi.SceneCamera()
+        host_lib().rth_scene_get_camera(self._h, C.byref(cam))
+        return cam
+    def getStat(self):
+        out = np.zeros(9, dtype=np.uint64)
+        host_lib().rth_scene_stats(self._h, out.ctypes.data)
+        return dict(zip(self.STAT_NAMES, (int(v) for v in out)))
+    @property
+    def lightWeights(self):
+        p, t = C.c_float(), C.c_float()
+        host_lib().rth_scene_light_weights(self._h, C.byref(p), C.byref(t))
+        return p.value, t.value
+    def desc(self, env=None):
+        d = abi.SceneDesc()
+        host_lib().rth_scene_desc(self._h, env._h if env is not None else None, C.byref(d))
+        return d
+
+
+def default_state(width, height, scene=None, env=None, time=1000):
+    """RtxState as SampleExample fills it: defaults (sample_example.hpp:154-184) + the derived constants of
+    sample_example.cpp:87 (lightLuminIntegInv) and :104-105 (fireflyClampThreshold, envMapLuminIntegInv)."""
+    st = abi.RtxState()
+    host_lib().rth_default_state(C.byref(st))
+    st.size.x, st.size.y = width, height
+    st.time = time
+    if scene is not None:
+        p, t = scene.lightWeights
+        st.lightLuminIntegInv = 1.0 / (p + t) if (p + t) > 0 else float("inf")
+    if env is not None:
+        st.fireflyClampThreshold = env.getIntegral() * 4.0
+        st.envMapLuminIntegInv = 1.0 / env.getIntegral()
+    return st

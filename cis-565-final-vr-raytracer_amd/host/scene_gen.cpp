@@ -1,0 +1,414 @@
+// scene_gen.cpp — seeded procedural stand-ins for the assets the benchmark configurations name.
+// The reference's CMake downloads robot_toon.zip / daytime.hdr / std_env.hdr (CMakeLists.txt:51-52) and the README
+// numbers use Sponza and Bistro; none of these exist here and there is no network, so each
+// BASELINE.json config gets a generator with the same triangle count class, material/texture mix, emissive-mesh
+// count and alpha-masked foliage fraction.  Everything is a function of (kind, scale, seed).
+#include "scene.hpp"
+#include <algorithm>
+#include <cmath>
+
+namespace rth {
+namespace {
+
+struct Rng {
+  uint32_t s;
+  explicit Rng(uint32_t seed) : s(seed * 747796405u + 2891336453u) {}
+  uint32_t next() { s = s * 747796405u + 2891336453u; uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u; return (w >> 22u) ^ w; }
+  float uni() { return float(next() >> 8) * (1.0f / 16777216.0f); }
+  float range(float a, float b) { return a + (b - a) * uni(); }
+};
+
+M4 translate(V3 t) { M4 m = M4::identity(); m.at(0, 3) = t.x; m.at(1, 3) = t.y; m.at(2, 3) = t.z; return m; }
+M4 scaleM(V3 s) { M4 m = M4::identity(); m.at(0, 0) = s.x; m.at(1, 1) = s.y; m.at(2, 2) = s.z; return m; }
+M4 rotateY(float a) { M4 m = M4::identity(); float c = std::cos(a), s = std::sin(a); m.at(0, 0) = c; m.at(0, 2) = s; m.at(2, 0) = -s; m.at(2, 2) = c; return m; }
+
+float hashNoise(int x, int y, uint32_t seed)
+{
+  uint32_t h = uint32_t(x) * 374761393u + uint32_t(y) * 668265263u + seed * 2246822519u;
+  h = (h ^ (h >> 13)) * 1274126177u;
+  return float((h ^ (h >> 16)) & 0xffffffu) * (1.0f / 16777215.0f);
+}
+float valueNoise(float x, float y, uint32_t seed)
+{
+  int xi = int(std::floor(x)), yi = int(std::floor(y));
+  float fx = x - xi, fy = y - yi;
+  fx = fx * fx * (3 - 2 * fx); fy = fy * fy * (3 - 2 * fy);
+  float a = hashNoise(xi, yi, seed), b = hashNoise(xi + 1, yi, seed), c = hashNoise(xi, yi + 1, seed), d = hashNoise(xi + 1, yi + 1, seed);
+  return (a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy;
+}
+float fbm(float x, float y, uint32_t seed) { return 0.5f * valueNoise(x, y, seed) + 0.3f * valueNoise(2 * x, 2 * y, seed + 1) + 0.2f * valueNoise(4 * x, 4 * y, seed + 2); }
+
+struct Builder {
+  GltfScene g;
+  Rng rng;
+  uint32_t meshVertexOffset = 0, meshFirstIndex = 0;
+  int meshMaterial = 0;
+  explicit Builder(uint32_t seed) : rng(seed) {}
+
+  int addMaterial(const GltfMaterial& m) { g.materials.push_back(m); return int(g.materials.size()) - 1; }
+  int addTexture(TextureImage&& t) { g.textures.push_back(std::move(t)); return int(g.textures.size()) - 1; }
+
+  void beginMesh(int material) { meshVertexOffset = uint32_t(g.positions.size()); meshFirstIndex = uint32_t(g.indices.size()); meshMaterial = material; }
+  int endMesh()
+  {
+    GltfPrimMesh pm;
+    pm.vertexOffset = meshVertexOffset; pm.vertexCount = uint32_t(g.positions.size()) - meshVertexOffset;
+    pm.firstIndex = meshFirstIndex; pm.indexCount = uint32_t(g.indices.size()) - meshFirstIndex;
+    pm.materialIndex = meshMaterial;
+    g.primMeshes.push_back(pm);
+    return int(g.primMeshes.size()) - 1;
+  }
+  int addNode(int primMesh, const M4& m = M4::identity()) { GltfNode n; n.primMesh = primMesh; n.worldMatrix = m; g.nodes.push_back(n); return int(g.nodes.size()) - 1; }
+
+  uint32_t vert(V3 p, V3 n, float u, float v, V3 t = V3{0, 0, 0})
+  {
+    if(length(t) < 1e-6f) { V3 c1 = cross(n, V3{0, 0, 1}), c2 = cross(n, V3{0, 1, 0}); t = normalize(length(c1) > length(c2) ? c1 : c2); }
+    g.positions.push_back(p); g.normals.push_back(n); g.texcoords0.push_back({u, v});
+    g.tangents.push_back({t.x, t.y, t.z, 1.f}); g.colors0.push_back({1.f, 1.f, 1.f, 1.f});
+    return uint32_t(g.positions.size()) - 1 - meshVertexOffset;
+  }
+  void tri(uint32_t a, uint32_t b, uint32_t c) { g.indices.push_back(a); g.indices.push_back(b); g.indices.push_back(c); }
+
+  // planar quad p0..p3 (any consistent order); wound so that the geometric normal agrees with `n`
+  void quad(V3 p0, V3 p1, V3 p2, V3 p3, V3 n, float uvScale = 1.f)
+  {
+    if(dot(cross(p1 - p0, p2 - p0), n) < 0) std::swap(p1, p3);
+    V3 t = normalize(p1 - p0);
+    uint32_t a = vert(p0, n, 0, 0, t), b = vert(p1, n, uvScale, 0, t), c = vert(p2, n, uvScale, uvScale, t), d = vert(p3, n, 0, uvScale, t);
+    tri(a, b, c); tri(a, c, d);
+  }
+  // axis-aligned box, optionally rotated about Y, faces outward (inward when `inside`)
+  void box(V3 c, V3 h, float rotY = 0.f, bool inside = false, float uvScale = 1.f)
+  {
+    M4 R = rotateY(rotY);
+    auto P = [&](float x, float y, float z) { return xformPoint(R, V3{x * h.x, y * h.y, z * h.z}) + c; };
+    auto N = [&](float x, float y, float z) { V3 n = xformDir(R, V3{x, y, z}); return inside ? n * -1.f : n; };
+    quad(P(-1, -1, 1), P(1, -1, 1), P(1, 1, 1), P(-1, 1, 1), N(0, 0, 1), uvScale);
+    quad(P(-1, -1, -1), P(1, -1, -1), P(1, 1, -1), P(-1, 1, -1), N(0, 0, -1), uvScale);
+    quad(P(1, -1, -1), P(1, -1, 1), P(1, 1, 1), P(1, 1, -1), N(1, 0, 0), uvScale);
+    quad(P(-1, -1, -1), P(-1, -1, 1), P(-1, 1, 1), P(-1, 1, -1), N(-1, 0, 0), uvScale);
+    quad(P(-1, 1, -1), P(1, 1, -1), P(1, 1, 1), P(-1, 1, 1), N(0, 1, 0), uvScale);
+    quad(P(-1, -1, -1), P(1, -1, -1), P(1, -1, 1), P(-1, -1, 1), N(0, -1, 0), uvScale);
+  }
+  // UV sphere with optional noise displacement; nu x nv quads => 2*nu*nv triangles
+  void sphere(V3 c, V3 radii, int nu, int nv, float disp = 0.f, uint32_t seed = 0)
+  {
+    uint32_t base = uint32_t(g.positions.size()) - meshVertexOffset;
+    for(int j = 0; j <= nv; j++)
+      for(int i = 0; i <= nu; i++) {
+        float u = float(i) / nu, v = float(j) / nv;
+        float th = v * 3.14159265f, ph = u * 6.2831853f;
+        V3 n{std::sin(th) * std::cos(ph), std::cos(th), std::sin(th) * std::sin(ph)};
+        float r = 1.f + (disp > 0 ? disp * (fbm(u * 12.f, v * 6.f, seed) - 0.5f) : 0.f);
+        V3 t{-std::sin(ph), 0, std::cos(ph)};
+        vert(V3{n.x * radii.x * r, n.y * radii.y * r, n.z * radii.z * r} + c, n, u * 2.f, v, t);
+      }
+    for(int j = 0; j < nv; j++)
+      for(int i = 0; i < nu; i++) {
+        uint32_t a = base + j * (nu + 1) + i, b = a + 1, d = a + (nu + 1), e = d + 1;
+        tri(a, b, e); tri(a, e, d);
+      }
+  }
+  // cylinder along Y with caps omitted (columns, trunks, poles); ns segments x nr rings
+  void cylinder(V3 c, float radius, float height, int ns, int nr, float flute = 0.f)
+  {
+    uint32_t base = uint32_t(g.positions.size()) - meshVertexOffset;
+    for(int j = 0; j <= nr; j++)
+      for(int i = 0; i <= ns; i++) {
+        float u = float(i) / ns, v = float(j) / nr, ph = u * 6.2831853f;
+        float r = radius * (1.f + flute * std::cos(ph * 12.f)) * (1.f - 0.15f * v);
+        V3 n{std::cos(ph), 0, std::sin(ph)};
+        vert(V3{n.x * r, v * height, n.z * r} + c, n, u * 3.f, v * height, V3{-std::sin(ph), 0, std::cos(ph)});
+      }
+    for(int j = 0; j < nr; j++)
+      for(int i = 0; i < ns; i++) {
+        uint32_t a = base + j * (ns + 1) + i, b = a + 1, d = a + (ns + 1), e = d + 1;
+        tri(a, e, b); tri(a, d, e);
+      }
+  }
+  // height-field grid in the XZ plane (ground, drapes when rotated through `frame`)
+  void grid(V3 origin, V3 ax, V3 az, V3 up, int nx, int nz, float amp, float freq, uint32_t seed, float uvScale)
+  {
+    uint32_t base = uint32_t(g.positions.size()) - meshVertexOffset;
+    auto H = [&](float u, float v) { return amp * (fbm(u * freq, v * freq, seed) - 0.5f); };
+    for(int j = 0; j <= nz; j++)
+      for(int i = 0; i <= nx; i++) {
+        float u = float(i) / nx, v = float(j) / nz, e = 1.f / float(std::max(nx, nz));
+        float h = H(u, v), hx = H(u + e, v), hz = H(u, v + e);
+        V3 p = origin + ax * u + az * v + up * h;
+        V3 dx = ax * e + up * (hx - h), dz = az * e + up * (hz - h);
+        V3 n = normalize(cross(dz, dx));
+        if(dot(n, up) < 0) n = n * -1.f;
+        vert(p, n, u * uvScale, v * uvScale, normalize(ax));
+      }
+    bool flip = dot(cross(ax, az), up) > 0;  // keep CCW as seen from +up
+    for(int j = 0; j < nz; j++)
+      for(int i = 0; i < nx; i++) {
+        uint32_t a = base + j * (nx + 1) + i, b = a + 1, d = a + (nx + 1), e = d + 1;
+        if(flip) { tri(a, b, e); tri(a, e, d); } else { tri(a, e, b); tri(a, d, e); }
+      }
+  }
+};
+
+TextureImage makeTexture(int size, int kind, uint32_t seed, const float tint[3])
+{
+  TextureImage t; t.width = t.height = size; t.bgra.resize(size_t(size) * size * 4);
+  for(int y = 0; y < size; y++)
+    for(int x = 0; x < size; x++) {
+      float u = float(x) / size, v = float(y) / size;
+      float r = 1, g = 1, b = 1, a = 1;
+      switch(kind) {
+        case 0: { float n = 0.55f + 0.45f * fbm(u * 16, v * 16, seed); r = tint[0] * n; g = tint[1] * n; b = tint[2] * n; break; }                 // mottled
+        case 1: { bool c = ((int(u * 8) + int(v * 8)) & 1) != 0; float n = c ? 0.9f : 0.35f; r = tint[0] * n; g = tint[1] * n; b = tint[2] * n; break; }  // checker
+        case 2: {  // bricks
+          float row = std::floor(v * 16), bu = u * 8 + (int(row) & 1) * 0.5f;
+          bool mortar = (v * 16 - row) < 0.08f || (bu - std::floor(bu)) < 0.04f;
+          float n = mortar ? 0.75f : (0.45f + 0.4f * hashNoise(int(std::floor(bu)), int(row), seed));
+          r = mortar ? n : tint[0] * n; g = mortar ? n : tint[1] * n; b = mortar ? n : tint[2] * n; break;
+        }
+        case 3: {  // leaf cut-out: alpha = 1 inside a lobed shape
+          float cx = u - 0.5f, cy = v - 0.5f, rad = std::sqrt(cx * cx + cy * cy), ang = std::atan2(cy, cx);
+          float lim = 0.32f + 0.12f * std::cos(ang * 5.f) + 0.05f * fbm(u * 9, v * 9, seed);
+          a = rad < lim ? 1.f : 0.f;
+          float n = 0.6f + 0.4f * fbm(u * 20, v * 20, seed);
+          r = tint[0] * n; g = tint[1] * n; b = tint[2] * n; break;
+        }
+        case 4: {  // tangent-space normal map from a height field
+          float e = 1.f / size, h0 = fbm(u * 24, v * 24, seed), hx = fbm((u + e) * 24, v * 24, seed), hy = fbm(u * 24, (v + e) * 24, seed);
+          float nx = (h0 - hx) * 6.f, ny = (h0 - hy) * 6.f, nz = 1.f, l = std::sqrt(nx * nx + ny * ny + nz * nz);
+          r = nx / l * 0.5f + 0.5f; g = ny / l * 0.5f + 0.5f; b = nz / l * 0.5f + 0.5f; break;
+        }
+        case 5: { float n = fbm(u * 10, v * 10, seed); r = 1; g = 0.25f + 0.7f * n; b = n > 0.6f ? 1.f : 0.f; break; }  // occlusion/roughness/metallic
+      }
+      uint8_t* p = &t.bgra[(size_t(y) * size + x) * 4];
+      auto q = [](float f) { f = f < 0 ? 0 : (f > 1 ? 1 : f); return uint8_t(f * 255.f + 0.5f); };
+      p[0] = q(b); p[1] = q(g); p[2] = q(r); p[3] = q(a);  // BGRA (scene.cpp:559)
+    }
+  return t;
+}
+
+GltfMaterial diffuse(float r, float g, float b, float rough = 1.f, float metal = 0.f)
+{
+  GltfMaterial m; m.baseColorFactor[0] = r; m.baseColorFactor[1] = g; m.baseColorFactor[2] = b; m.roughnessFactor = rough; m.metallicFactor = metal;
+  return m;
+}
+GltfMaterial emissive(float r, float g, float b)
+{
+  GltfMaterial m = diffuse(0, 0, 0); m.emissiveFactor[0] = r; m.emissiveFactor[1] = g; m.emissiveFactor[2] = b;
+  return m;
+}
+
+// ---- config 2: Cornell box --------------------------------------------------------------------------------
+GltfScene makeCornell()
+{
+  Builder B(1);
+  int white = B.addMaterial(diffuse(0.73f, 0.73f, 0.73f)), red = B.addMaterial(diffuse(0.65f, 0.05f, 0.05f)), green = B.addMaterial(diffuse(0.12f, 0.45f, 0.15f));
+  int light = B.addMaterial(emissive(17.f, 12.f, 4.f));
+  B.beginMesh(white);
+  B.quad({-1, 0, 1}, {1, 0, 1}, {1, 0, -1}, {-1, 0, -1}, {0, 1, 0});   // floor
+  B.quad({-1, 2, 1}, {1, 2, 1}, {1, 2, -1}, {-1, 2, -1}, {0, -1, 0});  // ceiling
+  B.quad({-1, 0, -1}, {1, 0, -1}, {1, 2, -1}, {-1, 2, -1}, {0, 0, 1}); // back wall
+  B.addNode(B.endMesh());
+  B.beginMesh(red); B.quad({-1, 0, -1}, {-1, 0, 1}, {-1, 2, 1}, {-1, 2, -1}, {1, 0, 0}); B.addNode(B.endMesh());
+  B.beginMesh(green); B.quad({1, 0, -1}, {1, 0, 1}, {1, 2, 1}, {1, 2, -1}, {-1, 0, 0}); B.addNode(B.endMesh());
+  B.beginMesh(white); B.box({0.33f, 0.3f, 0.35f}, {0.3f, 0.3f, 0.3f}, -0.3f); B.addNode(B.endMesh());  // short box
+  B.beginMesh(white); B.box({-0.35f, 0.6f, -0.3f}, {0.3f, 0.6f, 0.3f}, 0.3f); B.addNode(B.endMesh());  // tall box
+  B.beginMesh(light); B.quad({-0.25f, 1.98f, -0.25f}, {0.25f, 1.98f, -0.25f}, {0.25f, 1.98f, 0.25f}, {-0.25f, 1.98f, 0.25f}, {0, -1, 0}); B.addNode(B.endMesh());
+  GltfCamera cam; cam.eye = {0, 1, 3.4f}; cam.center = {0, 1, 0}; cam.yfovDeg = 40.f;
+  B.g.cameras.push_back(cam);
+  return std::move(B.g);
+}
+
+// ---- config 1: "DamagedHelmet-class" — one textured, displaced ~70k-triangle mesh -----------------------------
+GltfScene makeHelmet(float scale, uint32_t seed)
+{
+  Builder B(seed);
+  const float tint[3] = {0.8f, 0.7f, 0.6f}, one[3] = {1, 1, 1};
+  GltfMaterial m = diffuse(1, 1, 1, 1.f, 1.f);
+  m.baseColorTexture = B.addTexture(makeTexture(512, 0, seed, tint));
+  m.metallicRoughnessTexture = B.addTexture(makeTexture(512, 5, seed + 3, one));
+  m.normalTexture = B.addTexture(makeTexture(512, 4, seed + 5, one));
+  int mat = B.addMaterial(m);
+  int nu = std::max(8, int(190 * std::sqrt(scale))), nv = std::max(6, int(185 * std::sqrt(scale)));
+  B.beginMesh(mat); B.sphere({0, 0, 0}, {1.f, 1.1f, 1.f}, nu, nv, 0.25f, seed); B.addNode(B.endMesh(), translate({-1, 2, -1}));
+  int lamp = B.addMaterial(emissive(30, 28, 25));
+  B.beginMesh(lamp); B.quad({-2.f, 5.f, -2.f}, {0.f, 5.f, -2.f}, {0.f, 5.f, 0.f}, {-2.f, 5.f, 0.f}, {0, -1, 0}); B.addNode(B.endMesh());
+  GltfCamera cam; cam.eye = {2, 2, -5}; cam.center = {-1, 2, -1}; cam.yfovDeg = 45.f;  // main.cpp:68 default look-at
+  B.g.cameras.push_back(cam);
+  return std::move(B.g);
+}
+
+struct Palette { std::vector<int> opaque; int leaf = 0, glass = 0, lamp = 0, metal = 0; };
+Palette makePalette(Builder& B, int numTextured, int texSize, uint32_t seed, float lampR, float lampG, float lampB)
+{
+  Palette P;
+  const float one[3] = {1, 1, 1};
+  for(int i = 0; i < numTextured; i++) {
+    float tint[3] = {B.rng.range(0.35f, 0.95f), B.rng.range(0.35f, 0.9f), B.rng.range(0.3f, 0.85f)};
+    GltfMaterial m = diffuse(1, 1, 1, B.rng.range(0.2f, 1.f), B.rng.uni() < 0.2f ? 1.f : 0.f);  // SURVEY §8d value distributions
+    m.baseColorTexture = B.addTexture(makeTexture(texSize, i % 3, seed + 11u * i, tint));
+    if(i % 4 == 0) m.normalTexture = B.addTexture(makeTexture(texSize, 4, seed + 101u * i, one));
+    if(i % 5 == 0) m.metallicRoughnessTexture = B.addTexture(makeTexture(texSize, 5, seed + 1001u * i, one));
+    P.opaque.push_back(B.addMaterial(m));
+  }
+  const float leafTint[3] = {0.25f, 0.55f, 0.18f};
+  GltfMaterial leaf = diffuse(1, 1, 1, 0.8f);
+  leaf.baseColorTexture = B.addTexture(makeTexture(texSize / 2, 3, seed + 77, leafTint));
+  leaf.alphaMode = RT_ALPHA_MASK; leaf.alphaCutoff = 0.5f; leaf.doubleSided = 1;
+  P.leaf = B.addMaterial(leaf);
+  GltfMaterial glass = diffuse(0.6f, 0.7f, 0.75f, 0.05f, 1.f);
+  P.glass = B.addMaterial(glass);
+  P.metal = B.addMaterial(diffuse(0.9f, 0.85f, 0.7f, 0.25f, 1.f));
+  P.lamp = B.addMaterial(emissive(lampR, lampG, lampB));
+  return P;
+}
+
+// ---- config 3: "Sponza-class" atrium, ~262k triangles at scale 1 ------------------------------------------------
+GltfScene makeSponza(float scale, uint32_t seed)
+{
+  Builder B(seed);
+  Palette P = makePalette(B, 25, 512, seed, 40.f, 34.f, 26.f);
+  float s = std::sqrt(scale);
+  auto mat = [&](int i) { return P.opaque[size_t(i) % P.opaque.size()]; };
+  B.beginMesh(mat(0)); B.grid({-15, 0, -6}, {30, 0, 0}, {0, 0, 12}, {0, 1, 0}, std::max(2, int(200 * s)), std::max(2, int(100 * s)), 0.04f, 40.f, seed, 30.f); B.addNode(B.endMesh());
+  // enclosing walls (inward-facing box shell without a roof: the sky lights the atrium)
+  B.beginMesh(mat(1));
+  B.quad({-15, 0, -6}, {15, 0, -6}, {15, 10, -6}, {-15, 10, -6}, {0, 0, 1}, 10.f);
+  B.quad({-15, 0, 6}, {15, 0, 6}, {15, 10, 6}, {-15, 10, 6}, {0, 0, -1}, 10.f);
+  B.quad({-15, 0, -6}, {-15, 0, 6}, {-15, 10, 6}, {-15, 10, -6}, {1, 0, 0}, 6.f);
+  B.quad({15, 0, -6}, {15, 0, 6}, {15, 10, 6}, {15, 10, -6}, {-1, 0, 0}, 6.f);
+  B.addNode(B.endMesh());
+  // two storeys of fluted columns: one prim mesh, instanced 48 times
+  B.beginMesh(mat(2)); B.cylinder({0, 0, 0}, 0.35f, 4.2f, std::max(6, int(48 * s)), std::max(2, int(32 * s)), 0.06f); int column = B.endMesh();
+  for(int storey = 0; storey < 2; storey++)
+    for(int i = 0; i < 12; i++)
+      for(int side = 0; side < 2; side++) B.addNode(column, translate({-13.f + i * 2.36f, storey * 4.6f, side ? 4.2f : -4.2f}));
+  // gallery slabs + balustrades
+  B.beginMesh(mat(3));
+  for(int side = 0; side < 2; side++) { B.box({0, 4.4f, side ? 5.1f : -5.1f}, {15, 0.2f, 0.9f}, 0, false, 8.f); B.box({0, 5.1f, side ? 4.25f : -4.25f}, {15, 0.45f, 0.05f}, 0, false, 8.f); }
+  B.addNode(B.endMesh());
+  // drapes: wavy grids hanging between columns
+  for(int k = 0; k < 6; k++) {
+    B.beginMesh(mat(4 + k));
+    int n = std::max(2, int(80 * s));
+    B.grid({-12.f + k * 4.2f, 8.4f, (k & 1) ? 3.6f : -3.6f}, {2.8f, 0, 0}, {0, -3.6f, 0}, {0, 0, 1}, n, n, 0.5f, 5.f, seed + k, 2.f);
+    B.addNode(B.endMesh());
+  }
+  // one emissive mesh (a row of lanterns) — "1 emissive mesh" of config 3
+  B.beginMesh(P.lamp);
+  for(int i = 0; i < 6; i++) B.sphere({-10.f + i * 4.f, 3.6f, 0.f}, {0.18f, 0.18f, 0.18f}, 6, 4);
+  B.addNode(B.endMesh());
+  GltfCamera cam; cam.eye = {-12.5f, 2.2f, 0.6f}; cam.center = {6.f, 3.2f, -0.4f}; cam.yfovDeg = 60.f;
+  B.g.cameras.push_back(cam);
+  return std::move(B.g);
+}
+
+// ---- configs 4/5: "Bistro-class" street / interior ------------------------------------------------------------
+GltfScene makeBistro(bool interior, float scale, uint32_t seed)
+{
+  Builder B(seed);
+  Palette P = interior ? makePalette(B, 30, 512, seed, 26.f, 22.f, 16.f) : makePalette(B, 40, 512, seed, 60.f, 48.f, 30.f);
+  float s = std::sqrt(scale);
+  auto mat = [&](int i) { return P.opaque[size_t(i) % P.opaque.size()]; };
+  const float X = interior ? 10.f : 60.f, Z = interior ? 6.f : 40.f;
+  // ground / floor: displaced grid (cobblestones), the largest single mesh
+  {
+    int nx = std::max(2, int((interior ? 300 : 600) * s)), nz = std::max(2, int((interior ? 200 : 600) * s));
+    B.beginMesh(mat(0)); B.grid({-X, 0, -Z}, {2 * X, 0, 0}, {0, 0, 2 * Z}, {0, 1, 0}, nx, nz, interior ? 0.01f : 0.06f, interior ? 30.f : 150.f, seed, interior ? 10.f : 60.f);
+    B.addNode(B.endMesh());
+  }
+  if(interior) {
+    B.beginMesh(mat(1)); B.box({0, 2.f, 0}, {X, 2.f, Z}, 0.f, true, 6.f); B.addNode(B.endMesh());  // room shell, facing inward
+  } else {
+    // buildings along both sides of the street: facade with window frames
+    int nb = std::max(2, int(24 * scale + 0.5f));
+    for(int b = 0; b < nb; b++) {
+      float bx = -X + 6.f + (b / 2) * (2 * X - 12.f) / std::max(1, nb / 2 - 1 + (nb / 2 == 1)), bz = (b & 1) ? 14.f : -14.f;
+      float hw = B.rng.range(3.5f, 4.8f), hh = B.rng.range(6.f, 11.f), hd = B.rng.range(4.f, 6.f);
+      B.beginMesh(mat(2 + b)); B.box({bx, hh, bz}, {hw, hh, hd}, 0.f, false, 4.f); B.addNode(B.endMesh());
+      B.beginMesh(mat(7 + b));
+      int floors = std::max(1, int(10 * s)), cols = std::max(1, int(12 * s));
+      float face = (b & 1) ? bz - hd : bz + hd, dir = (b & 1) ? -1.f : 1.f;
+      for(int f = 0; f < floors; f++)
+        for(int c = 0; c < cols; c++) {
+          float wx = bx - hw + (c + 0.5f) * 2 * hw / cols, wy = (f + 0.6f) * 2 * hh / floors, ww = 0.7f * hw / cols, wh = 0.6f * hh / floors;
+          B.box({wx - ww, wy, face + dir * 0.06f}, {0.04f, wh, 0.06f});
+          B.box({wx + ww, wy, face + dir * 0.06f}, {0.04f, wh, 0.06f});
+          B.box({wx, wy - wh, face + dir * 0.06f}, {ww, 0.04f, 0.08f});
+          B.box({wx, wy + wh, face + dir * 0.06f}, {ww, 0.04f, 0.06f});
+        }
+      B.addNode(B.endMesh());
+      B.beginMesh(P.glass);
+      for(int f = 0; f < floors; f++)
+        for(int c = 0; c < cols; c++) {
+          float wx = bx - hw + (c + 0.5f) * 2 * hw / cols, wy = (f + 0.6f) * 2 * hh / floors, ww = 0.7f * hw / cols, wh = 0.6f * hh / floors, z = face + dir * 0.02f;
+          B.quad({wx - ww, wy - wh, z}, {wx + ww, wy - wh, z}, {wx + ww, wy + wh, z}, {wx - ww, wy + wh, z}, {0, 0, dir});
+        }
+      B.addNode(B.endMesh());
+    }
+    // trees: 4 prim meshes (trunk + alpha-masked leaf quads), instanced — ~10 % of all triangles
+    int leafQuads = std::max(8, int(3000 * scale));
+    int treeMesh[4], trunkMesh;
+    B.beginMesh(mat(3)); B.cylinder({0, 0, 0}, 0.22f, 3.2f, std::max(5, int(24 * s)), std::max(2, int(20 * s))); trunkMesh = B.endMesh();
+    for(int t = 0; t < 4; t++) {
+      B.beginMesh(P.leaf);
+      for(int q = 0; q < leafQuads; q++) {
+        float th = B.rng.range(0, 3.14159f), ph = B.rng.range(0, 6.28318f), r = 1.7f * std::cbrt(B.rng.uni());
+        V3 c{r * std::sin(th) * std::cos(ph), 4.2f + r * std::cos(th) * 0.8f, r * std::sin(th) * std::sin(ph)};
+        V3 n = normalize(V3{B.rng.range(-1, 1), B.rng.range(-0.3f, 1), B.rng.range(-1, 1)});
+        V3 t1 = normalize(cross(n, V3{0.3f, 1, 0.2f})), t2 = cross(n, t1);
+        float sz = B.rng.range(0.12f, 0.22f);
+        B.quad(c - t1 * sz - t2 * sz, c + t1 * sz - t2 * sz, c + t1 * sz + t2 * sz, c - t1 * sz + t2 * sz, n);
+      }
+      treeMesh[t] = B.endMesh();
+    }
+    int nt = std::max(2, int(40 * scale + 0.5f));
+    for(int t = 0; t < nt; t++) {
+      M4 m = translate({-X + 5.f + t * (2 * X - 10.f) / nt, 0, (t & 1) ? 7.5f : -7.5f}) * rotateY(B.rng.range(0, 6.28f)) * scaleM({1, B.rng.range(0.85f, 1.2f), 1});
+      B.addNode(trunkMesh, m); B.addNode(treeMesh[t & 3], m);
+    }
+  }
+  // lamps: emissive meshes (street lamps outside, ~30 ceiling lamps inside: config 5)
+  {
+    int nl = interior ? std::max(2, int(30 * std::min(1.f, scale * 4))) : std::max(2, int(40 * std::min(1.f, scale * 4)));
+    for(int l = 0; l < nl; l++) {
+      float lx = -X + 3.f + (l + 0.5f) * (2 * X - 6.f) / nl, lz = interior ? ((l % 3) - 1) * 3.2f : ((l & 1) ? 5.2f : -5.2f), ly = interior ? 3.6f : 4.4f;
+      B.beginMesh(P.lamp); B.sphere({lx, ly, lz}, {0.16f, 0.12f, 0.16f}, interior ? 8 : 6, 4); B.addNode(B.endMesh());
+      if(!interior) { B.beginMesh(P.metal); B.cylinder({lx, 0, lz}, 0.05f, 4.3f, 8, 2); B.addNode(B.endMesh()); }
+    }
+  }
+  // props (chairs / bikes / crockery stand-ins): high-resolution blobs, the bulk of the triangle count
+  {
+    int np = std::max(2, int((interior ? 200 : 300) * s)), nu = std::max(6, int(50 * s)), nv = std::max(4, int(40 * s));
+    int meshes[8];
+    for(int k = 0; k < 8; k++) { B.beginMesh(k == 7 ? P.metal : mat(11 + k)); B.sphere({0, 0, 0}, {1.f, 0.7f + 0.1f * k, 1.f}, nu, nv, 0.35f, seed + 31u * k); meshes[k] = B.endMesh(); }
+    for(int p = 0; p < np; p++) {
+      float r = B.rng.range(0.15f, interior ? 0.45f : 0.7f);
+      V3 pos{B.rng.range(-X + 1.f, X - 1.f), r * 0.8f, interior ? B.rng.range(-Z + 1.f, Z - 1.f) : B.rng.range(-6.5f, 6.5f)};
+      float sgn = (p % 11 == 0) ? -1.f : 1.f;  // a few mirrored instances (negative determinant)
+      B.addNode(meshes[p & 7], translate(pos) * rotateY(B.rng.range(0, 6.28f)) * scaleM({r * sgn, r, r}));
+    }
+  }
+  GltfCamera cam;
+  if(interior) { cam.eye = {-8.5f, 1.7f, 4.5f}; cam.center = {2.f, 1.2f, -1.f}; cam.yfovDeg = 65.f; }
+  else { cam.eye = {-52.f, 2.4f, 1.5f}; cam.center = {10.f, 4.5f, -1.f}; cam.yfovDeg = 60.f; }
+  B.g.cameras.push_back(cam);
+  return std::move(B.g);
+}
+
+}  // namespace
+
+GltfScene makeProceduralScene(ProcScene kind, float scale, uint32_t seed)
+{
+  scale = std::min(1.f, std::max(1e-4f, scale));
+  switch(kind) {
+    case PROC_CORNELL: return makeCornell();
+    case PROC_HELMET: return makeHelmet(scale, seed);
+    case PROC_SPONZA: return makeSponza(scale, seed);
+    case PROC_BISTRO_EXT: return makeBistro(false, scale, seed);
+    case PROC_BISTRO_INT: return makeBistro(true, scale, seed);
+  }
+  return makeCornell();
+}
+
+}  // namespace rth

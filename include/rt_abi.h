@@ -1,0 +1,341 @@
+/*
+ * rt_abi.h — data contract + C-ABI of librestir_hip.so (MI355X / gfx950 ReSTIR DI+GI frame path).
+ *
+ * This header is the drop-in boundary for the per-frame hot path of
+ * IwakuraRein/CIS-565-Final-VR-Raytracer.  It replaces two reference interfaces:
+ *
+ *   (1) the host<->shader data contract   shaders/host_device.h:153-333
+ *       (RtxState push constant, SceneCamera UBO, VertexAttributes, GltfShadeMaterial,
+ *        reservoirs, light records, ImptSampData).  Every POD below has the same field
+ *        order and the same byte size as the reference struct it cites (GLSL `scalar`
+ *        block layout == tightly packed C), checked by static_assert at the bottom.
+ *
+ *   (2) the Vulkan plumbing inside Renderer / Scene / AccelStructure / HdrSampling
+ *       (src/renderer.cpp:97-237, src/scene.cpp:57-125, src/accelstruct.cpp:55-162,
+ *        src/hdr_sampling.cpp:56-99): buffer creation + vkCmdDispatch sequences become
+ *       the extern "C" calls at the bottom.
+ *
+ * Plain C: pointers and sizes only, no C++/torch types.  All calls return 0 on success or a
+ * negative rt_status; the message is available from rt_last_error().  Nothing throws.
+ */
+#ifndef RT_ABI_H
+#define RT_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------------
+ * Small POD vector types (nvmath::vecNf stand-ins; column-major mat4 like nvmath::mat4f)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { float x, y; } rt_vec2;
+typedef struct { float x, y, z; } rt_vec3;
+typedef struct { float x, y, z, w; } rt_vec4;
+typedef struct { int32_t x, y; } rt_ivec2;
+typedef struct { float m[16]; } rt_mat4; /* column-major: m[c*4+r] */
+
+/* ------------------------------------------------------------------------------------------------
+ * host_device.h mirrors
+ * ---------------------------------------------------------------------------------------------- */
+
+/* host_device.h:128-139 */
+enum rt_debug_mode {
+  RT_DBG_NONE = 0, RT_DBG_DIRECT_STAGE = 1, RT_DBG_INDIRECT_STAGE = 2, RT_DBG_BASECOLOR = 3, RT_DBG_NORMAL = 4,
+  RT_DBG_DEPTH = 5, RT_DBG_METALLIC = 6, RT_DBG_EMISSIVE = 7, RT_DBG_ROUGHNESS = 8, RT_DBG_TEXCOORD = 9
+};
+
+/* host_device.h:142-148 */
+enum rt_restir_state { RT_RESTIR_NONE = 0, RT_RESTIR_RIS = 1, RT_RESTIR_SPATIAL = 2, RT_RESTIR_TEMPORAL = 3, RT_RESTIR_SPATIOTEMPORAL = 4 };
+
+#define RT_ALPHA_OPAQUE 0 /* host_device.h:179-181 */
+#define RT_ALPHA_MASK 1
+#define RT_ALPHA_BLEND 2
+#define RT_MAX_IOR_MINUS_ONE 3.0f /* host_device.h:182 */
+#define RT_INFINITY 1e28f         /* globals.glsl:35 */
+#define RT_INVALID_MAT_ID 0xff000000u /* globals.glsl:106 */
+
+/* host_device.h:153-165 — 336 B */
+typedef struct {
+  rt_mat4 viewInverse;
+  rt_mat4 projInverse;
+  rt_mat4 projView;
+  rt_mat4 lastView;
+  rt_mat4 lastProjView;
+  rt_vec3 lastPosition;
+  int32_t nbLights;
+} rt_scene_camera;
+
+/* host_device.h:167-174 — 32 B; packed by scene.cpp:236-258 */
+typedef struct {
+  rt_vec3 position;
+  uint32_t normal;   /* oct-compressed (compress.glsl:111-139) */
+  rt_vec2 texcoord;  /* LSB of .y = tangent handedness */
+  uint32_t tangent;  /* oct-compressed */
+  uint32_t color;    /* unorm8 x4 */
+} rt_vertex;
+
+/* host_device.h:183-204 — 80 B */
+typedef struct {
+  rt_vec4 pbrBaseColorFactor;
+  int32_t pbrBaseColorTexture;
+  float pbrMetallicFactor;
+  float pbrRoughnessFactor;
+  int32_t pbrMetallicRoughnessTexture;
+  int32_t emissiveTexture;
+  rt_vec3 emissiveFactor;
+  int32_t normalTexture;
+  float normalTextureScale;
+  float transmissionFactor;
+  int32_t transmissionTexture;
+  float ior;
+  int32_t alphaMode;
+  float alphaCutoff;
+  int32_t pad;
+} rt_material;
+
+/* host_device.h:207-238 — 100 B push constant, passed by value to every stage */
+typedef struct {
+  int32_t frame;
+  int32_t maxDepth;
+  int32_t modulate;
+  float fireflyClampThreshold;
+  float hdrMultiplier;
+  int32_t debugging_mode;
+  float environmentProb;
+  uint32_t time; /* RNG seed input; wall-clock ms in the reference (sample_example.cpp:402), explicit here */
+  int32_t ReSTIRState;
+  int32_t RISSampleNum;
+  int32_t reservoirClamp;
+  int32_t accumulate;
+  rt_ivec2 size;
+  float envMapLuminIntegInv;
+  float lightLuminIntegInv;
+  int32_t MIS;
+  float sigLuminDirect;
+  float sigNormalDirect;
+  float sigDepthDirect;
+  int32_t denoise;
+  float sigLuminIndirect;
+  float sigNormalIndirect;
+  float sigDepthIndirect;
+  int32_t denoiseLevel;
+} rt_state;
+
+/* host_device.h:260-264 — 28 B */
+typedef struct { rt_vec3 Li; rt_vec3 wi; float dist; } rt_light_sample;
+/* host_device.h:266-271 — 64 B */
+typedef struct { rt_vec3 L; rt_vec3 xv, nv; rt_vec3 xs, ns; float pHat; } rt_gi_sample;
+/* host_device.h:273-277 — 36 B */
+typedef struct { rt_light_sample lightSample; uint32_t num; float weight; } rt_direct_reservoir;
+/* host_device.h:279-284 — 76 B */
+typedef struct { rt_gi_sample giSample; uint32_t num; float weight; float bigW; } rt_indirect_reservoir;
+
+/* host_device.h:287-293 — 16 B */
+typedef struct { int32_t alias; float q; float pdf; float aliasPdf; } rt_impt_samp;
+
+/* host_device.h:295-312 — 80 B */
+typedef struct {
+  int32_t type; rt_vec3 direction;
+  float intensity; rt_vec3 color;
+  rt_vec3 position; float range;
+  float outerConeCos; float innerConeCos; rt_vec2 padding;
+  rt_impt_samp impSamp;
+} rt_punc_light;
+
+/* host_device.h:314-325 — 96 B */
+typedef struct {
+  uint32_t matIndex; uint32_t transformIndex;
+  rt_vec3 v0, v1, v2;
+  rt_vec2 uv0, uv1, uv2;
+  rt_impt_samp impSamp;
+  rt_vec3 pad;
+} rt_trig_light;
+
+/* host_device.h:327-333 — 16 B */
+typedef struct { uint32_t puncLightSize; uint32_t trigLightSize; float trigSampProb; int32_t pad; } rt_light_buf_info;
+
+/* ------------------------------------------------------------------------------------------------
+ * Scene description handed to rt_upload_scene.  The reference hands the same content to Vulkan as
+ * one vertex + one index VkBuffer per glTF primitive mesh (scene.cpp:209-289), an InstanceData table
+ * with buffer device addresses (host_device.h:242-247, scene.cpp:179-195), one TLAS instance per node
+ * (accelstruct.cpp:132-162), a material SSBO, a texture array, light SSBOs and the env texture + alias
+ * table (hdr_sampling.cpp:56-99).  Device addresses become offsets into two shared arrays.
+ * All arrays are copied by rt_upload_scene; the caller keeps ownership.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* one per glTF primitive mesh == one reference BLAS + one InstanceData row (index = instanceCustomIndex) */
+typedef struct {
+  uint32_t vertexOffset; /* into rt_scene_desc.vertices */
+  uint32_t vertexCount;
+  uint32_t firstIndex;   /* into rt_scene_desc.indices; indices are relative to vertexOffset */
+  uint32_t indexCount;   /* multiple of 3 */
+  int32_t materialIndex;
+} rt_prim_mesh;
+
+/* accelstruct.cpp:145-149 */
+#define RT_INST_FORCE_OPAQUE 1u /* VK_GEOMETRY_INSTANCE_FORCE_OPAQUE_BIT_KHR */
+#define RT_INST_CULL_DISABLE 2u /* VK_GEOMETRY_INSTANCE_TRIANGLE_FACING_CULL_DISABLE_BIT_KHR */
+
+/* one per drawable glTF node == one reference TLAS instance */
+typedef struct {
+  float objectToWorld[12]; /* 3 rows x 4 cols, row-major (VkTransformMatrixKHR, accelstruct.cpp:152) */
+  uint32_t primMesh;       /* instanceCustomIndex */
+  uint32_t flags;          /* RT_INST_* */
+} rt_instance;
+
+/* glTF sampler enums kept as glTF integers (scene.cpp:513-548) */
+#define RT_WRAP_REPEAT 10497
+#define RT_WRAP_CLAMP 33071
+#define RT_WRAP_MIRROR 33648
+#define RT_FILTER_NEAREST 9728
+#define RT_FILTER_LINEAR 9729
+
+/* VK_FORMAT_B8G8R8A8_UNORM texels, LOD 0 only (scene.cpp:559, 598 — mip generation is commented out) */
+typedef struct {
+  const uint8_t* bgra8;
+  int32_t width, height;
+  int32_t wrapS, wrapT; /* RT_WRAP_* */
+  int32_t magFilter;    /* RT_FILTER_*; compute shaders sample LOD 0 => mag filter applies */
+  int32_t pad;
+} rt_texture;
+
+typedef struct {
+  uint32_t numPrimMeshes;  const rt_prim_mesh* primMeshes;
+  uint64_t numVertices;    const rt_vertex* vertices;
+  uint64_t numIndices;     const uint32_t* indices;
+  uint32_t numInstances;   const rt_instance* instances;
+  uint32_t numMaterials;   const rt_material* materials;
+  uint32_t numTextures;    const rt_texture* textures;
+  const rt_punc_light* puncLights;  /* lightInfo.puncLightSize entries (may be NULL when 0) */
+  const rt_trig_light* trigLights;  /* lightInfo.trigLightSize entries (may be NULL when 0) */
+  rt_light_buf_info lightInfo;
+  int32_t envWidth, envHeight;      /* RGBA32F lat-long map, U repeat / V clamp, bilinear (hdr_sampling.cpp:69-77) */
+  const float* envRgba32f;          /* envWidth*envHeight*4 floats; NULL => 1x1 black */
+  const rt_impt_samp* envAccel;     /* envWidth*envHeight entries (hdr_sampling.cpp:181-242); NULL when no env */
+} rt_scene_desc;
+
+/* ------------------------------------------------------------------------------------------------
+ * Screen-space buffers owned by the context (renderer.cpp:227-302, render_output.cpp:82-148).
+ * Reference element layouts are kept at the boundary (readback/upload use them verbatim).
+ * ---------------------------------------------------------------------------------------------- */
+typedef enum {
+  RT_BUF_GBUFFER0 = 0,        /* RGBA32UI 16 B/px (renderer.hpp:88)              */
+  RT_BUF_GBUFFER1 = 1,
+  RT_BUF_MOTION = 2,          /* RG16_SINT 4 B/px (renderer.hpp:94)               */
+  RT_BUF_DIRECT_RESV0 = 3,    /* rt_direct_reservoir 36 B/px (renderer.cpp:229)   */
+  RT_BUF_DIRECT_RESV1 = 4,
+  RT_BUF_DIRECT_RESV_TEMP = 5,
+  RT_BUF_INDIRECT_RESV0 = 6,  /* rt_indirect_reservoir 76 B/half-px               */
+  RT_BUF_INDIRECT_RESV1 = 7,
+  RT_BUF_INDIRECT_RESV_TEMP = 8,
+  RT_BUF_DENOISE_DIR_A = 9,   /* RGBA32F 16 B/px (renderer.cpp:267-285)           */
+  RT_BUF_DENOISE_DIR_B = 10,
+  RT_BUF_DENOISE_IND_A = 11,  /* RGBA32F, allocated full-res, top-left quarter used */
+  RT_BUF_DENOISE_IND_B = 12,
+  RT_BUF_DIRECT_RESULT0 = 13, /* RGBA32F 16 B/px (render_output.cpp:104-133)      */
+  RT_BUF_DIRECT_RESULT1 = 14,
+  RT_BUF_INDIRECT_RESULT0 = 15,
+  RT_BUF_INDIRECT_RESULT1 = 16,
+  RT_BUF_LIGHT_ID0 = 17,      /* u32/px, ping-pong like the reservoirs: id of the light sample held by the direct
+                                 reservoir (0x80000000|env texel, 0x40000000|triangle light, 0x20000000|punctual light,
+                                 0xffffffff none).  Added for the "reservoir sample indices bit-exact" check of
+                                 BASELINE.json; the reference stores the sample itself, not an index. */
+  RT_BUF_LIGHT_ID1 = 18,
+  RT_BUF_COUNT = 19
+} rt_buffer_id;
+
+/* per-frame stage selector for rt_run_stage — the dispatch list of renderer.cpp:163-205 */
+typedef enum {
+  RT_STAGE_DIRECT = 0,           /* direct_stage.comp  (live)                    */
+  RT_STAGE_INDIRECT = 1,         /* indirect_stage.comp, half resolution         */
+  RT_STAGE_DENOISE_DIRECT = 2,   /* denoise_direct.comp, level 0..3              */
+  RT_STAGE_DENOISE_INDIRECT = 3, /* denoise_indirect.comp, level 0..4            */
+  RT_STAGE_COMPOSE = 4,          /* compose.comp                                 */
+  RT_STAGE_DIRECT_GEN = 5,       /* direct_gen.comp   (compiled, not dispatched: renderer.cpp:166-168) */
+  RT_STAGE_DIRECT_REUSE = 6,     /* direct_reuse.comp (compiled, not dispatched: renderer.cpp:170-171) */
+  RT_STAGE_COUNT = 7
+} rt_stage_id;
+
+typedef struct {
+  uint64_t closestHitRays;   /* ClosestHit() invocations (traceray_rq.glsl:108)  */
+  uint64_t anyHitRays;       /* AnyHit() invocations (traceray_rq.glsl:153)      */
+  uint64_t nodesVisited;     /* BVH8 nodes fetched (80 B each)                   */
+  uint64_t trisTested;       /* triangle records fetched (48 B + 8 B each)       */
+  uint64_t hitsShaded;       /* GetState() invocations (108 B gather + 80 B material) */
+  uint64_t risCandidates;    /* SampleDirectLightNoVisibility() invocations      */
+  float stageMs[RT_STAGE_COUNT]; /* last frame, HIP events on the ctx stream (denoise = sum of levels) */
+  float frameMs;
+} rt_counters;
+
+typedef enum {
+  RT_OK = 0,
+  RT_ERR_INVALID_ARG = -1,
+  RT_ERR_NO_DEVICE = -2,
+  RT_ERR_HIP = -3,
+  RT_ERR_NO_SCENE = -4,
+  RT_ERR_NO_ACCEL = -5,
+  RT_ERR_NO_TARGET = -6,
+  RT_ERR_OOM = -7
+} rt_status;
+
+typedef struct rt_ctx rt_ctx;
+
+/* Renderer::setup (renderer.cpp:62-73): bind to HIP device `device`, create the stream + events. */
+int rt_create(rt_ctx** out, int device);
+/* Renderer::destroy + Scene::destroy + AccelStructure::destroy (renderer.cpp:75-91). */
+int rt_destroy(rt_ctx* ctx);
+/* Run every later launch on a caller-owned hipStream_t (NULL = ctx-owned stream). Lets the caller
+ * order RCCL halo exchanges with the stages without host syncs. */
+int rt_set_stream(rt_ctx* ctx, void* hipStream);
+/* Scene::load's buffer uploads (scene.cpp:94-112) + HdrSampling::loadEnvironment upload (hdr_sampling.cpp:79-95). */
+int rt_upload_scene(rt_ctx* ctx, const rt_scene_desc* scene);
+/* AccelStructure::create (accelstruct.cpp:55-65): host-built flat BVH8 over world-space triangles. */
+int rt_build_accel(rt_ctx* ctx);
+/* Renderer::create / Renderer::update (renderer.cpp:97-148, 209-225): (re)allocate all screen-space buffers, zeroed. */
+int rt_resize(rt_ctx* ctx, int width, int height);
+/* Scene::updateCamera's vkCmdUpdateBuffer (scene.cpp:777-811). */
+int rt_set_camera(rt_ctx* ctx, const rt_scene_camera* cam);
+/* Renderer::run (renderer.cpp:154-206): the 12 dispatches of one frame. `frames` selects the ping-pong
+ * side exactly like m_descSet[(frames+1)%2] (renderer.cpp:157, 346-356): this = [frames&1], last = [(frames+1)&1]. */
+int rt_render_frame(rt_ctx* ctx, const rt_state* state, int frames);
+/* One dispatch of the list above, restricted to pixel rows [rowBegin,rowEnd) of the stage's own grid
+ * (full-res rows for direct/denoise_direct/compose, half-res rows for indirect/denoise_indirect).
+ * rowEnd <= 0 means "all rows".  Used for row-tiled multi-GPU frames. */
+int rt_run_stage(rt_ctx* ctx, const rt_state* state, int frames, int stage, int level, int rowBegin, int rowEnd);
+/* Copy a screen-space buffer to / from host memory in the reference element layout. Synchronous. */
+int rt_readback(rt_ctx* ctx, int buffer, void* dst, size_t bytes);
+int rt_upload_history(rt_ctx* ctx, int buffer, const void* src, size_t bytes);
+/* Size in bytes of a buffer's boundary layout at the current resolution. */
+size_t rt_buffer_bytes(rt_ctx* ctx, int buffer);
+/* Raw device pointer of a buffer's device-side storage (+ its byte size and bytes per row of the stage grid),
+ * for RCCL halo exchange by the caller.  Device-side layout == boundary layout. */
+int rt_device_ptr(rt_ctx* ctx, int buffer, void** ptr, size_t* bytes, size_t* rowPitch);
+/* Enable (1) / disable (0) traversal + gather counting for subsequent frames (slower, instrumented kernels). */
+int rt_set_counting(rt_ctx* ctx, int enable);
+int rt_get_counters(rt_ctx* ctx, rt_counters* out);
+/* Wait for all work on the ctx stream. */
+int rt_sync(rt_ctx* ctx);
+/* Last error message of this ctx (or of rt_create when ctx == NULL). Never NULL. */
+const char* rt_last_error(rt_ctx* ctx);
+/* ABI version: (major<<16)|minor */
+uint32_t rt_abi_version(void);
+
+#ifdef __cplusplus
+} /* extern "C" */
+
+static_assert(sizeof(rt_scene_camera) == 336, "SceneCamera host_device.h:153-165");
+static_assert(sizeof(rt_vertex) == 32, "VertexAttributes host_device.h:167-174");
+static_assert(sizeof(rt_material) == 80, "GltfShadeMaterial host_device.h:183-204");
+static_assert(sizeof(rt_state) == 100, "RtxState host_device.h:207-238");
+static_assert(sizeof(rt_direct_reservoir) == 36, "DirectReservoir host_device.h:273-277");
+static_assert(sizeof(rt_indirect_reservoir) == 76, "IndirectReservoir host_device.h:279-284");
+static_assert(sizeof(rt_impt_samp) == 16, "ImptSampData host_device.h:287-293");
+static_assert(sizeof(rt_punc_light) == 80, "PuncLight host_device.h:295-312");
+static_assert(sizeof(rt_trig_light) == 96, "TrigLight host_device.h:314-325");
+static_assert(sizeof(rt_light_buf_info) == 16, "LightBufInfo host_device.h:327-333");
+#endif
+
+#endif /* RT_ABI_H */

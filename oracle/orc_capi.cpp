@@ -1,0 +1,202 @@
+// orc_capi.cpp — ctypes-facing C entry points of the CPU oracle (liboracle.so).
+// TEST INFRASTRUCTURE: loaded only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+#include "orc_stages.h"
+#include <cstdio>
+#include <thread>
+
+using namespace orc;
+
+namespace {
+struct Ctx {
+  Scene scene;
+  Frame frame;
+  bool haveScene = false;
+};
+template <class T> size_t vbytes(const std::vector<T>& v) { return v.size() * sizeof(T); }
+
+void* bufPtr(Ctx* c, int id, size_t& bytes)
+{
+  Frame& f = c->frame;
+  switch(id) {
+    case RT_BUF_GBUFFER0: bytes = vbytes(f.gbuffer[0]); return f.gbuffer[0].data();
+    case RT_BUF_GBUFFER1: bytes = vbytes(f.gbuffer[1]); return f.gbuffer[1].data();
+    case RT_BUF_MOTION: bytes = vbytes(f.motion); return f.motion.data();
+    case RT_BUF_DIRECT_RESV0: bytes = vbytes(f.directResv[0]); return f.directResv[0].data();
+    case RT_BUF_DIRECT_RESV1: bytes = vbytes(f.directResv[1]); return f.directResv[1].data();
+    case RT_BUF_DIRECT_RESV_TEMP: bytes = vbytes(f.directResvTemp); return f.directResvTemp.data();
+    case RT_BUF_INDIRECT_RESV0: bytes = vbytes(f.indirectResv[0]); return f.indirectResv[0].data();
+    case RT_BUF_INDIRECT_RESV1: bytes = vbytes(f.indirectResv[1]); return f.indirectResv[1].data();
+    case RT_BUF_INDIRECT_RESV_TEMP: bytes = vbytes(f.indirectResvTemp); return f.indirectResvTemp.data();
+    case RT_BUF_DENOISE_DIR_A: bytes = vbytes(f.denoiseTemp[0]); return f.denoiseTemp[0].data();
+    case RT_BUF_DENOISE_DIR_B: bytes = vbytes(f.denoiseTemp[1]); return f.denoiseTemp[1].data();
+    case RT_BUF_DENOISE_IND_A: bytes = vbytes(f.denoiseTemp[2]); return f.denoiseTemp[2].data();
+    case RT_BUF_DENOISE_IND_B: bytes = vbytes(f.denoiseTemp[3]); return f.denoiseTemp[3].data();
+    case RT_BUF_DIRECT_RESULT0: bytes = vbytes(f.directResult[0]); return f.directResult[0].data();
+    case RT_BUF_DIRECT_RESULT1: bytes = vbytes(f.directResult[1]); return f.directResult[1].data();
+    case RT_BUF_INDIRECT_RESULT0: bytes = vbytes(f.indirectResult[0]); return f.indirectResult[0].data();
+    case RT_BUF_INDIRECT_RESULT1: bytes = vbytes(f.indirectResult[1]); return f.indirectResult[1].data();
+    case RT_BUF_LIGHT_ID0: bytes = vbytes(f.lightId2[0]); return f.lightId2[0].data();
+    case RT_BUF_LIGHT_ID1: bytes = vbytes(f.lightId2[1]); return f.lightId2[1].data();
+  }
+  bytes = 0;
+  return nullptr;
+}
+}  // namespace
+
+extern "C" {
+
+void* orc_create(int threads)
+{
+  Ctx* c = new Ctx();
+  if(threads <= 0) threads = int(std::thread::hardware_concurrency());
+  c->frame.threads = threads > 0 ? threads : 1;
+  c->frame.scene = &c->scene;
+  return c;
+}
+void orc_destroy(void* p) { delete static_cast<Ctx*>(p); }
+int orc_threads(void* p) { return static_cast<Ctx*>(p)->frame.threads; }
+int orc_upload_scene(void* p, const rt_scene_desc* d)
+{
+  Ctx* c = static_cast<Ctx*>(p);
+  if(!d) return RT_ERR_INVALID_ARG;
+  c->scene.upload(d);
+  c->scene.build();
+  c->haveScene = true;
+  return RT_OK;
+}
+int orc_resize(void* p, int w, int h)
+{
+  if(w <= 0 || h <= 0) return RT_ERR_INVALID_ARG;
+  static_cast<Ctx*>(p)->frame.resize(w, h);
+  return RT_OK;
+}
+int orc_set_camera(void* p, const rt_scene_camera* cam) { static_cast<Ctx*>(p)->frame.cam = *cam; return RT_OK; }
+int orc_render_frame(void* p, const rt_state* st, int frames)
+{
+  Ctx* c = static_cast<Ctx*>(p);
+  if(!c->haveScene) return RT_ERR_NO_SCENE;
+  if(st->size.x != c->frame.W || st->size.y != c->frame.H) return RT_ERR_NO_TARGET;
+  c->frame.renderFrame(*st, frames);
+  return RT_OK;
+}
+int orc_run_stage(void* p, const rt_state* st, int frames, int stage, int level, int rowBegin, int rowEnd)
+{
+  Ctx* c = static_cast<Ctx*>(p);
+  if(!c->haveScene) return RT_ERR_NO_SCENE;
+  if(st->size.x != c->frame.W || st->size.y != c->frame.H) return RT_ERR_NO_TARGET;
+  c->frame.runStage(*st, frames, stage, level, rowBegin, rowEnd);
+  return RT_OK;
+}
+size_t orc_buffer_bytes(void* p, int id) { size_t b; bufPtr(static_cast<Ctx*>(p), id, b); return b; }
+int orc_readback(void* p, int id, void* dst, size_t bytes)
+{
+  size_t b; void* src = bufPtr(static_cast<Ctx*>(p), id, b);
+  if(!src || bytes != b) return RT_ERR_INVALID_ARG;
+  memcpy(dst, src, b);
+  return RT_OK;
+}
+int orc_upload_history(void* p, int id, const void* src, size_t bytes)
+{
+  size_t b; void* dst = bufPtr(static_cast<Ctx*>(p), id, b);
+  if(!dst || bytes != b) return RT_ERR_INVALID_ARG;
+  memcpy(dst, src, b);
+  return RT_OK;
+}
+int orc_get_counters(void* p, rt_counters* out)
+{
+  Ctx* c = static_cast<Ctx*>(p);
+  memset(out, 0, sizeof(*out));
+  out->closestHitRays = c->scene.counters.closestHitRays; out->anyHitRays = c->scene.counters.anyHitRays;
+  out->nodesVisited = c->scene.counters.nodesVisited; out->trisTested = c->scene.counters.trisTested;
+  out->hitsShaded = c->scene.counters.hitsShaded; out->risCandidates = c->scene.counters.risCandidates;
+  return RT_OK;
+}
+void orc_reset_counters(void* p) { static_cast<Ctx*>(p)->scene.counters.reset(); }
+uint64_t orc_num_triangles(void* p) { return static_cast<Ctx*>(p)->scene.tris.size(); }
+
+// ---- ray-level access for traversal parity tests ----------------------------------------------------------
+// rays: n x {ox,oy,oz,dx,dy,dz,tmax,seedbits}; out: n x {t, tri(u32 bits), u, v}
+void orc_trace_closest(void* p, int n, const float* rays, float* out)
+{
+  Ctx* c = static_cast<Ctx*>(p);
+  for(int i = 0; i < n; i++) {
+    const float* r = rays + 8 * i;
+    Hit h = c->scene.closestHit(V3(r[0], r[1], r[2]), V3(r[3], r[4], r[5]), rt_f2u(r[7]));
+    out[4 * i + 0] = h.t; out[4 * i + 1] = rt_u2f(h.tri); out[4 * i + 2] = h.u; out[4 * i + 3] = h.v;
+  }
+}
+void orc_trace_any(void* p, int n, const float* rays, int32_t* out)
+{
+  Ctx* c = static_cast<Ctx*>(p);
+  for(int i = 0; i < n; i++) {
+    const float* r = rays + 8 * i;
+    out[i] = c->scene.anyHit(V3(r[0], r[1], r[2]), V3(r[3], r[4], r[5]), r[6], rt_f2u(r[7])) ? 1 : 0;
+  }
+}
+// brute force over all triangles (no BVH): validates the oracle's own BVH
+void orc_trace_closest_brute(void* p, int n, const float* rays, float* out)
+{
+  Ctx* c = static_cast<Ctx*>(p);
+  const Scene& S = c->scene;
+  for(int i = 0; i < n; i++) {
+    const float* r = rays + 8 * i;
+    vec3 o = V3(r[0], r[1], r[2]), d = V3(r[3], r[4], r[5]);
+    Hit best;
+    for(uint32_t ti = 0; ti < S.tris.size(); ti++) {
+      float t, u, v;
+      if(!S.intersectTri(S.tris[ti], o, d, t, u, v)) continue;
+      if(!(t > 0.0f && t < RT_INFINITY)) continue;
+      if(!(t < best.t || (t == best.t && ti < best.tri))) continue;
+      if(!(S.tris[ti].flags & TRI_OPAQUE) && !S.hitTest(S.tris[ti], ti, u, v, rt_f2u(r[7]))) continue;
+      best.t = t; best.tri = ti; best.u = u; best.v = v;
+    }
+    out[4 * i + 0] = best.t; out[4 * i + 1] = rt_u2f(best.tri); out[4 * i + 2] = best.u; out[4 * i + 3] = best.v;
+  }
+}
+
+// ---- known-answer entry points (random.glsl, compress.glsl, common.glsl) ------------------------------------
+uint32_t orc_tea(uint32_t a, uint32_t b) { return tea(a, b); }
+uint32_t orc_pcg(uint32_t* s) { return pcg(*s); }
+float orc_rand(uint32_t* s) { return rnd(*s); }
+uint32_t orc_compress_unit_vec(float x, float y, float z) { return compress_unit_vec(V3(x, y, z)); }
+void orc_decompress_unit_vec(uint32_t p, float* out) { vec3 v = decompress_unit_vec(p); out[0] = v.x; out[1] = v.y; out[2] = v.z; }
+uint32_t orc_pack_unorm4x8(float x, float y, float z, float w) { return packUnorm4x8(V4(x, y, z, w)); }
+uint32_t orc_hash8bit(uint32_t a) { return hash8bit(a); }
+void orc_offset_ray(const float* p, const float* n, float* out) { vec3 r = OffsetRay(V3(p[0], p[1], p[2]), V3(n[0], n[1], n[2])); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+void orc_concentric_disk(float a, float b, float* out) { vec2 r = toConcentricDisk(V2(a, b)); out[0] = r.x; out[1] = r.y; }
+
+// ---- BSDF access for property tests ------------------------------------------------------------------------
+// m = {albedo.rgb, metallic, roughness}
+static State mkState(const float* m) { State s; s.mat.albedo = V3(m[0], m[1], m[2]); s.mat.metallic = m[3]; s.mat.roughness = m[4]; return s; }
+void orc_bsdf_eval(const float* m, const float* n, const float* wo, const float* wi, float* out)
+{
+  State s = mkState(m); float pdf = 0;
+  vec3 f = metallicWorkflowEval(s, V3(n[0], n[1], n[2]), V3(wo[0], wo[1], wo[2]), V3(wi[0], wi[1], wi[2]), pdf);
+  out[0] = f.x; out[1] = f.y; out[2] = f.z; out[3] = pdf;
+}
+void orc_bsdf_sample(const float* m, const float* n, const float* wo, const float* r, float* out)
+{
+  State s = mkState(m); vec3 bsdf = V3(0.0f), dir = V3(0.0f);
+  float pdf = metallicWorkflowSample(s, V3(n[0], n[1], n[2]), V3(wo[0], wo[1], wo[2]), V3(r[0], r[1], r[2]), bsdf, dir);
+  out[0] = dir.x; out[1] = dir.y; out[2] = dir.z; out[3] = pdf; out[4] = bsdf.x; out[5] = bsdf.y; out[6] = bsdf.z;
+}
+
+// ---- numerics contract (include/rt_detmath.h) on arrays -----------------------------------------------------
+void orc_detmath(int op, int n, const float* a, const float* b, float* out)
+{
+  for(int i = 0; i < n; i++) {
+    switch(op) {
+      case 0: out[i] = rt_exp(a[i]); break;
+      case 1: out[i] = rt_log(a[i]); break;
+      case 2: out[i] = rt_pow(a[i], b[i]); break;
+      case 3: out[i] = rt_sin(a[i]); break;
+      case 4: out[i] = rt_cos(a[i]); break;
+      case 5: out[i] = rt_asin(a[i]); break;
+      case 6: out[i] = rt_acos(a[i]); break;
+      case 7: out[i] = rt_atan2(a[i], b[i]); break;
+      default: out[i] = 0;
+    }
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,59 @@
+// orc_stages.h — CPU oracle frame state (screen-space buffers of renderer.cpp:227-302) and stage entry points.
+// TEST INFRASTRUCTURE, not product code.
+#pragma once
+#include <vector>
+#include "orc_shading.h"
+
+namespace orc {
+
+struct Frame {
+  const Scene* scene = nullptr;
+  rt_scene_camera cam{};
+  int W = 0, H = 0;
+  int threads = 1;
+
+  // boundary layouts == reference layouts (rt_abi.h rt_buffer_id)
+  std::vector<uint32_t> gbuffer[2];                 // RGBA32UI
+  std::vector<int16_t> motion;                      // RG16_SINT
+  std::vector<rt_direct_reservoir> directResv[2], directResvTemp;
+  std::vector<rt_indirect_reservoir> indirectResv[2], indirectResvTemp;
+  std::vector<float> denoiseTemp[4];                // DirA, DirB, IndA, IndB (RGBA32F, full-res allocation)
+  std::vector<float> directResult[2], indirectResult[2];
+  std::vector<uint32_t> lightId2[2];
+
+  std::vector<uint32_t>& lightId_cur(int cur) { return lightId2[cur]; }
+  const std::vector<uint32_t>& lightId_last(int last) const { return lightId2[last]; }
+
+  void resize(int w, int h);
+  void renderFrame(const rt_state& st, int frames);
+  void runStage(const rt_state& st, int frames, int stage, int level, int rowBegin, int rowEnd);
+
+  void directStage(const rt_state& st, int frames, int rowBegin, int rowEnd);
+  void directGen(const rt_state& st, int frames, int rowBegin, int rowEnd);
+  void directReuse(const rt_state& st, int frames, int rowBegin, int rowEnd);
+  void indirectStage(const rt_state& st, int frames, int rowBegin, int rowEnd);
+  void denoiseDirect(const rt_state& st, int frames, int level, int rowBegin, int rowEnd);
+  void denoiseIndirect(const rt_state& st, int frames, int level, int rowBegin, int rowEnd);
+  void compose(const rt_state& st, int frames, int rowBegin, int rowEnd);
+
+  // image access
+  uvec4 loadG(int which, ivec2 c) const;
+  void storeG(int which, ivec2 c, uvec4 v);
+  vec4 loadImg(const std::vector<float>& img, ivec2 c) const;
+  void storeImg(std::vector<float>& img, ivec2 c, vec4 v);
+  void storeMotion(ivec2 c, ivec2 v);
+  ivec2 loadMotion(ivec2 c) const;
+
+ private:
+  template <class F> void parallelRows(int rows, int rowBegin, int rowEnd, F&& fn) const;
+  void loadLastGeometryInfo(int last, ivec2 c, vec3& normal, float& depth, uint32_t& matHash) const;
+  bool findTemporalNeighborDirect(const rt_state& st, int last, vec3 norm, float reprojDepth, uint32_t matId, ivec2 lastCoord,
+                                  rt_direct_reservoir& resv, uint32_t& lid) const;
+  vec3 ReSTIRDirect(Shader& sh, const Ray& r, int cur, int last);
+  vec3 ReSTIRIndirect(Shader& sh, float dist, float primSamplePdf, vec3 primWo, State primState, rt_gi_sample gi, int cur, int last);
+  void loadThisGeometry(int cur, ivec2 coord, vec3& normal, vec3& pos, uint32_t& matHash, ivec2 imageSize) const;
+  vec3 waveletFilter(const rt_state& st, int cur, const std::vector<float>& inImage, ivec2 coord, vec3 norm, vec3 pos, uint32_t matHash,
+                     float sigLumin, float sigNormal, float sigDepth, int level, bool indirect) const;
+};
+
+}  // namespace orc
