@@ -1,0 +1,64 @@
+"""Build every native piece of the package in-tree (so the .so files travel with gpurun snapshots).
+
+  csrc/librestir_hip.so   HIP kernels + C-ABI (hipcc, gfx950 only)
+  host/librestir_host.so  Scene / HdrSampling / procedural scenes (g++)
+"""
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB = os.path.join(_HERE, "csrc", "librestir_hip.so")
+HOST_LIB = os.path.join(_HERE, "host", "librestir_host.so")
+
+# -ffp-contract=off + correctly rounded divide/sqrt: the bit-reproducibility rules of include/rt_detmath.h
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+             "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-unused-result", "-x", "hip"]
+HIP_SRC = ["rt_api.cpp", "bvh8_builder.cpp", "stages.hip"]
+HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-pthread"]
+HOST_SRC = ["scene.cpp", "scene_gen.cpp", "hdr_sampling.cpp", "gltf_loader.cpp", "host_capi.cpp"]
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources if os.path.exists(s))
+
+
+def _deps(d, exts):
+    out = []
+    for root in (d, os.path.join(_HERE, "..", "include")):
+        for f in os.listdir(root):
+            if f.endswith(exts):
+                out.append(os.path.join(root, f))
+    return out
+
+
+def build_hip(force=False, verbose=False):
+    d = os.path.join(_HERE, "csrc")
+    if force or _stale(HIP_LIB, _deps(d, (".cpp", ".hip", ".h"))):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        cmd = [hipcc] + HIP_FLAGS + [os.path.join(d, s) for s in HIP_SRC] + ["-o", HIP_LIB]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return HIP_LIB
+
+
+def build_host(force=False, verbose=False):
+    d = os.path.join(_HERE, "host")
+    if force or _stale(HOST_LIB, _deps(d, (".cpp", ".h", ".hpp"))):
+        cmd = [os.environ.get("CXX", "g++")] + HOST_FLAGS + [os.path.join(d, s) for s in HOST_SRC] + ["-o", HOST_LIB]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return HOST_LIB
+
+
+def build_all(force=False, verbose=False):
+    return build_host(force, verbose), build_hip(force, verbose)
+
+
+if __name__ == "__main__":
+    print(build_all(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,25 @@
+#pragma once
+#include <vector>
+#include "bvh8.h"
+#include "dev_scene.h"
+
+namespace rt {
+
+struct BuildInput {
+  const rt_scene_desc* scene;
+};
+struct BuildOutput {
+  std::vector<Node8> nodes;
+  std::vector<Tri48> tris;       // BVH leaf order
+  std::vector<TriRef> triRef;    // by globalId
+  std::vector<DevInstance> instances;
+  int maxDepth = 0;
+  double sahCost = 0;
+  float pad = 0;
+};
+// Host-side build: flatten (instance, triangle) pairs to world space, binned-SAH BVH2, greedy collapse to 8-wide,
+// octant-ordered slot assignment, conservative 8-bit quantisation.  Replaces AccelStructure::create
+// (src/accelstruct.cpp:55-162: BLAS per prim mesh + TLAS per node, built by the Vulkan driver).
+bool buildBvh8(const rt_scene_desc& scene, BuildOutput& out, int threads);
+
+}  // namespace rt

@@ -1,0 +1,112 @@
+// dev_math.h — float vector helpers for the gfx950 kernels.
+// Per-operation semantics follow DESIGN.md §Numerics (sums left to right, normalize = v * (1/sqrt(dot)),
+// mix = a*(1-t)+b*t, no FMA contraction: the translation unit is built with -ffp-contract=off) so that results are
+// bit-identical to any other implementation of the same contract.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/rt_abi.h"
+#include "../../include/rt_detmath.h"
+
+#define RT_DEV __device__ __forceinline__
+
+namespace rt {
+
+struct f2 { float x, y; };
+struct f3 { float x, y, z; };
+struct f4 { float x, y, z, w; };
+struct i2 { int x, y; };
+
+RT_DEV f2 mk2(float x, float y) { return f2{x, y}; }
+RT_DEV f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+RT_DEV f3 mk3(float s) { return f3{s, s, s}; }
+RT_DEV f3 mk3(rt_vec3 v) { return f3{v.x, v.y, v.z}; }
+RT_DEV f4 mk4(float x, float y, float z, float w) { return f4{x, y, z, w}; }
+RT_DEV f4 mk4(f3 v, float w) { return f4{v.x, v.y, v.z, w}; }
+RT_DEV rt_vec3 toR(f3 v) { return rt_vec3{v.x, v.y, v.z}; }
+RT_DEV f3 xyz(f4 v) { return f3{v.x, v.y, v.z}; }
+
+RT_DEV f2 operator+(f2 a, f2 b) { return {a.x + b.x, a.y + b.y}; }
+RT_DEV f2 operator-(f2 a, f2 b) { return {a.x - b.x, a.y - b.y}; }
+RT_DEV f2 operator*(f2 a, float s) { return {a.x * s, a.y * s}; }
+RT_DEV f2 operator*(float s, f2 a) { return {s * a.x, s * a.y}; }
+RT_DEV f2 operator*(f2 a, f2 b) { return {a.x * b.x, a.y * b.y}; }
+RT_DEV f2 operator/(f2 a, f2 b) { return {a.x / b.x, a.y / b.y}; }
+RT_DEV f2 operator+(f2 a, float s) { return {a.x + s, a.y + s}; }
+RT_DEV f2 operator-(f2 a, float s) { return {a.x - s, a.y - s}; }
+
+RT_DEV f3 operator+(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+RT_DEV f3 operator-(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+RT_DEV f3 operator-(f3 a) { return {-a.x, -a.y, -a.z}; }
+RT_DEV f3 operator*(f3 a, f3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+RT_DEV f3 operator*(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+RT_DEV f3 operator*(float s, f3 a) { return {s * a.x, s * a.y, s * a.z}; }
+RT_DEV f3 operator/(f3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+RT_DEV f3 operator/(f3 a, f3 b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
+RT_DEV f3 operator+(f3 a, float s) { return {a.x + s, a.y + s, a.z + s}; }
+RT_DEV f3 operator-(float s, f3 a) { return {s - a.x, s - a.y, s - a.z}; }
+RT_DEV f3& operator+=(f3& a, f3 b) { a = a + b; return a; }
+RT_DEV f3& operator*=(f3& a, f3 b) { a = a * b; return a; }
+RT_DEV f3& operator*=(f3& a, float s) { a = a * s; return a; }
+
+RT_DEV f4 operator+(f4 a, f4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+RT_DEV f4 operator*(f4 a, float s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
+RT_DEV f4 operator*(f4 a, f4 b) { return {a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; }
+
+RT_DEV float dot(f2 a, f2 b) { return a.x * b.x + a.y * b.y; }
+RT_DEV float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+RT_DEV f3 cross(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+RT_DEV float length(f3 a) { return rt_sqrt(dot(a, a)); }
+RT_DEV f3 normalize(f3 a) { float inv = 1.0f / rt_sqrt(dot(a, a)); return a * inv; }
+RT_DEV float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+RT_DEV f3 mix(f3 a, f3 b, float t) { return a * (1.0f - t) + b * t; }
+RT_DEV f3 mix(f3 a, f3 b, f3 t) { return {mixf(a.x, b.x, t.x), mixf(a.y, b.y, t.y), mixf(a.z, b.z, t.z)}; }
+RT_DEV f4 mix(f4 a, f4 b, float t) { return a * (1.0f - t) + b * t; }
+RT_DEV f3 reflect(f3 I, f3 N) { return I - (2.0f * dot(N, I)) * N; }
+RT_DEV float luminance(f3 c) { return (0.2126f * c.x + 0.7152f * c.y) + 0.0722f * c.z; }
+RT_DEV bool hasNan(f3 v) { return rt_isnan(v.x) || rt_isnan(v.y) || rt_isnan(v.z); }
+
+// column-major 4x4 times vec4
+RT_DEV f4 mul(const rt_mat4& M, f4 v)
+{
+  f4 r;
+  r.x = ((M.m[0] * v.x + M.m[4] * v.y) + M.m[8] * v.z) + M.m[12] * v.w;
+  r.y = ((M.m[1] * v.x + M.m[5] * v.y) + M.m[9] * v.z) + M.m[13] * v.w;
+  r.z = ((M.m[2] * v.x + M.m[6] * v.y) + M.m[10] * v.z) + M.m[14] * v.w;
+  r.w = ((M.m[3] * v.x + M.m[7] * v.y) + M.m[11] * v.z) + M.m[15] * v.w;
+  return r;
+}
+struct m3 { f3 c0, c1, c2; };
+RT_DEV f3 mul(const m3& M, f3 v) { return (M.c0 * v.x + M.c1 * v.y) + M.c2 * v.z; }
+RT_DEV m3 inverse(const m3& M)
+{
+  float a = M.c0.x, b = M.c1.x, c = M.c2.x;
+  float d = M.c0.y, e = M.c1.y, f = M.c2.y;
+  float g = M.c0.z, h = M.c1.z, i = M.c2.z;
+  float A = e * i - f * h, B = f * g - d * i, C = d * h - e * g;
+  float det = (a * A + b * B) + c * C;
+  float inv = 1.0f / det;
+  m3 R;
+  R.c0 = mk3(A * inv, B * inv, C * inv);
+  R.c1 = mk3((c * h - b * i) * inv, (a * i - c * g) * inv, (b * g - a * h) * inv);
+  R.c2 = mk3((b * f - c * e) * inv, (c * d - a * f) * inv, (a * e - b * d) * inv);
+  return R;
+}
+
+// 3x4 row-major affine (a[r*4+c]); the same three products as GLSL's mat4x3 uses
+__host__ __device__ inline void xformPointRaw(const float* a, float x, float y, float z, float* o)
+{
+  o[0] = ((a[0] * x + a[1] * y) + a[2] * z) + a[3];
+  o[1] = ((a[4] * x + a[5] * y) + a[6] * z) + a[7];
+  o[2] = ((a[8] * x + a[9] * y) + a[10] * z) + a[11];
+}
+RT_DEV f3 xformPoint(const float* a, f3 p) { float o[3]; xformPointRaw(a, p.x, p.y, p.z, o); return mk3(o[0], o[1], o[2]); }
+RT_DEV f3 xformDir(const float* a, f3 v)
+{
+  return {(a[0] * v.x + a[1] * v.y) + a[2] * v.z, (a[4] * v.x + a[5] * v.y) + a[6] * v.z, (a[8] * v.x + a[9] * v.y) + a[10] * v.z};
+}
+RT_DEV f3 xformNormal(const float* w, f3 v)
+{
+  return {(v.x * w[0] + v.y * w[4]) + v.z * w[8], (v.x * w[1] + v.y * w[5]) + v.z * w[9], (v.x * w[2] + v.y * w[6]) + v.z * w[10]};
+}
+
+}  // namespace rt

@@ -1,0 +1,55 @@
+// dev_scene.h — device-resident scene (HBM): what the reference binds as descriptor sets S_ACCEL / S_SCENE / S_ENV
+// (shaders/host_device.h:67-110, shaders/layouts.glsl:38-55) as one POD of raw pointers passed by value to every kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "bvh8.h"
+#include "../../include/rt_abi.h"
+
+namespace rt {
+
+struct DevInstance {   // TLAS instance + the two matrices rayQueryGetIntersection{ObjectToWorld,WorldToObject}EXT return
+  float o2w[12];
+  float w2o[12];
+  uint32_t primMesh;   // instanceCustomIndex
+  uint32_t flags;
+  uint32_t pad[2];
+};
+
+struct DevTexture {
+  const uint8_t* bgra;
+  int32_t w, h, wrapS, wrapT, filter, pad;
+};
+
+struct DevScene {
+  const Node8* nodes;
+  const Tri48* tris;
+  const TriRef* triRef;
+  const DevInstance* instances;
+  const rt_prim_mesh* primMeshes;   // geoInfo[] (InstanceData rows): vertex/index offsets + materialIndex
+  const rt_vertex* vertices;
+  const uint32_t* indices;
+  const rt_material* materials;
+  const DevTexture* textures;
+  const rt_punc_light* puncLights;
+  const rt_trig_light* trigLights;
+  const float* env;                 // RGBA32F
+  const rt_impt_samp* envAccel;
+  rt_light_buf_info lightInfo;
+  int32_t envW, envH;
+  uint32_t numTris, numNodes;
+};
+
+// per-frame screen-space state (renderer.cpp:227-302), "this"/"last" already resolved from the frame parity
+struct DevFrame {
+  uint4* thisG; const uint4* lastG;
+  short2* motion;
+  rt_direct_reservoir* thisDirectResv; const rt_direct_reservoir* lastDirectResv;
+  rt_indirect_reservoir* thisIndirectResv; const rt_indirect_reservoir* lastIndirectResv;
+  uint32_t* thisLightId; const uint32_t* lastLightId;
+  float4* thisDirectResult; float4* thisIndirectResult;
+  float4* denoiseDirA; float4* denoiseDirB; float4* denoiseIndA; float4* denoiseIndB;
+  unsigned long long* counters;     // 6 x u64 (rt_counters order) or nullptr
+  int32_t W, H;
+};
+
+}  // namespace rt

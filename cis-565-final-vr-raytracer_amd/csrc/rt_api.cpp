@@ -1,0 +1,401 @@
+// rt_api.cpp — the C-ABI of include/rt_abi.h over HIP: context, HBM residency, stage launches, readback.
+// Stands where the reference has Renderer / Scene / AccelStructure / HdrSampling talking to Vulkan
+// (src/renderer.cpp:62-302, src/scene.cpp:453-508, src/accelstruct.cpp:55-65, src/hdr_sampling.cpp:79-95).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+#include "../../include/rt_abi.h"
+#include "bvh8_builder.h"
+#include "stages.h"
+
+using namespace rt;
+
+struct rt_ctx {
+  int device = 0;
+  hipStream_t ownStream = nullptr, stream = nullptr;
+  std::string err;
+  // host copy of the scene (rt_build_accel runs after rt_upload_scene returns; the caller keeps ownership of its arrays)
+  std::vector<rt_prim_mesh> primMeshes; std::vector<rt_vertex> vertices; std::vector<uint32_t> indices; std::vector<rt_instance> instances;
+  // device allocations of the scene
+  std::vector<void*> sceneAllocs, accelAllocs;
+  DevScene ds{};
+  bool haveScene = false, haveAccel = false;
+  int maxDepth = 0; size_t numNodes = 0, numTris = 0;
+  // screen-space buffers
+  int W = 0, H = 0;
+  void* bufs[RT_BUF_COUNT] = {};
+  size_t bufBytes[RT_BUF_COUNT] = {};
+  rt_scene_camera cam{};
+  bool counting = false;
+  unsigned long long* dCounters = nullptr;
+  // timing: event 0 = frame start, event k = end of launch k
+  static constexpr int MAX_EV = 16;
+  hipEvent_t ev[MAX_EV] = {};
+  int evStage[MAX_EV] = {};
+  int evCount = 0;
+  bool timingValid = false;
+};
+
+static thread_local std::string g_createErr;
+
+#define RT_HIP(ctx, call)                                                                                                   \
+  do {                                                                                                                      \
+    hipError_t e_ = (call);                                                                                                 \
+    if(e_ != hipSuccess) {                                                                                                  \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                                                       \
+      return (e_ == hipErrorOutOfMemory) ? RT_ERR_OOM : RT_ERR_HIP;                                                         \
+    }                                                                                                                       \
+  } while(0)
+
+static int fail(rt_ctx* c, int code, const char* msg) { c->err = msg; return code; }
+
+template <class T> static int upload(rt_ctx* c, std::vector<void*>& pool, const T* src, size_t count, const T** out)
+{
+  void* d = nullptr;
+  size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  RT_HIP(c, hipMalloc(&d, bytes));
+  pool.push_back(d);
+  if(count && src) RT_HIP(c, hipMemcpy(d, src, count * sizeof(T), hipMemcpyHostToDevice));
+  else RT_HIP(c, hipMemset(d, 0, bytes));
+  *out = static_cast<const T*>(d);
+  return RT_OK;
+}
+static void freePool(std::vector<void*>& pool) { for(void* p : pool) (void)hipFree(p); pool.clear(); }
+
+static size_t elemBytes(int id)
+{
+  switch(id) {
+    case RT_BUF_GBUFFER0: case RT_BUF_GBUFFER1: return 16;
+    case RT_BUF_MOTION: return 4;
+    case RT_BUF_DIRECT_RESV0: case RT_BUF_DIRECT_RESV1: case RT_BUF_DIRECT_RESV_TEMP: return sizeof(rt_direct_reservoir);
+    case RT_BUF_INDIRECT_RESV0: case RT_BUF_INDIRECT_RESV1: case RT_BUF_INDIRECT_RESV_TEMP: return sizeof(rt_indirect_reservoir);
+    case RT_BUF_LIGHT_ID0: case RT_BUF_LIGHT_ID1: return 4;
+    default: return 16;
+  }
+}
+static bool halfRes(int id) { return id == RT_BUF_INDIRECT_RESV0 || id == RT_BUF_INDIRECT_RESV1 || id == RT_BUF_INDIRECT_RESV_TEMP; }
+
+extern "C" {
+
+uint32_t rt_abi_version(void) { return (1u << 16) | 0u; }
+
+const char* rt_last_error(rt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_createErr.c_str(); }
+
+int rt_create(rt_ctx** out, int device)
+{
+  if(!out) { g_createErr = "rt_create: out is NULL"; return RT_ERR_INVALID_ARG; }
+  *out = nullptr;
+  int n = 0;
+  if(hipGetDeviceCount(&n) != hipSuccess || n <= 0) { g_createErr = "rt_create: no HIP device (this library has no CPU path)"; return RT_ERR_NO_DEVICE; }
+  if(device < 0 || device >= n) { g_createErr = "rt_create: device index out of range"; return RT_ERR_INVALID_ARG; }
+  if(hipSetDevice(device) != hipSuccess) { g_createErr = "rt_create: hipSetDevice failed"; return RT_ERR_HIP; }
+  rt_ctx* c = new(std::nothrow) rt_ctx();
+  if(!c) { g_createErr = "rt_create: out of host memory"; return RT_ERR_OOM; }
+  c->device = device;
+  if(hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) != hipSuccess) { g_createErr = "rt_create: hipStreamCreate failed"; delete c; return RT_ERR_HIP; }
+  c->stream = c->ownStream;
+  for(int i = 0; i < rt_ctx::MAX_EV; i++) (void)hipEventCreate(&c->ev[i]);
+  if(hipMalloc(reinterpret_cast<void**>(&c->dCounters), 8 * sizeof(unsigned long long)) != hipSuccess) { g_createErr = "rt_create: hipMalloc failed"; delete c; return RT_ERR_OOM; }
+  (void)hipMemset(c->dCounters, 0, 8 * sizeof(unsigned long long));
+  *out = c;
+  return RT_OK;
+}
+
+int rt_destroy(rt_ctx* c)
+{
+  if(!c) return RT_ERR_INVALID_ARG;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  freePool(c->sceneAllocs); freePool(c->accelAllocs);
+  for(int i = 0; i < RT_BUF_COUNT; i++) if(c->bufs[i]) (void)hipFree(c->bufs[i]);
+  if(c->dCounters) (void)hipFree(c->dCounters);
+  for(int i = 0; i < rt_ctx::MAX_EV; i++) if(c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  if(c->ownStream) (void)hipStreamDestroy(c->ownStream);
+  delete c;
+  return RT_OK;
+}
+
+int rt_set_stream(rt_ctx* c, void* s)
+{
+  if(!c) return RT_ERR_INVALID_ARG;
+  c->stream = s ? static_cast<hipStream_t>(s) : c->ownStream;
+  return RT_OK;
+}
+
+int rt_sync(rt_ctx* c)
+{
+  if(!c) return RT_ERR_INVALID_ARG;
+  RT_HIP(c, hipSetDevice(c->device));
+  RT_HIP(c, hipStreamSynchronize(c->stream));
+  return RT_OK;
+}
+
+int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
+{
+  if(!c) return RT_ERR_INVALID_ARG;
+  if(!d || !d->primMeshes || !d->vertices || !d->indices || !d->instances || !d->materials || d->numMaterials == 0)
+    return fail(c, RT_ERR_INVALID_ARG, "rt_upload_scene: missing geometry/material arrays");
+  for(uint32_t i = 0; i < d->numInstances; i++)
+    if(d->instances[i].primMesh >= d->numPrimMeshes) return fail(c, RT_ERR_INVALID_ARG, "rt_upload_scene: instance references a missing prim mesh");
+  for(uint32_t i = 0; i < d->numPrimMeshes; i++) {
+    const rt_prim_mesh& pm = d->primMeshes[i];
+    if(uint64_t(pm.firstIndex) + pm.indexCount > d->numIndices || uint64_t(pm.vertexOffset) + pm.vertexCount > d->numVertices || pm.indexCount % 3 != 0)
+      return fail(c, RT_ERR_INVALID_ARG, "rt_upload_scene: prim mesh range out of bounds");
+    if(pm.materialIndex >= int32_t(d->numMaterials)) return fail(c, RT_ERR_INVALID_ARG, "rt_upload_scene: material index out of range");
+  }
+  RT_HIP(c, hipSetDevice(c->device));
+  RT_HIP(c, hipStreamSynchronize(c->stream));
+  freePool(c->sceneAllocs); freePool(c->accelAllocs);
+  c->haveScene = c->haveAccel = false;
+  c->ds = DevScene{};
+  c->primMeshes.assign(d->primMeshes, d->primMeshes + d->numPrimMeshes);
+  c->vertices.assign(d->vertices, d->vertices + d->numVertices);
+  c->indices.assign(d->indices, d->indices + d->numIndices);
+  c->instances.assign(d->instances, d->instances + d->numInstances);
+
+  int rc;
+  if((rc = upload(c, c->sceneAllocs, d->primMeshes, d->numPrimMeshes, &c->ds.primMeshes))) return rc;
+  if((rc = upload(c, c->sceneAllocs, d->vertices, size_t(d->numVertices), &c->ds.vertices))) return rc;
+  if((rc = upload(c, c->sceneAllocs, d->indices, size_t(d->numIndices), &c->ds.indices))) return rc;
+  if((rc = upload(c, c->sceneAllocs, d->materials, d->numMaterials, &c->ds.materials))) return rc;
+  if((rc = upload(c, c->sceneAllocs, d->puncLights, d->puncLights ? d->lightInfo.puncLightSize : 0, &c->ds.puncLights))) return rc;
+  if((rc = upload(c, c->sceneAllocs, d->trigLights, d->trigLights ? d->lightInfo.trigLightSize : 0, &c->ds.trigLights))) return rc;
+  c->ds.lightInfo = d->lightInfo;
+  if(!d->puncLights) c->ds.lightInfo.puncLightSize = 0;
+  if(!d->trigLights) c->ds.lightInfo.trigLightSize = 0;
+  // textures (BGRA8, LOD 0)
+  std::vector<DevTexture> texs(std::max<uint32_t>(d->numTextures, 1));
+  static const uint8_t white[4] = {255, 255, 255, 255};
+  for(uint32_t i = 0; i < uint32_t(texs.size()); i++) {
+    rt_texture t{white, 1, 1, RT_WRAP_REPEAT, RT_WRAP_REPEAT, RT_FILTER_LINEAR, 0};
+    if(i < d->numTextures && d->textures && d->textures[i].bgra8 && d->textures[i].width > 0 && d->textures[i].height > 0) t = d->textures[i];
+    const uint8_t* dp = nullptr;
+    if((rc = upload(c, c->sceneAllocs, t.bgra8, size_t(t.width) * t.height * 4, &dp))) return rc;
+    texs[i] = DevTexture{dp, t.width, t.height, t.wrapS, t.wrapT, t.magFilter, 0};
+  }
+  if((rc = upload(c, c->sceneAllocs, texs.data(), texs.size(), &c->ds.textures))) return rc;
+  // environment
+  if(d->envRgba32f && d->envWidth > 0 && d->envHeight > 0) {
+    const size_t n = size_t(d->envWidth) * d->envHeight;
+    if((rc = upload(c, c->sceneAllocs, d->envRgba32f, n * 4, &c->ds.env))) return rc;
+    if(d->envAccel) { if((rc = upload(c, c->sceneAllocs, d->envAccel, n, &c->ds.envAccel))) return rc; }
+    else {
+      std::vector<rt_impt_samp> a(n, rt_impt_samp{0, 1.0f, 0.0f, 0.0f});
+      if((rc = upload(c, c->sceneAllocs, a.data(), n, &c->ds.envAccel))) return rc;
+    }
+    c->ds.envW = d->envWidth; c->ds.envH = d->envHeight;
+  } else {
+    const float black[4] = {0, 0, 0, 0};
+    const rt_impt_samp one{0, 1.0f, 0.0f, 0.0f};
+    if((rc = upload(c, c->sceneAllocs, black, 4, &c->ds.env))) return rc;
+    if((rc = upload(c, c->sceneAllocs, &one, 1, &c->ds.envAccel))) return rc;
+    c->ds.envW = c->ds.envH = 1;
+  }
+  c->haveScene = true;
+  return RT_OK;
+}
+
+int rt_build_accel(rt_ctx* c)
+{
+  if(!c) return RT_ERR_INVALID_ARG;
+  if(!c->haveScene) return fail(c, RT_ERR_NO_SCENE, "rt_build_accel: no scene uploaded");
+  RT_HIP(c, hipSetDevice(c->device));
+  RT_HIP(c, hipStreamSynchronize(c->stream));
+  freePool(c->accelAllocs);
+  c->haveAccel = false;
+  rt_scene_desc d{};
+  d.numPrimMeshes = uint32_t(c->primMeshes.size()); d.primMeshes = c->primMeshes.data();
+  d.numVertices = c->vertices.size(); d.vertices = c->vertices.data();
+  d.numIndices = c->indices.size(); d.indices = c->indices.data();
+  d.numInstances = uint32_t(c->instances.size()); d.instances = c->instances.data();
+  BuildOutput bo;
+  int threads = int(std::thread::hardware_concurrency());
+  if(!buildBvh8(d, bo, threads > 0 ? threads : 1)) return fail(c, RT_ERR_INVALID_ARG, "rt_build_accel: BVH8 build failed");
+  if(bo.maxDepth > STACK_N) return fail(c, RT_ERR_INVALID_ARG, "rt_build_accel: BVH8 deeper than the traversal stack");
+  int rc;
+  if((rc = upload(c, c->accelAllocs, bo.nodes.data(), bo.nodes.size(), &c->ds.nodes))) return rc;
+  if((rc = upload(c, c->accelAllocs, bo.tris.data(), bo.tris.size(), &c->ds.tris))) return rc;
+  if((rc = upload(c, c->accelAllocs, bo.triRef.data(), bo.triRef.size(), &c->ds.triRef))) return rc;
+  if((rc = upload(c, c->accelAllocs, bo.instances.data(), bo.instances.size(), &c->ds.instances))) return rc;
+  c->ds.numNodes = uint32_t(bo.nodes.size()); c->ds.numTris = uint32_t(bo.tris.size());
+  c->numNodes = bo.nodes.size(); c->numTris = bo.tris.size(); c->maxDepth = bo.maxDepth;
+  c->haveAccel = true;
+  return RT_OK;
+}
+
+int rt_resize(rt_ctx* c, int w, int h)
+{
+  if(!c) return RT_ERR_INVALID_ARG;
+  if(w <= 0 || h <= 0 || w > 32767 || h > 32767) return fail(c, RT_ERR_INVALID_ARG, "rt_resize: size must be in 1..32767 (RG16_SINT motion vectors)");
+  RT_HIP(c, hipSetDevice(c->device));
+  RT_HIP(c, hipStreamSynchronize(c->stream));
+  for(int i = 0; i < RT_BUF_COUNT; i++) { if(c->bufs[i]) (void)hipFree(c->bufs[i]); c->bufs[i] = nullptr; c->bufBytes[i] = 0; }
+  c->W = c->H = 0;
+  const size_t n = size_t(w) * h, nh = size_t(w / 2) * (h / 2);
+  for(int i = 0; i < RT_BUF_COUNT; i++) {
+    const size_t bytes = (halfRes(i) ? nh : n) * elemBytes(i);
+    RT_HIP(c, hipMalloc(&c->bufs[i], std::max<size_t>(bytes, 16)));
+    RT_HIP(c, hipMemset(c->bufs[i], (i == RT_BUF_LIGHT_ID0 || i == RT_BUF_LIGHT_ID1) ? 0xff : 0, std::max<size_t>(bytes, 16)));
+    c->bufBytes[i] = bytes;
+  }
+  c->W = w; c->H = h;
+  return RT_OK;
+}
+
+int rt_set_camera(rt_ctx* c, const rt_scene_camera* cam)
+{
+  if(!c || !cam) return RT_ERR_INVALID_ARG;
+  c->cam = *cam;
+  return RT_OK;
+}
+
+static DevFrame makeFrame(rt_ctx* c, int frames)
+{
+  const int cur = frames & 1, last = (frames + 1) & 1;  // m_descSet[(frames+1)%2]: this = [!i] (renderer.cpp:157, 346-356)
+  DevFrame F{};
+  F.thisG = static_cast<uint4*>(c->bufs[RT_BUF_GBUFFER0 + cur]); F.lastG = static_cast<const uint4*>(c->bufs[RT_BUF_GBUFFER0 + last]);
+  F.motion = static_cast<short2*>(c->bufs[RT_BUF_MOTION]);
+  F.thisDirectResv = static_cast<rt_direct_reservoir*>(c->bufs[RT_BUF_DIRECT_RESV0 + cur]);
+  F.lastDirectResv = static_cast<const rt_direct_reservoir*>(c->bufs[RT_BUF_DIRECT_RESV0 + last]);
+  F.thisIndirectResv = static_cast<rt_indirect_reservoir*>(c->bufs[RT_BUF_INDIRECT_RESV0 + cur]);
+  F.lastIndirectResv = static_cast<const rt_indirect_reservoir*>(c->bufs[RT_BUF_INDIRECT_RESV0 + last]);
+  F.thisLightId = static_cast<uint32_t*>(c->bufs[RT_BUF_LIGHT_ID0 + cur]); F.lastLightId = static_cast<const uint32_t*>(c->bufs[RT_BUF_LIGHT_ID0 + last]);
+  F.thisDirectResult = static_cast<float4*>(c->bufs[RT_BUF_DIRECT_RESULT0 + cur]);
+  F.thisIndirectResult = static_cast<float4*>(c->bufs[RT_BUF_INDIRECT_RESULT0 + cur]);
+  F.denoiseDirA = static_cast<float4*>(c->bufs[RT_BUF_DENOISE_DIR_A]); F.denoiseDirB = static_cast<float4*>(c->bufs[RT_BUF_DENOISE_DIR_B]);
+  F.denoiseIndA = static_cast<float4*>(c->bufs[RT_BUF_DENOISE_IND_A]); F.denoiseIndB = static_cast<float4*>(c->bufs[RT_BUF_DENOISE_IND_B]);
+  F.counters = c->counting ? c->dCounters : nullptr;
+  F.W = c->W; F.H = c->H;
+  return F;
+}
+
+static int checkReady(rt_ctx* c, const rt_state* st)
+{
+  if(!c || !st) return RT_ERR_INVALID_ARG;
+  if(!c->haveScene) return fail(c, RT_ERR_NO_SCENE, "no scene uploaded");
+  if(!c->haveAccel) return fail(c, RT_ERR_NO_ACCEL, "rt_build_accel has not been called");
+  if(c->W == 0 || st->size.x != c->W || st->size.y != c->H) return fail(c, RT_ERR_NO_TARGET, "RtxState.size does not match rt_resize");
+  return RT_OK;
+}
+
+int rt_run_stage(rt_ctx* c, const rt_state* st, int frames, int stage, int level, int rowBegin, int rowEnd)
+{
+  int rc = checkReady(c, st);
+  if(rc) return rc;
+  if(stage < 0 || stage >= RT_STAGE_COUNT) return fail(c, RT_ERR_INVALID_ARG, "rt_run_stage: unknown stage");
+  if(rowBegin < 0 || (rowBegin & 7)) return fail(c, RT_ERR_INVALID_ARG, "rt_run_stage: rowBegin must be a non-negative multiple of 8");
+  RT_HIP(c, hipSetDevice(c->device));
+  const DevFrame F = makeFrame(c, frames);
+  RT_HIP(c, launchStage(c->stream, c->ds, F, *st, c->cam, stage, level, rowBegin, rowEnd));
+  c->timingValid = false;
+  return RT_OK;
+}
+
+int rt_render_frame(rt_ctx* c, const rt_state* st, int frames)
+{
+  int rc = checkReady(c, st);
+  if(rc) return rc;
+  RT_HIP(c, hipSetDevice(c->device));
+  const DevFrame F = makeFrame(c, frames);
+  int k = 0;
+  RT_HIP(c, hipEventRecord(c->ev[k], c->stream));
+  c->evStage[k++] = -1;
+  auto run = [&](int stage, int level) -> int {
+    hipError_t e = launchStage(c->stream, c->ds, F, *st, c->cam, stage, level, 0, 0);
+    if(e != hipSuccess) { c->err = std::string("launchStage: ") + hipGetErrorString(e); return RT_ERR_HIP; }
+    e = hipEventRecord(c->ev[k], c->stream);
+    if(e != hipSuccess) { c->err = std::string("hipEventRecord: ") + hipGetErrorString(e); return RT_ERR_HIP; }
+    c->evStage[k++] = stage;
+    return RT_OK;
+  };
+  // Renderer::run, renderer.cpp:163-205
+  if((rc = run(RT_STAGE_DIRECT, 0))) return rc;
+  if((rc = run(RT_STAGE_INDIRECT, 0))) return rc;
+  if(st->denoise > 0) {
+    for(int i = 0; i < 4; i++) if((rc = run(RT_STAGE_DENOISE_DIRECT, i))) return rc;
+    for(int i = 0; i < 5; i++) if((rc = run(RT_STAGE_DENOISE_INDIRECT, i))) return rc;
+  }
+  if((rc = run(RT_STAGE_COMPOSE, 0))) return rc;
+  c->evCount = k;
+  c->timingValid = true;
+  return RT_OK;
+}
+
+size_t rt_buffer_bytes(rt_ctx* c, int buffer) { return (c && buffer >= 0 && buffer < RT_BUF_COUNT) ? c->bufBytes[buffer] : 0; }
+
+int rt_readback(rt_ctx* c, int buffer, void* dst, size_t bytes)
+{
+  if(!c || !dst || buffer < 0 || buffer >= RT_BUF_COUNT) return RT_ERR_INVALID_ARG;
+  if(c->W == 0) return fail(c, RT_ERR_NO_TARGET, "rt_readback: rt_resize has not been called");
+  if(bytes != c->bufBytes[buffer]) return fail(c, RT_ERR_INVALID_ARG, "rt_readback: size mismatch (see rt_buffer_bytes)");
+  RT_HIP(c, hipSetDevice(c->device));
+  RT_HIP(c, hipStreamSynchronize(c->stream));
+  RT_HIP(c, hipMemcpy(dst, c->bufs[buffer], bytes, hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+int rt_upload_history(rt_ctx* c, int buffer, const void* src, size_t bytes)
+{
+  if(!c || !src || buffer < 0 || buffer >= RT_BUF_COUNT) return RT_ERR_INVALID_ARG;
+  if(c->W == 0) return fail(c, RT_ERR_NO_TARGET, "rt_upload_history: rt_resize has not been called");
+  if(bytes != c->bufBytes[buffer]) return fail(c, RT_ERR_INVALID_ARG, "rt_upload_history: size mismatch (see rt_buffer_bytes)");
+  RT_HIP(c, hipSetDevice(c->device));
+  RT_HIP(c, hipStreamSynchronize(c->stream));
+  RT_HIP(c, hipMemcpy(c->bufs[buffer], src, bytes, hipMemcpyHostToDevice));
+  return RT_OK;
+}
+
+int rt_device_ptr(rt_ctx* c, int buffer, void** ptr, size_t* bytes, size_t* rowPitch)
+{
+  if(!c || buffer < 0 || buffer >= RT_BUF_COUNT || !ptr) return RT_ERR_INVALID_ARG;
+  if(c->W == 0) return fail(c, RT_ERR_NO_TARGET, "rt_device_ptr: rt_resize has not been called");
+  *ptr = c->bufs[buffer];
+  if(bytes) *bytes = c->bufBytes[buffer];
+  if(rowPitch) *rowPitch = size_t(halfRes(buffer) ? c->W / 2 : c->W) * elemBytes(buffer);
+  return RT_OK;
+}
+
+int rt_set_counting(rt_ctx* c, int enable)
+{
+  if(!c) return RT_ERR_INVALID_ARG;
+  RT_HIP(c, hipSetDevice(c->device));
+  RT_HIP(c, hipStreamSynchronize(c->stream));
+  RT_HIP(c, hipMemset(c->dCounters, 0, 8 * sizeof(unsigned long long)));
+  c->counting = enable != 0;
+  return RT_OK;
+}
+
+int rt_get_counters(rt_ctx* c, rt_counters* out)
+{
+  if(!c || !out) return RT_ERR_INVALID_ARG;
+  memset(out, 0, sizeof(*out));
+  RT_HIP(c, hipSetDevice(c->device));
+  RT_HIP(c, hipStreamSynchronize(c->stream));
+  unsigned long long h[8];
+  RT_HIP(c, hipMemcpy(h, c->dCounters, sizeof(h), hipMemcpyDeviceToHost));
+  out->closestHitRays = h[0]; out->anyHitRays = h[1]; out->nodesVisited = h[2]; out->trisTested = h[3]; out->hitsShaded = h[4]; out->risCandidates = h[5];
+  if(c->timingValid) {
+    for(int k = 1; k < c->evCount; k++) {
+      float ms = 0.f;
+      if(hipEventElapsedTime(&ms, c->ev[k - 1], c->ev[k]) == hipSuccess && c->evStage[k] >= 0) out->stageMs[c->evStage[k]] += ms;
+    }
+    float ms = 0.f;
+    if(c->evCount > 1 && hipEventElapsedTime(&ms, c->ev[0], c->ev[c->evCount - 1]) == hipSuccess) out->frameMs = ms;
+  }
+  return RT_OK;
+}
+
+/* extra introspection used by bench.py / DESIGN.md numbers (not part of the reference-facing surface) */
+int rt_accel_stats(rt_ctx* c, uint64_t* numNodes, uint64_t* numTris, int* maxDepth)
+{
+  if(!c || !c->haveAccel) return RT_ERR_NO_ACCEL;
+  if(numNodes) *numNodes = c->numNodes;
+  if(numTris) *numTris = c->numTris;
+  if(maxDepth) *maxDepth = c->maxDepth;
+  return RT_OK;
+}
+
+}  // extern "C"

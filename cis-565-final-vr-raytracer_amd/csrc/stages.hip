@@ -1,0 +1,619 @@
+// stages.hip — the per-frame kernels of the ReSTIR DI+GI path on gfx950.
+//
+//   k_direct_stage     direct_stage.comp:150-288  (live)     primary ray + G-buffer + M-candidate RIS + shadow ray + temporal reuse + shade
+//   k_direct_gen       direct_gen.comp:77-149     (compiled by the reference, dispatch disabled: renderer.cpp:166-168)
+//   k_direct_reuse     direct_reuse.comp:102-153  (idem, renderer.cpp:170-171)
+//   k_indirect_stage   indirect_stage.comp:129-309, half resolution, tile-level multi-bounce
+//   k_denoise<IND>     denoise_direct.comp / denoise_indirect.comp: one edge-avoiding A-Trous level
+//   k_compose          compose.comp:23-43
+//
+// Launch shape: one wave64 per 8x8 pixel tile (= the reference's 8x8 workgroups, host_device.h:31-38), 1-D grid with
+// an XCD-aware tile order: consecutive workgroup ids land on different XCDs (observed b % 8), so XCD x gets the x-th
+// contiguous band of tile rows and its private 4 MiB L2 sees one compact screen region + the BVH subtrees under it.
+#include "shading.h"
+#include "stages.h"
+
+namespace rt {
+
+// ---- tile / lane bookkeeping ------------------------------------------------------------------------------------
+struct TileCoord { int x, y; bool valid; };
+RT_DEV TileCoord tileOf(int tilesX, int tilesY)
+{
+  const int nTiles = tilesX * tilesY;
+  const int L = int(blockIdx.x);
+  const int chunk = (nTiles + 7) >> 3;
+  const int tile = (L & 7) * chunk + (L >> 3);
+  TileCoord t;
+  t.valid = (L >> 3) < chunk && tile < nTiles;
+  t.y = tile / tilesX;
+  t.x = tile - t.y * tilesX;
+  return t;
+}
+
+RT_DEV void flushCounters(const DevFrame& F, const Ctx& c)
+{
+  if(!F.counters) return;
+  atomicAdd(&F.counters[0], (unsigned long long)c.nClosest);
+  atomicAdd(&F.counters[1], (unsigned long long)c.nAny);
+  atomicAdd(&F.counters[2], (unsigned long long)c.tc.nodes);
+  atomicAdd(&F.counters[3], (unsigned long long)c.tc.tris);
+  atomicAdd(&F.counters[4], (unsigned long long)c.nShaded);
+  atomicAdd(&F.counters[5], (unsigned long long)c.nRis);
+}
+
+// ---- image helpers: Vulkan storage-image semantics (out-of-bounds loads return 0) ------------------------------
+RT_DEV uint4 loadG(const uint4* g, const DevFrame& F, i2 c)
+{
+  if(c.x < 0 || c.y < 0 || c.x >= F.W || c.y >= F.H) return make_uint4(0, 0, 0, 0);
+  return g[size_t(c.y) * F.W + c.x];
+}
+RT_DEV f4 loadImg(const float4* img, const DevFrame& F, i2 c)
+{
+  if(c.x < 0 || c.y < 0 || c.x >= F.W || c.y >= F.H) return mk4(0, 0, 0, 0);
+  const float4 v = img[size_t(c.y) * F.W + c.x];
+  return mk4(v.x, v.y, v.z, v.w);
+}
+RT_DEV void storeImg(float4* img, const DevFrame& F, i2 c, f4 v) { img[size_t(c.y) * F.W + c.x] = make_float4(v.x, v.y, v.z, v.w); }
+RT_DEV short sat16(int v) { return short(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+RT_DEV void storeMotion(const DevFrame& F, i2 c, i2 v) { F.motion[size_t(c.y) * F.W + c.x] = make_short2(sat16(v.x), sat16(v.y)); }  // RG16_SINT
+RT_DEV i2 loadMotion(const DevFrame& F, i2 c)
+{
+  if(c.x < 0 || c.y < 0 || c.x >= F.W || c.y >= F.H) return i2{0, 0};
+  const short2 m = F.motion[size_t(c.y) * F.W + c.x];
+  return i2{int(m.x), int(m.y)};
+}
+
+// ---- shared by the direct stages ---------------------------------------------------------------------------------
+RT_DEV uint4 encodeGeometryInfo(const State& state, float depth)  // direct_stage.comp:37-45
+{
+  uint4 g;
+  g.x = rt_f2u(depth);
+  g.y = compress_unit_vec(state.normal);
+  g.z = packUnorm4x8(mk4(state.mat.metallic, state.mat.roughness, (state.mat.ior - 1.0f) / RT_MAX_IOR_MINUS_ONE, state.mat.transmission));
+  g.w = packUnorm4x8(mk4(state.mat.albedo, 1.0f)) & 0xFFFFFFu;
+  g.w += hash8bit(state.matID);
+  return g;
+}
+RT_DEV void updateGeometryAlbedo(uint4& g, f3 albedo)  // direct_gen.comp:63-66
+{
+  uint32_t matId = g.w & 0xff000000u;
+  g.w = (packUnorm4x8(mk4(albedo, 1.0f)) & 0x00ffffffu) | matId;
+}
+RT_DEV i2 createMotionIndex(const Ctx& c, f3 wpos)  // direct_stage.comp:125-139
+{
+  f4 proj = mul(c.cam.lastProjView, mk4(wpos, 1.0f));
+  f3 ndc = xyz(proj) / proj.w;
+  f2 mv = mk2(ndc.x, ndc.y) * 0.5f + 0.5f;
+  f2 s = mv * mk2(float(c.rtx.size.x), float(c.rtx.size.y));
+  return i2{rt_ftoi(s.x), rt_ftoi(s.y)};
+}
+// direct_stage.comp:47-84 == direct_reuse.comp:52-89
+RT_DEV bool findTemporalNeighborDirect(const DevFrame& F, const rt_state& st, f3 norm, float reprojDepth, uint32_t matId, i2 lastCoord,
+                                       rt_direct_reservoir& resv, uint32_t& lid)
+{
+  const i2 size{st.size.x, st.size.y};
+  if(!inBound(lastCoord, i2{2, 0}, size)) return false;
+  const uint4 g = loadG(F.lastG, F, lastCoord);
+  const f3 pnorm = decompress_unit_vec(g.y);
+  const float pdepth = rt_u2f(g.x);
+  const uint32_t matHash = g.w & 0xFF000000u;
+  if(inBound(lastCoord, size)) {
+    if(hash8bit(matId) == matHash) {
+      if(dot(norm, pnorm) > 0.9f && reprojDepth < pdepth * 1.05f) {
+        const size_t li = size_t(lastCoord.y) * st.size.x + lastCoord.x;
+        resv = F.lastDirectResv[li];
+        lid = F.lastLightId[li];
+        return true;
+      }
+    }
+  }
+  return false;
+}
+// resvUpdate / resvMerge / resvClamp / resvCheckValidity on the AoS reservoir (reservoir.glsl:34-82, 116-128)
+RT_DEV bool resvUpdate(rt_direct_reservoir& r, const rt_light_sample& s, float w, float rr)
+{
+  r.weight += w; r.num += 1;
+  if(rr * r.weight < w) { r.lightSample = s; return true; }
+  return false;
+}
+RT_DEV bool resvMerge(rt_direct_reservoir& r, const rt_direct_reservoir& rhs, float rr)
+{
+  r.weight += rhs.weight; r.num += rhs.num;
+  if(rr * r.weight < rhs.weight) { r.lightSample = rhs.lightSample; return true; }
+  return false;
+}
+template <class R> RT_DEV void resvClamp(R& r, int clamp)
+{
+  if(r.num > uint32_t(clamp)) { r.weight *= float(clamp) / float(r.num); r.num = uint32_t(clamp); }
+}
+RT_DEV rt_direct_reservoir zeroDirectResv()
+{
+  rt_direct_reservoir r;
+  r.lightSample.Li = rt_vec3{0, 0, 0}; r.lightSample.wi = rt_vec3{0, 0, 0}; r.lightSample.dist = 0.f; r.num = 0; r.weight = 0.f;
+  return r;
+}
+
+// the M-candidate RIS loop + visibility of the winner (direct_stage.comp:189-210 == direct_gen.comp:110-132)
+RT_DEV void risCandidates(Ctx& c, const State& state, f3 wo, rt_direct_reservoir& resv, uint32_t& lid)
+{
+  for(int i = 0; i < c.rtx.RISSampleNum; i++) {
+    rt_light_sample ls;
+    float p = c.SampleDirectLightNoVisibility(state.position, ls);
+    f3 pHat = mk3(ls.Li) * metallicWorkflowBSDF(state.mat, state.ffnormal, wo, mk3(ls.wi)) * rt_abs(dot(state.ffnormal, mk3(ls.wi)));
+    float weight = resvToScalar(pHat / p);
+    if(Ctx::IsPdfInvalid(p) || rt_isnan(weight)) weight = 0.0f;
+    if(resvUpdate(resv, ls, weight, rnd(c.seed))) lid = c.lastLightId;
+  }
+  const rt_light_sample ls = resv.lightSample;
+  Ray shadowRay{OffsetRay(state.position, state.ffnormal), mk3(ls.wi)};
+  // a zero-weight reservoir cannot change here (the only effect of the shadow ray is weight := 0): skip the ray
+  if(resv.weight != 0.0f && c.Occlusion(shadowRay, state.position, ls.dist)) resv.weight = 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// direct_stage.comp
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_direct_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY)
+{
+  __shared__ uint2 s_stack[STACK_N * 64];
+  const TileCoord tile = tileOf(tilesX, tilesY);
+  if(!tile.valid) return;
+  const int lane = int(threadIdx.x);
+  const i2 px{tile.x * 8 + (lane & 7), rowBegin + tile.y * 8 + (lane >> 3)};
+  if(px.x >= st.size.x || px.y >= rowEnd) return;
+
+  Ctx c(S, st, cam, s_stack + lane);
+  c.imageCoords = px;
+  const size_t index = size_t(px.y) * st.size.x + px.x;
+  c.seed = tea(uint32_t(st.size.x) * uint32_t(px.y) + uint32_t(px.x), st.time);  // :279
+  const Ray r = c.raySpawn(px, i2{st.size.x, st.size.y});
+
+  f3 radiance;
+  c.ClosestHit(r);
+  if(c.hit.t >= RT_INFINITY) {  // :155-159
+    F.thisG[index] = make_uint4(rt_f2u(RT_INFINITY), 0u, 0u, RT_INVALID_MAT_ID);
+    storeMotion(F, px, i2{0, 0});
+    radiance = c.EnvRadiance(r.direction);
+  } else {
+    State state = c.GetState(r.direction);
+    c.GetMaterials(state, r);
+    const i2 motionIdx = createMotionIndex(c, state.position);
+    const uint4 gInfo = encodeGeometryInfo(state, c.hit.t);
+    storeMotion(F, px, motionIdx);
+    F.thisG[index] = gInfo;
+
+    if(st.debugging_mode > RT_DBG_INDIRECT_STAGE) radiance = c.DebugInfo(state);
+    else if(state.isEmitter) radiance = state.mat.emission;
+    else {
+      const f3 wo = -r.direction;
+      f3 direct = mk3(0.0f);
+      state.mat.albedo = mk3(1.0f);
+      if(st.ReSTIRState == RT_RESTIR_NONE) direct = c.DirectLight(state, wo);
+      else {
+        rt_direct_reservoir resv = zeroDirectResv();
+        uint32_t lid = 0xffffffffu;
+        risCandidates(c, state, wo, resv, lid);
+        if(st.ReSTIRState == RT_RESTIR_TEMPORAL || st.ReSTIRState == RT_RESTIR_SPATIOTEMPORAL) {
+          const float reprojDepth = length(mk3(cam.lastPosition) - state.position);
+          rt_direct_reservoir temporal; uint32_t tlid = 0xffffffffu;
+          if(findTemporalNeighborDirect(F, st, state.normal, reprojDepth, state.matID, motionIdx, temporal, tlid)) {
+            if(!resvInvalidW(temporal.weight)) { if(resvMerge(resv, temporal, rnd(c.seed))) lid = tlid; }
+          }
+        }
+        rt_direct_reservoir tempResv = resv;
+        if(resvInvalidW(tempResv.weight)) { tempResv.num = 0; tempResv.weight = 0.f; }
+        resvClamp(tempResv, st.RISSampleNum * st.reservoirClamp);
+        F.thisDirectResv[index] = tempResv;  // saveNewReservoir
+        F.thisLightId[index] = lid;
+        // in-workgroup spatial reuse (direct_stage.comp:224-255) is SURVEY §8(f) rank 4: not implemented
+        const rt_light_sample ls = resv.lightSample;
+        if(!resvInvalidW(resv.weight)) {
+          f3 LiBsdf = mk3(ls.Li) * metallicWorkflowBSDF(state.mat, state.ffnormal, wo, mk3(ls.wi));
+          direct = LiBsdf / resvToScalar(LiBsdf) * resv.weight / float(resv.num);
+        }
+      }
+      if(rt_isnan(direct.x) || rt_isnan(direct.y) || rt_isnan(direct.z)) direct = mk3(0.0f);
+      radiance = HDRToLDR(c.clampRadiance(state.mat.emission + direct));
+    }
+  }
+  const f3 pixelColor = c.clampRadiance(radiance);
+  storeImg(F.thisDirectResult, F, px, mk4(pixelColor, 1.0f));  // :286
+  flushCounters(F, c);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// direct_gen.comp / direct_reuse.comp
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_direct_gen(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY)
+{
+  __shared__ uint2 s_stack[STACK_N * 64];
+  const TileCoord tile = tileOf(tilesX, tilesY);
+  if(!tile.valid) return;
+  const int lane = int(threadIdx.x);
+  const i2 px{tile.x * 8 + (lane & 7), rowBegin + tile.y * 8 + (lane >> 3)};
+  if(px.x >= st.size.x || px.y >= rowEnd) return;
+  Ctx c(S, st, cam, s_stack + lane);
+  c.imageCoords = px;
+  const size_t index = size_t(px.y) * st.size.x + px.x;
+  c.seed = tea(uint32_t(st.size.x) * uint32_t(px.y) + uint32_t(px.x), st.time);  // direct_gen.comp:146
+  const Ray r = c.raySpawn(px, i2{st.size.x, st.size.y});
+  c.ClosestHit(r);
+  rt_direct_reservoir resv = zeroDirectResv();
+  uint32_t lid = 0xffffffffu;
+  if(c.hit.t >= RT_INFINITY * 0.8f) {  // :86
+    uint4 g = make_uint4(rt_f2u(RT_INFINITY), 0u, 0u, RT_INVALID_MAT_ID);
+    updateGeometryAlbedo(g, c.EnvRadiance(r.direction));
+    F.thisG[index] = g;
+    storeMotion(F, px, i2{0, 0});
+  } else {
+    State state = c.GetState(r.direction);
+    c.GetMaterials(state, r);
+    storeMotion(F, px, createMotionIndex(c, state.position));
+    uint4 g = encodeGeometryInfo(state, c.hit.t);
+    if(st.debugging_mode > RT_DBG_INDIRECT_STAGE) updateGeometryAlbedo(g, c.DebugInfo(state));
+    else if(state.isEmitter) updateGeometryAlbedo(g, state.mat.emission);
+    else {
+      state.mat.albedo = mk3(1.0f);
+      risCandidates(c, state, -r.direction, resv, lid);
+    }
+    F.thisG[index] = g;
+  }
+  F.thisDirectResv[index] = resv;
+  F.thisLightId[index] = lid;
+  flushCounters(F, c);
+}
+
+struct GState { f3 position, normal, ffnormal; Material mat; uint32_t matID; };
+// getDirectStateFromGBuffer / getIndirectStateFromGBuffer, pathtrace.glsl:277-313
+RT_DEV bool stateFromGBuffer(uint4 g, const Ray& ray, GState& s, float& depth)
+{
+  depth = rt_u2f(g.x);
+  if(depth >= RT_INFINITY * 0.8f) return false;
+  s.position = ray.origin + ray.direction * depth;
+  s.normal = decompress_unit_vec(g.y);
+  s.ffnormal = dot(s.normal, ray.direction) <= 0.0f ? s.normal : -s.normal;
+  s.mat.albedo = xyz(unpackUnorm4x8(g.w));
+  s.mat.emission = mk3(0.f);
+  const f4 matInfo = unpackUnorm4x8(g.z);
+  s.mat.metallic = matInfo.x;
+  s.mat.roughness = matInfo.y;
+  s.mat.ior = matInfo.z * RT_MAX_IOR_MINUS_ONE + 1.f;
+  s.mat.transmission = matInfo.w;
+  s.matID = g.w >> 24;
+  return true;
+}
+
+__global__ __launch_bounds__(64) void k_direct_reuse(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY)
+{
+  const TileCoord tile = tileOf(tilesX, tilesY);
+  if(!tile.valid) return;
+  const int lane = int(threadIdx.x);
+  const i2 px{tile.x * 8 + (lane & 7), rowBegin + tile.y * 8 + (lane >> 3)};
+  if(px.x >= st.size.x || px.y >= rowEnd) return;
+  Ctx c(S, st, cam, nullptr);
+  c.imageCoords = px;
+  const int index = px.y * st.size.x + px.x;
+  c.seed = tea(uint32_t(index + st.size.x * st.size.y), st.time);  // direct_reuse.comp:109
+  const Ray ray = c.raySpawn(px, i2{st.size.x, st.size.y});
+  GState state; float depth;
+  if(!stateFromGBuffer(F.thisG[index], ray, state, depth)) { storeImg(F.thisDirectResult, F, px, mk4(0, 0, 0, 0)); return; }
+  f3 direct = mk3(0.0f);
+  rt_direct_reservoir resv = F.thisDirectResv[index];
+  uint32_t lid = F.thisLightId[index];
+  const rt_light_sample ls = resv.lightSample;  // captured before the merge (direct_reuse.comp:124)
+  const i2 motionIdx = loadMotion(F, px);
+  if(st.ReSTIRState == RT_RESTIR_TEMPORAL || st.ReSTIRState == RT_RESTIR_SPATIOTEMPORAL) {
+    const float reprojDepth = length(mk3(cam.lastPosition) - state.position);
+    rt_direct_reservoir temporal; uint32_t tlid = 0xffffffffu;
+    if(findTemporalNeighborDirect(F, st, state.normal, reprojDepth, state.matID, motionIdx, temporal, tlid)) {
+      if(!resvInvalidW(temporal.weight)) { if(resvMerge(resv, temporal, rnd(c.seed))) lid = tlid; }
+    }
+  }
+  if(!resvInvalidW(resv.weight)) direct = mk3(ls.Li);  // :143
+  resvClamp(resv, st.RISSampleNum * st.reservoirClamp);
+  if(resvInvalidW(resv.weight)) { resv.num = 0; resv.weight = 0.f; }
+  if(rt_isnan(direct.x) || rt_isnan(direct.y) || rt_isnan(direct.z)) direct = mk3(0.0f);
+  F.thisDirectResv[index] = resv;
+  F.thisLightId[index] = lid;
+  storeImg(F.thisDirectResult, F, px, mk4(HDRToLDR(c.clampRadiance(direct)), 1.0f));
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// indirect_stage.comp
+// ------------------------------------------------------------------------------------------------------------
+RT_DEV rt_gi_sample newGISample()  // :110-115
+{
+  rt_gi_sample s;
+  s.L = rt_vec3{0, 0, 0}; s.xv = rt_vec3{0, 0, 0}; s.nv = rt_vec3{100.0f, 100.0f, 100.0f}; s.xs = rt_vec3{0, 0, 0}; s.ns = rt_vec3{0, 0, 0}; s.pHat = 0.f;
+  return s;
+}
+RT_DEV bool GISampleValid(const rt_gi_sample& s) { return s.nv.x < 1.1f && !hasNan(mk3(s.L)); }  // :117-119
+RT_DEV float MISw(const rt_state& st, float f, float g) { return (st.MIS > 0) ? powerHeuristic(f, g) : 1.0f; }  // :57-59
+
+__global__ __launch_bounds__(64) void k_indirect_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY)
+{
+  __shared__ uint2 s_stack[STACK_N * 64];
+  const TileCoord tile = tileOf(tilesX, tilesY);
+  if(!tile.valid) return;
+  const int lane = int(threadIdx.x);
+  const i2 indSize{st.size.x / 2, st.size.y / 2};
+  const i2 px{tile.x * 8 + (lane & 7), rowBegin + tile.y * 8 + (lane >> 3)};
+  Ctx c(S, st, cam, s_stack + lane);
+  c.imageCoords = px;
+  c.seed = tea(uint32_t(indSize.x) * uint32_t(px.y) + uint32_t(px.x), st.time);  // :280
+  // TILED_MULTIBOUNCE (:283-288): invocation 0 of the workgroup draws the tile flag from its own stream; the tile is
+  // one wave64, so the flag is wave-uniform and costs one readfirstlane instead of shared memory + barrier.
+  int mb = 0;
+  if(lane == 0) mb = rnd(c.seed) < 0.25f ? 1 : 0;
+  const bool multiBounce = __builtin_amdgcn_readfirstlane(mb) != 0;
+  if(px.x >= indSize.x || px.y >= indSize.y || px.y >= rowEnd) return;
+  Ray ray = c.raySpawn(px, indSize);
+
+  GState g0; float depth;
+  if(!stateFromGBuffer(loadG(F.thisG, F, i2{px.x * 2, px.y * 2}), ray, g0, depth)) {
+    storeImg(F.denoiseIndA, F, px, mk4(0, 0, 0, 0));
+    flushCounters(F, c);
+    return;
+  }
+  g0.position += g0.ffnormal * 2e-2f;  // :299
+
+  // ---- pathTraceIndirect, :129-226 --------------------------------------------------------------------------
+  f3 throughput = mk3(multiBounce ? 4.0f : 1.0f);
+  const f3 primWo = -ray.direction;
+  const GState primState = g0;
+  rt_gi_sample gi = newGISample();
+  float primSamplePdf = 0.0f;
+  State state = zeroState();
+  state.position = g0.position; state.normal = g0.normal; state.ffnormal = g0.ffnormal; state.mat = g0.mat; state.matID = g0.matID;
+  state.mat.albedo = mk3(1.0f);
+  bool earlyReturn = false;
+  for(int depthI = 1; depthI <= st.maxDepth; depthI++) {
+    const f3 wo = -ray.direction;
+    if(depthI > 1 && st.MIS > 0) {
+      f3 Li = mk3(0.0f), wi = mk3(0.0f);
+      const float lightPdf = c.SampleDirectLight(state, Li, wi);
+      if(!Ctx::IsPdfInvalid(lightPdf)) {
+        const float BSDFPdf = metallicWorkflowPdf(state.mat, state.ffnormal, wo, wi);
+        const float weight = MISw(st, lightPdf, BSDFPdf);
+        const f3 add = Li * metallicWorkflowBSDF(state.mat, state.ffnormal, wo, wi) * absDot(state.ffnormal, wi) * throughput / lightPdf * weight;
+        gi.L = toR(mk3(gi.L) + add);
+      }
+    }
+    f3 sampleWi = mk3(0.0f);
+    float samplePdf = 0.0f;
+    const f3 sampleBSDF = c.Sample(state.mat, wo, state.ffnormal, sampleWi, samplePdf);
+    if(Ctx::IsPdfInvalid(samplePdf)) break;
+    if(depthI > 1) {
+      if(!multiBounce) { earlyReturn = true; break; }
+      throughput *= sampleBSDF / samplePdf * absDot(state.ffnormal, sampleWi);
+    } else {
+      primSamplePdf = samplePdf;
+      gi.xv = toR(state.position);
+      gi.nv = toR(state.ffnormal);
+    }
+    ray.origin = OffsetRay(state.position, state.ffnormal);
+    ray.direction = sampleWi;
+    c.ClosestHit(ray);
+    if(c.hit.t >= RT_INFINITY - 1e-4f) {
+      if(depthI > 1) {
+        float lightPdf;
+        const f3 Li = c.EnvEval(sampleWi, lightPdf);
+        const float weight = MISw(st, samplePdf, lightPdf);
+        gi.L = toR(mk3(gi.L) + Li * throughput * weight);
+      } else {
+        gi.xs = toR(state.position + sampleWi * RT_INFINITY * 0.8f);
+        gi.ns = toR(-sampleWi);
+      }
+      break;
+    }
+    state = c.GetState(ray.direction);
+    c.GetMaterials(state, ray);
+    if(state.isEmitter) {
+      if(depthI > 1) {
+        float lightPdf;
+        const f3 Li = c.LightEval(state, c.hit.t, sampleWi, lightPdf);
+        const float weight = MISw(st, samplePdf, lightPdf);
+        gi.L = toR(mk3(gi.L) + Li * throughput * weight);
+      } else {
+        gi.xs = toR(state.position);
+        gi.ns = toR(state.ffnormal);
+      }
+      break;
+    }
+    if(depthI == 1) { gi.xs = toR(state.position); gi.ns = toR(state.ffnormal); }
+    // Russian roulette (:218-224) is compiled out in the reference (`#ifndef RR`, pathtrace.glsl:2)
+  }
+  (void)earlyReturn;
+
+  // ---- ReSTIRIndirect, :228-268 (+ findTemporalNeighbor :74-108) -------------------------------------------------
+  f3 indirect = mk3(0.0f);
+  rt_indirect_reservoir resv;
+  resv.giSample.L = rt_vec3{0, 0, 0}; resv.giSample.xv = rt_vec3{0, 0, 0}; resv.giSample.nv = rt_vec3{0, 0, 0};
+  resv.giSample.xs = rt_vec3{0, 0, 0}; resv.giSample.ns = rt_vec3{0, 0, 0}; resv.giSample.pHat = 0.f;
+  resv.num = 0; resv.weight = 0.f; resv.bigW = 0.f;
+  if(st.ReSTIRState == RT_RESTIR_TEMPORAL || st.ReSTIRState == RT_RESTIR_SPATIOTEMPORAL) {
+    const float reprojDepth = length(mk3(cam.lastPosition) - primState.position);
+    const i2 motionIdx = loadMotion(F, i2{px.x * 2, px.y * 2});
+    const uint4 lg = loadG(F.lastG, F, motionIdx);
+    const f3 pnorm = decompress_unit_vec(lg.y);
+    const float pdepth = rt_u2f(lg.x);
+    const uint32_t matHash = lg.w & 0xFF000000u;
+    const i2 coord{motionIdx.x / 2, motionIdx.y / 2};
+    if(inBound(coord, indSize)) {
+      if(hash8bit(primState.matID) == matHash) {
+        if(dot(primState.ffnormal, pnorm) > 0.5f && reprojDepth < pdepth * 1.1f) resv = F.lastIndirectResv[size_t(coord.y) * indSize.x + coord.x];
+      }
+    }
+  }
+  float sampleWeight = 0.0f;
+  if(GISampleValid(gi)) {
+    gi.pHat = resvToScalar(mk3(gi.L));  // pHatIndirect :61-66
+    sampleWeight = gi.pHat / primSamplePdf;
+    if(rt_isnan(sampleWeight) || sampleWeight < 0.0f) sampleWeight = 0.0f;
+  }
+  {  // resvUpdate :54-60
+    const float rr = rnd(c.seed);
+    resv.weight += sampleWeight; resv.num += 1;
+    if(rr * resv.weight < sampleWeight) resv.giSample = gi;
+  }
+  if(resvInvalidW(resv.weight)) { resv.num = 0; resv.weight = 0.f; resv.bigW = 0.f; }
+  resvClamp(resv, st.reservoirClamp * 2);
+  F.thisIndirectResv[size_t(px.y) * indSize.x + px.x] = resv;  // saveNewReservoir
+
+  gi = resv.giSample;
+  if(!resvInvalidW(resv.weight) && GISampleValid(gi)) {
+    const f3 primWi = normalize(mk3(gi.xs) - mk3(gi.xv));
+    Material pm = primState.mat;
+    pm.albedo = mk3(1.0f);
+    const float bigW = resv.weight / (resvToScalar(mk3(resv.giSample.L)) * float(resv.num));  // bigWIndirect :68-70
+    indirect = mk3(gi.L) * metallicWorkflowBSDF(pm, mk3(gi.nv), primWo, primWi) * satDot(mk3(gi.nv), primWi) * bigW;
+  }
+  f3 pixelColor = HDRToLDR(c.clampRadiance(indirect));
+  pixelColor = c.clampRadiance(pixelColor);
+  storeImg(F.denoiseIndA, F, px, mk4(pixelColor, 1.0f));
+  flushCounters(F, c);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// denoise_common.glsl + denoise_direct.comp + denoise_indirect.comp
+// ------------------------------------------------------------------------------------------------------------
+__constant__ float c_gauss[5][5] = {{.0030f, .0133f, .0219f, .0133f, .0030f},
+                                    {.0133f, .0596f, .0983f, .0596f, .0133f},
+                                    {.0219f, .0983f, .1621f, .0983f, .0219f},
+                                    {.0133f, .0596f, .0983f, .0596f, .0133f},
+                                    {.0030f, .0133f, .0219f, .0133f, .0030f}};  // denoise_common.glsl:15-21
+
+// denoise_common.glsl:27-40: the direction is not re-normalised after the view transform
+RT_DEV f3 cameraPosDenoise(const rt_scene_camera& cam, i2 coord, float dist, i2 imageSize)
+{
+  const f2 pixelCenter = mk2(float(coord.x), float(coord.y)) + 0.5f;
+  const f2 inUV = pixelCenter / mk2(float(imageSize.x), float(imageSize.y));
+  const f2 d = inUV * 2.0f - 1.0f;
+  const f4 origin = mul(cam.viewInverse, mk4(0, 0, 0, 1));
+  const f4 target = mul(cam.projInverse, mk4(d.x, d.y, 1, 1));
+  const f4 direction = mul(cam.viewInverse, mk4(normalize(xyz(target)), 0));
+  return xyz(origin) + xyz(direction) * dist;
+}
+
+template <bool IND>
+__global__ __launch_bounds__(64) void k_denoise(DevFrame F, rt_state st, rt_scene_camera cam, const float4* src, float4* dst, int level, int rowBegin, int rowEnd,
+                                                int tilesX, int tilesY)
+{
+  const TileCoord tile = tileOf(tilesX, tilesY);
+  if(!tile.valid) return;
+  const int lane = int(threadIdx.x);
+  const i2 bound = IND ? i2{st.size.x / 2, st.size.y / 2} : i2{st.size.x, st.size.y};
+  const i2 coord{tile.x * 8 + (lane & 7), rowBegin + tile.y * 8 + (lane >> 3)};
+  if(coord.x >= bound.x || coord.y >= bound.y || coord.y >= rowEnd) return;
+  const float sigLumin = IND ? st.sigLuminIndirect : st.sigLuminDirect;
+  const float sigNormal = IND ? st.sigNormalIndirect : st.sigNormalDirect;
+  const float sigDepth = IND ? st.sigDepthIndirect : st.sigDepthDirect;
+  const int last = IND ? 4 : 3;
+
+  const i2 gc = IND ? i2{coord.x * 2, coord.y * 2} : coord;
+  const uint4 g = loadG(F.thisG, F, gc);
+  const f3 norm = decompress_unit_vec(g.y);
+  const f3 pos = cameraPosDenoise(cam, gc, rt_u2f(g.x), bound);
+  const uint32_t matHash = g.w & 0xFF000000u;
+
+  f3 res = mk3(0.0f);
+  if(matHash != RT_INVALID_MAT_ID) {  // waveletFilter, denoise_direct.comp:19-71 / denoise_indirect.comp:23-75
+    const int step = 1 << level;
+    f3 sum = mk3(0.0f);
+    float sumWeight = 0.0f;
+    const f3 color = xyz(loadImg(src, F, coord));
+    for(int j = -2; j <= 2; j++) {
+      for(int i = -2; i <= 2; i++) {
+        const i2 q{coord.x + i * step, coord.y + j * step};
+        if(q.x >= bound.x || q.y >= bound.y || q.x < 0 || q.y < 0) continue;
+        const i2 gq = IND ? i2{q.x * 2, q.y * 2} : q;
+        const uint4 gQ = loadG(F.thisG, F, gq);
+        const uint32_t matHashQ = gQ.w & 0xFF000000u;
+        if(matHash != matHashQ || matHashQ == RT_INVALID_MAT_ID) continue;
+        const f3 normQ = decompress_unit_vec(gQ.y);
+        const f3 posQ = cameraPosDenoise(cam, gq, rt_u2f(gQ.x), bound);
+        const f3 colorQ = xyz(loadImg(src, F, q));
+        const float distColor = IND ? dot(color - colorQ, color - colorQ) : rt_abs(luminance(color) - luminance(colorQ));
+        const float wColor = rt_exp(-distColor / sigLumin) + 1e-2f;
+        const float distNorm2 = dot(norm - normQ, norm - normQ);
+        const float wNorm = rt_min(1.0f, rt_exp(-distNorm2 / sigNormal));
+        const float distPos2 = dot(pos - posQ, pos - posQ);
+        const float wDepth = rt_exp(-distPos2 / sigDepth) + 1e-2f;
+        const float weight = wColor * wNorm * wDepth * c_gauss[i + 2][j + 2];
+        sum += colorQ * weight;
+        sumWeight += weight;
+      }
+    }
+    res = (sumWeight < 1e-5f) ? mk3(0.0f) : sum / sumWeight;
+    if(hasNan(res) || res.x < 0 || res.y < 0 || res.z < 0 || res.x > 1e8f || res.y > 1e8f || res.z > 1e8f) res = mk3(0.0f);
+  }
+  if(level == last) res = LDRToHDR(res);
+  storeImg(dst, F, coord, mk4(res, 1.0f));
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// compose.comp:23-43
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_compose(DevFrame F, rt_state st, int rowBegin, int rowEnd, int tilesX, int tilesY)
+{
+  const TileCoord tile = tileOf(tilesX, tilesY);
+  if(!tile.valid) return;
+  const int lane = int(threadIdx.x);
+  const i2 coord{tile.x * 8 + (lane & 7), rowBegin + tile.y * 8 + (lane >> 3)};
+  if(coord.x >= st.size.x || coord.y >= st.size.y || coord.y >= rowEnd) return;
+  const float4* indSrc = (st.denoise > 0) ? F.denoiseIndB : F.denoiseIndA;
+  const i2 half{coord.x / 2, coord.y / 2};
+  if(st.modulate == 0) {
+    storeImg(F.thisIndirectResult, F, coord, loadImg(indSrc, F, half));
+  } else {
+    const f3 albedo = xyz(unpackUnorm4x8(loadG(F.thisG, F, coord).w));
+    const f3 direct = xyz(loadImg(F.thisDirectResult, F, coord)) * albedo;
+    const f3 indirect = xyz(loadImg(indSrc, F, half)) * albedo;
+    storeImg(F.thisDirectResult, F, coord, mk4(direct, 1.0f));
+    storeImg(F.thisIndirectResult, F, coord, mk4(indirect, 1.0f));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host-side launch (one entry of Renderer::run's dispatch list, renderer.cpp:163-205)
+// ------------------------------------------------------------------------------------------------------------
+hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F, const rt_state& st, const rt_scene_camera& cam, int stage, int level,
+                       int rowBegin, int rowEnd)
+{
+  const bool half = (stage == RT_STAGE_INDIRECT || stage == RT_STAGE_DENOISE_INDIRECT);
+  const int gw = half ? st.size.x / 2 : st.size.x, gh = half ? st.size.y / 2 : st.size.y;
+  if(rowEnd <= 0 || rowEnd > gh) rowEnd = gh;
+  if(rowBegin < 0) rowBegin = 0;
+  if(rowBegin >= rowEnd || gw <= 0) return hipSuccess;
+  const int tilesX = (gw + 7) / 8, tilesY = (rowEnd - rowBegin + 7) / 8;
+  const int nTiles = tilesX * tilesY;
+  const dim3 grid(unsigned(((nTiles + 7) / 8) * 8)), block(64);
+  switch(stage) {
+    case RT_STAGE_DIRECT: hipLaunchKernelGGL(k_direct_stage, grid, block, 0, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY); break;
+    case RT_STAGE_DIRECT_GEN: hipLaunchKernelGGL(k_direct_gen, grid, block, 0, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY); break;
+    case RT_STAGE_DIRECT_REUSE: hipLaunchKernelGGL(k_direct_reuse, grid, block, 0, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY); break;
+    case RT_STAGE_INDIRECT: hipLaunchKernelGGL(k_indirect_stage, grid, block, 0, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY); break;
+    case RT_STAGE_DENOISE_DIRECT: {
+      // DirectResult -> DirA -> DirB -> DirA -> DirectResult (denoise_direct.comp:152-172)
+      const float4* src[4] = {F.thisDirectResult, F.denoiseDirA, F.denoiseDirB, F.denoiseDirA};
+      float4* dst[4] = {F.denoiseDirA, F.denoiseDirB, F.denoiseDirA, F.thisDirectResult};
+      if(level < 0 || level > 3) return hipErrorInvalidValue;
+      hipLaunchKernelGGL(k_denoise<false>, grid, block, 0, stream, F, st, cam, src[level], dst[level], level, rowBegin, rowEnd, tilesX, tilesY);
+      break;
+    }
+    case RT_STAGE_DENOISE_INDIRECT: {
+      // IndA -> IndB -> IndA -> thisIndirectResult (scratch) -> IndA -> IndB (denoise_indirect.comp:146-171)
+      if(st.denoise == 0) return hipSuccess;
+      const float4* src[5] = {F.denoiseIndA, F.denoiseIndB, F.denoiseIndA, F.thisIndirectResult, F.denoiseIndA};
+      float4* dst[5] = {F.denoiseIndB, F.denoiseIndA, F.thisIndirectResult, F.denoiseIndA, F.denoiseIndB};
+      if(level < 0 || level > 4) return hipErrorInvalidValue;
+      hipLaunchKernelGGL(k_denoise<true>, grid, block, 0, stream, F, st, cam, src[level], dst[level], level, rowBegin, rowEnd, tilesX, tilesY);
+      break;
+    }
+    case RT_STAGE_COMPOSE: hipLaunchKernelGGL(k_compose, grid, block, 0, stream, F, st, rowBegin, rowEnd, tilesX, tilesY); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace rt

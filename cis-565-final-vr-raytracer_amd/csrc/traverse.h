@@ -1,0 +1,246 @@
+// traverse.h — software ray query on gfx950: ClosestHit / AnyHit of shaders/traceray_rq.glsl:108-185 over the flat
+// BVH8 of bvh8.h.  One ray per lane, one wave64 per 8x8 pixel tile; the traversal stack lives in LDS
+// (STACK_N x 64 lanes x 8 B, entry-major so each lane owns one 8-byte column => conflict-free ds_read/write_b64).
+//
+// Semantics kept from the reference's ray flags: tmin 0 (exclusive), gl_RayFlagsCullBackFacingTrianglesEXT,
+// per-instance FORCE_OPAQUE / TRIANGLE_FACING_CULL_DISABLE (accelstruct.cpp:145-149), candidates of non-opaque
+// instances go through HitTest (traceray_rq.glsl:32-102).  Closest hit = lexicographic minimum of (t, globalId);
+// box tests use FMAs and are conservative w.r.t. the exact (non-contracted) triangle test.
+#pragma once
+#include "dev_math.h"
+#include "dev_scene.h"
+#include "stages.h"
+
+namespace rt {
+
+
+
+struct RayHit {
+  float t;
+  uint32_t gid;  // globalId of the hit triangle (0xffffffff = miss)
+  float u, v;
+};
+
+struct TravCounters { uint32_t nodes, tris; };
+
+// ---- texture fetch: Vulkan sampler restatement, LOD 0 (scene.cpp:513-548) -----------------
+RT_DEV int wrapCoord(int i, int n, int mode)
+{
+  if(mode == RT_WRAP_CLAMP) return i < 0 ? 0 : (i >= n ? n - 1 : i);
+  if(mode == RT_WRAP_MIRROR) {
+    int p = 2 * n;
+    int m = i % p; if(m < 0) m += p;
+    return m < n ? m : p - 1 - m;
+  }
+  int m = i % n; if(m < 0) m += n;
+  return m;
+}
+RT_DEV f4 texelBGRA(const DevTexture& t, int x, int y)
+{
+  uint32_t p = *reinterpret_cast<const uint32_t*>(t.bgra + (size_t(y) * t.w + x) * 4);
+  return mk4(float((p >> 16) & 0xffu) / 255.0f, float((p >> 8) & 0xffu) / 255.0f, float(p & 0xffu) / 255.0f, float(p >> 24) / 255.0f);
+}
+RT_DEV f4 sampleTexture(const DevScene& S, int id, f2 uv)
+{
+  const DevTexture t = S.textures[id];
+  float fx = uv.x * float(t.w), fy = uv.y * float(t.h);
+  if(t.filter == RT_FILTER_NEAREST) {
+    int x = wrapCoord(rt_ftoi(rt_floor(fx)), t.w, t.wrapS), y = wrapCoord(rt_ftoi(rt_floor(fy)), t.h, t.wrapT);
+    return texelBGRA(t, x, y);
+  }
+  fx = fx - 0.5f; fy = fy - 0.5f;
+  float x0f = rt_floor(fx), y0f = rt_floor(fy);
+  float ax = fx - x0f, ay = fy - y0f;
+  int x0 = rt_ftoi(x0f), y0 = rt_ftoi(y0f);
+  int xa = wrapCoord(x0, t.w, t.wrapS), xb = wrapCoord(x0 + 1, t.w, t.wrapS);
+  int ya = wrapCoord(y0, t.h, t.wrapT), yb = wrapCoord(y0 + 1, t.h, t.wrapT);
+  f4 top = mix(texelBGRA(t, xa, ya), texelBGRA(t, xb, ya), ax);
+  f4 bot = mix(texelBGRA(t, xa, yb), texelBGRA(t, xb, yb), ax);
+  return mix(top, bot, ay);
+}
+RT_DEV f4 envTexel(const DevScene& S, int x, int y)
+{
+  const float4 p = *reinterpret_cast<const float4*>(S.env + (size_t(y) * S.envW + x) * 4);
+  return mk4(p.x, p.y, p.z, p.w);
+}
+// environmentTexture: linear, U repeat, V clamp-to-edge (hdr_sampling.cpp:69-77)
+RT_DEV f4 sampleEnv(const DevScene& S, f2 uv)
+{
+  float fx = uv.x * float(S.envW) - 0.5f, fy = uv.y * float(S.envH) - 0.5f;
+  float x0f = rt_floor(fx), y0f = rt_floor(fy);
+  float ax = fx - x0f, ay = fy - y0f;
+  int x0 = rt_ftoi(x0f), y0 = rt_ftoi(y0f);
+  int xa = wrapCoord(x0, S.envW, RT_WRAP_REPEAT), xb = wrapCoord(x0 + 1, S.envW, RT_WRAP_REPEAT);
+  int ya = wrapCoord(y0, S.envH, RT_WRAP_CLAMP), yb = wrapCoord(y0 + 1, S.envH, RT_WRAP_CLAMP);
+  f4 top = mix(envTexel(S, xa, ya), envTexel(S, xb, ya), ax);
+  f4 bot = mix(envTexel(S, xa, yb), envTexel(S, xb, yb), ax);
+  return mix(top, bot, ay);
+}
+
+RT_DEV uint32_t pcgNext(uint32_t& state)  // random.glsl:59-65
+{
+  uint32_t prev = state * 747796405u + 2891336453u;
+  uint32_t word = ((prev >> ((prev >> 28u) + 4u)) ^ prev) * 277803737u;
+  state = prev;
+  return (word >> 22u) ^ word;
+}
+RT_DEV float rnd(uint32_t& seed)  // rand(), random.glsl:98-102
+{
+  uint32_t r = pcgNext(seed);
+  return rt_u2f(0x3f800000u | (r >> 9)) - 1.0f;
+}
+
+// HitTest, traceray_rq.glsl:32-102.  The stochastic draw comes from a hash of (ray seed, triangle id) instead of
+// advancing prd.seed per candidate, so the outcome does not depend on candidate order.
+__device__ __noinline__ bool hitTestAlpha(const DevScene& S, uint32_t gid, float u, float v, uint32_t raySeed)
+{
+  const TriRef ref = S.triRef[gid];
+  const rt_prim_mesh pm = S.primMeshes[S.instances[ref.inst].primMesh];
+  const uint32_t matIndex = uint32_t(pm.materialIndex > 0 ? pm.materialIndex : 0);
+  const rt_material* mat = &S.materials[matIndex];
+  float baseColorAlpha = mat->pbrBaseColorFactor.w;
+  const int tex = mat->pbrBaseColorTexture;
+  if(tex > -1) {
+    const uint32_t* ix = &S.indices[pm.firstIndex + 3 * ref.prim];
+    const rt_vec2 t0 = S.vertices[pm.vertexOffset + ix[0]].texcoord, t1 = S.vertices[pm.vertexOffset + ix[1]].texcoord,
+                  t2 = S.vertices[pm.vertexOffset + ix[2]].texcoord;
+    const f3 bary = mk3((1.0f - u) - v, u, v);
+    f2 uv = (mk2(t0.x, t0.y) * bary.x + mk2(t1.x, t1.y) * bary.y) + mk2(t2.x, t2.y) * bary.z;
+    baseColorAlpha = baseColorAlpha * sampleTexture(S, tex, uv).w;
+  }
+  float opacity;
+  if(mat->alphaMode == RT_ALPHA_MASK) opacity = baseColorAlpha > mat->alphaCutoff ? 1.0f : 0.0f;
+  else opacity = baseColorAlpha;
+  uint32_t s = raySeed ^ (gid * 2654435761u);
+  float r = rnd(s);
+  return !(r > opacity);
+}
+
+// Möller–Trumbore in the fixed operation order of DESIGN.md §Numerics (this TU is compiled with -ffp-contract=off)
+RT_DEV bool intersectTri(const Tri48& T, f3 o, f3 d, float& t, float& u, float& v)
+{
+  const f3 e1 = mk3(T.e1x, T.e1y, T.e1z), e2 = mk3(T.e2x, T.e2y, T.e2z), v0 = mk3(T.v0x, T.v0y, T.v0z);
+  const f3 p = cross(d, e2);
+  const float det = dot(e1, p);
+  if(T.flags & TRI_NOCULL) { if(det == 0.0f || rt_isnan(det)) return false; }
+  else {
+    const float sdet = (T.flags & TRI_FLIP) ? -det : det;
+    if(!(sdet > 0.0f)) return false;
+  }
+  const float inv = 1.0f / det;
+  const f3 tv = o - v0;
+  u = dot(tv, p) * inv;
+  if(!(u >= 0.0f && u <= 1.0f)) return false;
+  const f3 q = cross(tv, e1);
+  v = dot(d, q) * inv;
+  if(!(v >= 0.0f && u + v <= 1.0f)) return false;
+  t = dot(e2, q) * inv;
+  return !rt_isnan(t);
+}
+
+RT_DEV float cvtByte(uint32_t w, int j) { return float((w >> (8 * j)) & 0xffu); }  // v_cvt_f32_ubyte{j}
+
+// ANY = false: closest hit in (0, 1e28); ANY = true: first accepted hit in (0, tmax).
+// `stack` points at this lane's column of the wave's LDS stack (stride 64 entries).
+template <bool ANY>
+RT_DEV bool traceRay(const DevScene& S, f3 o, f3 d, float tmax, uint32_t raySeed, uint2* stack, RayHit& hit, TravCounters& tc)
+{
+  hit.t = ANY ? tmax : RT_INFINITY;
+  hit.gid = 0xffffffffu; hit.u = 0.f; hit.v = 0.f;
+  if(hasNan(o) || hasNan(d) || !(hit.t > 0.0f)) return false;
+
+  // reciprocal direction with a floor on |d| (a zero component must not produce inf*0 = NaN in the slab test)
+  const float eps = 1e-20f;
+  const float idx = 1.0f / (rt_abs(d.x) > eps ? d.x : (d.x < 0.0f ? -eps : eps));
+  const float idy = 1.0f / (rt_abs(d.y) > eps ? d.y : (d.y < 0.0f ? -eps : eps));
+  const float idz = 1.0f / (rt_abs(d.z) > eps ? d.z : (d.z < 0.0f ? -eps : eps));
+  const bool nx = d.x < 0.0f, ny = d.y < 0.0f, nz = d.z < 0.0f;
+  const uint32_t octinv = ((nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u)) ^ 7u;
+  const uint32_t octinv4 = octinv * 0x01010101u;
+
+  uint2 ngroup = make_uint2(0u, 0x80000000u);
+  uint2 tgroup = make_uint2(0u, 0u);
+  int sp = 0;
+  bool found = false;
+
+  for(;;) {
+    if(ngroup.y > 0x00FFFFFFu) {
+      const uint32_t hits = ngroup.y;
+      const uint32_t bit = 31u - uint32_t(__clz(int(hits)));
+      ngroup.y &= ~(1u << bit);
+      if(ngroup.y > 0x00FFFFFFu) { if(sp < STACK_N) stack[(sp++) * 64] = ngroup; }
+      const uint32_t slot = (bit - 24u) ^ octinv;
+      const uint32_t rel = uint32_t(__popc(hits & ~(0xFFFFFFFFu << slot) & 0xFFu));
+      const uint4* np = reinterpret_cast<const uint4*>(S.nodes + (ngroup.x + rel));
+      const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+      tc.nodes++;
+
+      const float adjx = rt_u2f((n0.w & 0xffu) << 23) * idx;
+      const float adjy = rt_u2f(((n0.w >> 8) & 0xffu) << 23) * idy;
+      const float adjz = rt_u2f(((n0.w >> 16) & 0xffu) << 23) * idz;
+      const float orgx = (rt_u2f(n0.x) - o.x) * idx, orgy = (rt_u2f(n0.y) - o.y) * idy, orgz = (rt_u2f(n0.z) - o.z) * idz;
+      const uint32_t imask = n0.w >> 24;
+      uint32_t hitmask = 0;
+#pragma unroll
+      for(int half = 0; half < 2; half++) {
+        const uint32_t meta4 = half ? n1.w : n1.z;
+        const uint32_t isInner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
+        const uint32_t innerMask4 = (isInner4 >> 4) * 0xffu;
+        const uint32_t bitIndex4 = (meta4 ^ (octinv4 & innerMask4)) & 0x1F1F1F1Fu;
+        const uint32_t childBits4 = (meta4 >> 5) & 0x07070707u;
+        const uint32_t qlx = half ? n2.y : n2.x, qly = half ? n2.w : n2.z, qlz = half ? n3.y : n3.x;
+        const uint32_t qhx = half ? n3.w : n3.z, qhy = half ? n4.y : n4.x, qhz = half ? n4.w : n4.z;
+        const uint32_t nearx = nx ? qhx : qlx, farx = nx ? qlx : qhx;
+        const uint32_t neary = ny ? qhy : qly, fary = ny ? qly : qhy;
+        const uint32_t nearz = nz ? qhz : qlz, farz = nz ? qlz : qhz;
+#pragma unroll
+        for(int j = 0; j < 4; j++) {
+          const float tlx = __builtin_fmaf(cvtByte(nearx, j), adjx, orgx), thx = __builtin_fmaf(cvtByte(farx, j), adjx, orgx);
+          const float tly = __builtin_fmaf(cvtByte(neary, j), adjy, orgy), thy = __builtin_fmaf(cvtByte(fary, j), adjy, orgy);
+          const float tlz = __builtin_fmaf(cvtByte(nearz, j), adjz, orgz), thz = __builtin_fmaf(cvtByte(farz, j), adjz, orgz);
+          const float tn = fmaxf(fmaxf(tlx, tly), fmaxf(tlz, 0.0f));
+          const float tf = fminf(fminf(thx, thy), fminf(thz, hit.t));
+          if(tn <= tf) hitmask |= ((childBits4 >> (8 * j)) & 0xffu) << ((bitIndex4 >> (8 * j)) & 0xffu);
+        }
+      }
+      ngroup = make_uint2(n1.x, (hitmask & 0xFF000000u) | imask);
+      tgroup = make_uint2(n1.y, hitmask & 0x00FFFFFFu);
+    } else {
+      tgroup = ngroup;
+      ngroup = make_uint2(0u, 0u);
+    }
+
+    while(tgroup.y != 0u) {
+      const uint32_t bit = 31u - uint32_t(__clz(int(tgroup.y)));
+      tgroup.y &= ~(1u << bit);
+      const uint4* tp = reinterpret_cast<const uint4*>(S.tris + (tgroup.x + bit));
+      const uint4 a = tp[0], b = tp[1], c = tp[2];
+      Tri48 T;
+      T.v0x = rt_u2f(a.x); T.v0y = rt_u2f(a.y); T.v0z = rt_u2f(a.z); T.e1x = rt_u2f(a.w);
+      T.e1y = rt_u2f(b.x); T.e1z = rt_u2f(b.y); T.e2x = rt_u2f(b.z); T.e2y = rt_u2f(b.w);
+      T.e2z = rt_u2f(c.x); T.globalId = c.y; T.flags = c.z;
+      tc.tris++;
+      float t, u, v;
+      if(!intersectTri(T, o, d, t, u, v)) continue;
+      if(ANY) {
+        if(!(t > 0.0f && t < tmax)) continue;
+      } else {
+        if(!(t > 0.0f && t < RT_INFINITY)) continue;
+        if(!(t < hit.t || (t == hit.t && T.globalId < hit.gid))) continue;
+      }
+      if(!(T.flags & TRI_OPAQUE) && !hitTestAlpha(S, T.globalId, u, v, raySeed)) continue;
+      hit.t = t; hit.gid = T.globalId; hit.u = u; hit.v = v;
+      found = true;
+      if(ANY) break;
+    }
+    if(ANY && found) break;
+
+    if(ngroup.y <= 0x00FFFFFFu) {
+      if(sp == 0) break;
+      ngroup = stack[(--sp) * 64];
+    }
+  }
+  return found;
+}
+
+}  // namespace rt

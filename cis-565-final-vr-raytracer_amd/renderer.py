@@ -1,0 +1,152 @@
+"""Renderer: the reference's stage dispatcher (src/renderer.hpp:49-61) over the C-ABI of csrc/librestir_hip.so.
+
+setup / create / run / update / destroy keep the reference's names and order; the Vulkan handle parameters are gone.
+There is no CPU path: if the HIP library or a GPU is missing every entry point raises.
+"""
+import ctypes as C
+import os
+import numpy as np
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(_HERE, "csrc", "librestir_hip.so")
+_lib = None
+
+# every symbol include/rt_abi.h declares (tests check that the library exports all of them)
+ABI_SYMBOLS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_build_accel", "rt_resize", "rt_set_camera",
+               "rt_render_frame", "rt_run_stage", "rt_readback", "rt_upload_history", "rt_buffer_bytes", "rt_device_ptr",
+               "rt_set_counting", "rt_get_counters", "rt_sync", "rt_last_error", "rt_abi_version"]
+
+
+def hip_lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(HIP_LIB_PATH):
+            raise RuntimeError(f"{HIP_LIB_PATH} is missing — build it with __graft_entry__.build(); this package has no fallback path")
+        L = C.CDLL(HIP_LIB_PATH)
+        L.rt_last_error.restype = C.c_char_p
+        L.rt_last_error.argtypes = [C.c_void_p]
+        L.rt_buffer_bytes.restype = C.c_size_t
+        L.rt_buffer_bytes.argtypes = [C.c_void_p, C.c_int]
+        L.rt_abi_version.restype = C.c_uint32
+        L.rt_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+        for n in ["rt_destroy", "rt_build_accel", "rt_sync"]:
+            getattr(L, n).argtypes = [C.c_void_p]
+        L.rt_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.rt_upload_scene.argtypes = [C.c_void_p, C.c_void_p]
+        L.rt_resize.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.rt_set_camera.argtypes = [C.c_void_p, C.c_void_p]
+        L.rt_render_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.rt_run_stage.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 5
+        L.rt_readback.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        L.rt_upload_history.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        L.rt_device_ptr.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        L.rt_set_counting.argtypes = [C.c_void_p, C.c_int]
+        L.rt_get_counters.argtypes = [C.c_void_p, C.c_void_p]
+        L.rt_accel_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+        _lib = L
+    return _lib
+
+
+class RtError(RuntimeError):
+    pass
+
+
+class _DevArray:
+    """Zero-copy view of a ctx-owned HBM buffer for torch.as_tensor / RCCL (via __cuda_array_interface__)."""
+    def __init__(self, ptr, nbytes, owner):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3}
+        self._owner = owner
+
+
+class Renderer:
+    def __init__(self):
+        self._h = None
+        self.size = (0, 0)
+
+    # Renderer::setup (renderer.cpp:62-73)
+    def setup(self, device=0):
+        h = C.c_void_p()
+        rc = hip_lib().rt_create(C.byref(h), device)
+        if rc != 0:
+            raise RtError(f"rt_create failed ({rc}): {hip_lib().rt_last_error(None).decode()}")
+        self._h = h
+        return self
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RtError(f"{what} failed ({rc}): {hip_lib().rt_last_error(self._h).decode()}")
+
+    # Renderer::destroy (renderer.cpp:75-91)
+    def destroy(self):
+        if self._h:
+            hip_lib().rt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    # AccelStructure::create + the upload half of Scene::load / HdrSampling::loadEnvironment
+    def load_scene(self, desc):
+        self._chk(hip_lib().rt_upload_scene(self._h, C.byref(desc)), "rt_upload_scene")
+        self._chk(hip_lib().rt_build_accel(self._h), "rt_build_accel")
+
+    # Renderer::create (renderer.cpp:97-148) / Renderer::update (renderer.cpp:209-225)
+    def create(self, width, height, scene=None, env=None):
+        if scene is not None:
+            self.load_scene(scene.desc(env))
+        self.update(width, height)
+        return self
+
+    def update(self, width, height):
+        self._chk(hip_lib().rt_resize(self._h, width, height), "rt_resize")
+        self.size = (width, height)
+
+    def set_camera(self, cam):
+        self._chk(hip_lib().rt_set_camera(self._h, C.byref(cam)), "rt_set_camera")
+
+    def set_stream(self, stream_ptr):
+        self._chk(hip_lib().rt_set_stream(self._h, stream_ptr), "rt_set_stream")
+
+    # Renderer::run (renderer.cpp:154-206)
+    def run(self, state, frames):
+        self._chk(hip_lib().rt_render_frame(self._h, C.byref(state), frames), "rt_render_frame")
+
+    def run_stage(self, state, frames, stage, level=0, row_begin=0, row_end=0):
+        self._chk(hip_lib().rt_run_stage(self._h, C.byref(state), frames, stage, level, row_begin, row_end), "rt_run_stage")
+
+    def sync(self):
+        self._chk(hip_lib().rt_sync(self._h), "rt_sync")
+
+    def buffer_bytes(self, buf):
+        return hip_lib().rt_buffer_bytes(self._h, buf)
+
+    def readback(self, buf):
+        out = np.empty(self.buffer_bytes(buf), dtype=np.uint8)
+        self._chk(hip_lib().rt_readback(self._h, buf, out.ctypes.data, out.nbytes), "rt_readback")
+        return out
+
+    def upload_history(self, buf, data):
+        a = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+        self._chk(hip_lib().rt_upload_history(self._h, buf, a.ctypes.data, a.nbytes), "rt_upload_history")
+
+    def device_array(self, buf):
+        p, n, pitch = C.c_void_p(), C.c_size_t(), C.c_size_t()
+        self._chk(hip_lib().rt_device_ptr(self._h, buf, C.byref(p), C.byref(n), C.byref(pitch)), "rt_device_ptr")
+        return _DevArray(p.value, n.value, self), pitch.value
+
+    def set_counting(self, enable):
+        self._chk(hip_lib().rt_set_counting(self._h, 1 if enable else 0), "rt_set_counting")
+
+    def counters(self):
+        c = abi.Counters()
+        self._chk(hip_lib().rt_get_counters(self._h, C.byref(c)), "rt_get_counters")
+        return c
+
+    def accel_stats(self):
+        n, t, d = C.c_uint64(), C.c_uint64(), C.c_int()
+        self._chk(hip_lib().rt_accel_stats(self._h, C.byref(n), C.byref(t), C.byref(d)), "rt_accel_stats")
+        return {"nodes": n.value, "triangles": t.value, "max_depth": d.value}
