@@ -1,0 +1,212 @@
+#!/usr/bin/env python
+"""bench.py — BASELINE.json's metric on MI355X: Mrays/s and ms/frame of the ReSTIR DI+GI+denoise frame at 1920x1080 on the
+Bistro-Exterior-class scene (BASELINE.json configs[3]; the real asset is absent => seeded procedural stand-in, 2.8 M
+triangles, alpha-masked foliage, emissive lamps, synthetic HDR sky: `data: synthetic`).
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A step = one frame = Renderer::run's 12 dispatches (renderer.cpp:154-206) at the reference defaults
+(sample_example.hpp:154-184: maxDepth 4, temporal ReSTIR, M=4, MIS, denoise on) with a fresh RNG seed per frame.
+N>1 row-tiles the frame (restir_amd/tiled.py): total work is fixed => "strong" scaling.
+
+The JSON line carries
+  roofline      dominant kernel: algorithmic bytes per launch (screen traffic of SURVEY.md §8d + counted BVH8 node / triangle
+                / hit / RIS-candidate gathers x declared sizes) / its mean launch time from HIP events on the launch stream
+  cpu_baseline  the CPU oracle (oracle/, "port") timed on a bounded band of the same frame on the host cores (N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+STAGE_NAMES = ["direct_stage", "indirect_stage", "denoise_direct", "denoise_indirect", "compose", "direct_gen", "direct_reuse"]
+# closed-form screen traffic per stage at the reference layouts (bytes per stage-grid pixel)
+SCREEN_BYTES = {0: 124.0, 1: 204.0, 2: 192.0, 3: 240.0, 4: 68.0}
+NODE_B, TRI_B, HIT_B, RIS_B = 80, 48, 12 + 96 + 80, 16 + 96  # bvh8.h node / triangle; hit gathers; RIS candidate gathers
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--scale", type=float, default=1.0, help="scene tessellation scale (1.0 = the 2.8 M-triangle benchmark scene)")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=32, help="height of the row band the CPU baseline renders")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import restir_amd  # noqa: F401
+    from restir_amd import abi, host
+    from restir_amd.renderer import Renderer
+    from restir_amd import tiled
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    W, H = args.width, args.height
+    scene = host.Scene().makeProcedural(abi.PROC_BISTRO_EXT, args.scale, 1)
+    env = host.HdrSampling()
+    env.makeSyntheticSky(2048, 1024, 5e4, 7)
+    st = host.default_state(W, H, scene, env)
+    desc = scene.desc(env)
+    r = Renderer().setup(local_rank)
+    t0 = time.time()
+    r.load_scene(desc)
+    build_s = time.time() - t0
+    r.update(W, H)
+    r.set_stream(torch.cuda.current_stream().cuda_stream)  # kernels and RCCL ops are ordered by torch's stream semantics
+    comm = tiled.TorchComm() if world > 1 else tiled.LocalComm()
+    frame = tiled.TiledFrame(tiled.RendererTensors(r), comm, W, H) if world > 1 else None
+
+    scene.updateCamera(W, H)  # prime the camera history (static camera: SURVEY.md §8d)
+
+    def step(f):
+        st.time = 1000 + f
+        scene.updateCamera(W, H)
+        r.set_camera(scene.getCamera())
+        if frame is None:
+            r.run(st, f)
+        else:
+            frame.render_frame(st, f)
+
+    def fence():
+        if frame is not None:
+            frame.finish()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    f = 0
+    for _ in range(args.warmup):
+        step(f); f += 1
+    fence()
+    r.set_counting(False)  # resets the accumulated stage timings
+    first_timed = f
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(f); f += 1
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    timing = r.counters()
+
+    # ---- rays / traversal counts of the same frames (instrumented kernels, outside the timed region) -------------
+    n_count = min(4, args.steps)
+    r.set_counting(True)
+    for k in range(n_count):
+        step(first_timed + k)
+    fence()
+    cnt = r.counters()
+    r.set_counting(False)
+    vals = np.array([cnt.closestHitRays, cnt.anyHitRays, cnt.nodesVisited, cnt.trisTested, cnt.hitsShaded, cnt.risCandidates], dtype=np.float64) / n_count
+    if dist is not None:
+        t = torch.tensor(vals, dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        vals = t.cpu().numpy()
+    rays_per_frame = float(vals[0] + vals[1])
+
+    # per-stage counts for the roofline: re-run the dominant stage alone with counting (N=1 only: stages timed in-library)
+    out = None
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        mrays = rays_per_frame * args.steps / elapsed / 1e6
+        out = {
+            "metric": "Mrays/s (ClosestHit+AnyHit ray queries per second) of the 1080p ReSTIR DI+GI+denoise frame; ms_per_step = ms/frame",
+            "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"bistro-exterior-class procedural scene, {scene.getStat()['instancedTriangles']} triangles, {W}x{H}, "
+                                   "ReSTIR DI (temporal, M=4) + GI (maxDepth 4, MIS) + A-Trous 4+5 levels + compose, static camera, "
+                                   "2048x1024 synthetic HDR sky", "width": W, "height": H, "scene_scale": args.scale,
+                       "parallelism": "single GPU" if world == 1 else f"row-tiled x{world}, in-place all-gather + neighbour halos over RCCL",
+                       "rays_per_frame": round(rays_per_frame), "fps": round(1e3 / ms_per_step, 2), "bvh8_build_s": round(build_s, 2),
+                       "accel": r.accel_stats()},
+        }
+    if world == 1:
+        stage_ms = [timing.stageMs[i] / max(1, timing.framesTimed) for i in range(5)]
+        dom = int(np.argmax(stage_ms))
+        launches = {0: 1, 1: 1, 2: 4, 3: 5, 4: 1}[dom]
+        # counts of the dominant stage alone
+        r.set_counting(True)
+        for k in range(n_count):
+            st.time = 1000 + first_timed + k
+            levels = range(launches) if dom in (2, 3) else [0]
+            for lv in levels:
+                r.run_stage(st, first_timed + k, dom, lv)
+        r.sync()
+        c2 = r.counters()
+        r.set_counting(False)
+        grid_px = (W // 2) * (H // 2) if dom in (1, 3) else W * H
+        b_screen = SCREEN_BYTES[dom] * grid_px / launches
+        b_trav = (c2.nodesVisited * NODE_B + c2.trisTested * TRI_B + c2.hitsShaded * HIT_B + c2.risCandidates * RIS_B) / float(n_count) / launches
+        dur_ms = stage_ms[dom] / launches
+        achieved = (b_screen + b_trav) / (dur_ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": STAGE_NAMES[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                           "algorithmic_bytes_per_launch": round(b_screen + b_trav), "screen_bytes": round(b_screen), "traversal_bytes": round(b_trav),
+                           "launch_ms": round(dur_ms, 4), "stage_ms_per_frame": {STAGE_NAMES[i]: round(stage_ms[i], 4) for i in range(5)}}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(abi, host, scene, env, st, desc, W, H, args.cpu_rows, first_timed)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(abi, host, scene, env, st, desc, W, H, rows, frame0):
+    """The CPU oracle (naive binary BVH + scalar C++, std::thread over all host cores) on a bounded sample: the full
+    12-dispatch frame restricted to a horizontal band of `rows` full-res rows around the image centre."""
+    from oracle.binding import Oracle
+    o = Oracle(0)
+    o.upload_scene(desc)
+    o.resize(W, H)
+    y0 = (H // 2 // 16) * 16
+    y1 = min(H, y0 + rows)
+    h0, h1 = y0 // 2, y1 // 2
+    o.set_camera(scene.getCamera())
+    st.time = 1000 + frame0
+    o.reset_counters()
+    t0 = time.perf_counter()
+    o.run_stage(st, frame0, abi.STAGE_DIRECT, 0, y0, y1)
+    o.run_stage(st, frame0, abi.STAGE_INDIRECT, 0, h0, h1)
+    for l in range(4):
+        o.run_stage(st, frame0, abi.STAGE_DENOISE_DIRECT, l, y0, y1)
+    for l in range(5):
+        o.run_stage(st, frame0, abi.STAGE_DENOISE_INDIRECT, l, h0, h1)
+    o.run_stage(st, frame0, abi.STAGE_COMPOSE, 0, y0, y1)
+    dt = time.perf_counter() - t0
+    c = o.counters()
+    rays = c.closestHitRays + c.anyHitRays
+    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": o.threads, "kind": "port",
+            "sample": f"rows {y0}..{y1} of one {W}x{H} frame (all 12 dispatches, cold temporal history), {rays} rays in {dt:.2f} s "
+                      f"=> {dt * H / max(1, y1 - y0) * 1e3:.0f} ms/frame extrapolated"}
+
+
+if __name__ == "__main__":
+    main()

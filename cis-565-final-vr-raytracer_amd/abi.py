@@ -35,7 +35,7 @@ class SceneDesc(C.Structure):  # rt_scene_desc
 RT_STAGE_COUNT = 7
 class Counters(C.Structure):  # rt_counters
     _fields_ = [("closestHitRays", C.c_uint64), ("anyHitRays", C.c_uint64), ("nodesVisited", C.c_uint64), ("trisTested", C.c_uint64),
-                ("hitsShaded", C.c_uint64), ("risCandidates", C.c_uint64), ("stageMs", C.c_float * RT_STAGE_COUNT), ("frameMs", C.c_float)]
+                ("hitsShaded", C.c_uint64), ("risCandidates", C.c_uint64), ("stageMs", C.c_float * RT_STAGE_COUNT), ("frameMs", C.c_float), ("framesTimed", C.c_uint32)]
 
 assert C.sizeof(SceneCamera) == 336 and C.sizeof(RtxState) == 100
 

@@ -27,17 +27,32 @@ struct rt_ctx {
   // screen-space buffers
   int W = 0, H = 0;
   void* bufs[RT_BUF_COUNT] = {};
-  size_t bufBytes[RT_BUF_COUNT] = {};
+  size_t bufBytes[RT_BUF_COUNT] = {};   // logical bytes (W x H elements): readback / upload size
+  size_t bufAlloc[RT_BUF_COUNT] = {};   // allocated bytes: + RT_PAD_ROWS rows so equal-height row bands can be all-gathered in place
   rt_scene_camera cam{};
   bool counting = false;
   unsigned long long* dCounters = nullptr;
-  // timing: event 0 = frame start, event k = end of launch k
-  static constexpr int MAX_EV = 16;
-  hipEvent_t ev[MAX_EV] = {};
-  int evStage[MAX_EV] = {};
-  int evCount = 0;
-  bool timingValid = false;
+  // timing: per frame one event set; event 0 = frame start, event k = end of launch k.  Sets are harvested lazily.
+  static constexpr int MAX_EV = 16, MAX_SETS = 1024;
+  struct EvSet { hipEvent_t ev[MAX_EV]; int stage[MAX_EV]; int count; };
+  std::vector<EvSet> evSets;
+  size_t evUsed = 0;
+  double accStage[RT_STAGE_COUNT] = {}; double accFrame = 0; uint32_t accFrames = 0;
 };
+
+static void harvestTimings(rt_ctx* c)
+{
+  for(size_t s = 0; s < c->evUsed; s++) {
+    rt_ctx::EvSet& E = c->evSets[s];
+    for(int k = 1; k < E.count; k++) {
+      float ms = 0.f;
+      if(hipEventElapsedTime(&ms, E.ev[k - 1], E.ev[k]) == hipSuccess && E.stage[k] >= 0) c->accStage[E.stage[k]] += ms;
+    }
+    float ms = 0.f;
+    if(E.count > 1 && hipEventElapsedTime(&ms, E.ev[0], E.ev[E.count - 1]) == hipSuccess) { c->accFrame += ms; c->accFrames++; }
+  }
+  c->evUsed = 0;
+}
 
 static thread_local std::string g_createErr;
 
@@ -76,6 +91,7 @@ static size_t elemBytes(int id)
     default: return 16;
   }
 }
+static constexpr int RT_PAD_ROWS = 128;  // full-res rows of slack behind every buffer (64 for half-res buffers)
 static bool halfRes(int id) { return id == RT_BUF_INDIRECT_RESV0 || id == RT_BUF_INDIRECT_RESV1 || id == RT_BUF_INDIRECT_RESV_TEMP; }
 
 extern "C" {
@@ -97,7 +113,6 @@ int rt_create(rt_ctx** out, int device)
   c->device = device;
   if(hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) != hipSuccess) { g_createErr = "rt_create: hipStreamCreate failed"; delete c; return RT_ERR_HIP; }
   c->stream = c->ownStream;
-  for(int i = 0; i < rt_ctx::MAX_EV; i++) (void)hipEventCreate(&c->ev[i]);
   if(hipMalloc(reinterpret_cast<void**>(&c->dCounters), 8 * sizeof(unsigned long long)) != hipSuccess) { g_createErr = "rt_create: hipMalloc failed"; delete c; return RT_ERR_OOM; }
   (void)hipMemset(c->dCounters, 0, 8 * sizeof(unsigned long long));
   *out = c;
@@ -112,7 +127,7 @@ int rt_destroy(rt_ctx* c)
   freePool(c->sceneAllocs); freePool(c->accelAllocs);
   for(int i = 0; i < RT_BUF_COUNT; i++) if(c->bufs[i]) (void)hipFree(c->bufs[i]);
   if(c->dCounters) (void)hipFree(c->dCounters);
-  for(int i = 0; i < rt_ctx::MAX_EV; i++) if(c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  for(auto& E : c->evSets) for(int i = 0; i < rt_ctx::MAX_EV; i++) (void)hipEventDestroy(E.ev[i]);
   if(c->ownStream) (void)hipStreamDestroy(c->ownStream);
   delete c;
   return RT_OK;
@@ -237,9 +252,10 @@ int rt_resize(rt_ctx* c, int w, int h)
   const size_t n = size_t(w) * h, nh = size_t(w / 2) * (h / 2);
   for(int i = 0; i < RT_BUF_COUNT; i++) {
     const size_t bytes = (halfRes(i) ? nh : n) * elemBytes(i);
-    RT_HIP(c, hipMalloc(&c->bufs[i], std::max<size_t>(bytes, 16)));
-    RT_HIP(c, hipMemset(c->bufs[i], (i == RT_BUF_LIGHT_ID0 || i == RT_BUF_LIGHT_ID1) ? 0xff : 0, std::max<size_t>(bytes, 16)));
-    c->bufBytes[i] = bytes;
+    const size_t alloc = bytes + (halfRes(i) ? size_t(w / 2) * (RT_PAD_ROWS / 2) : size_t(w) * RT_PAD_ROWS) * elemBytes(i) + 16;
+    RT_HIP(c, hipMalloc(&c->bufs[i], alloc));
+    RT_HIP(c, hipMemset(c->bufs[i], (i == RT_BUF_LIGHT_ID0 || i == RT_BUF_LIGHT_ID1) ? 0xff : 0, alloc));
+    c->bufBytes[i] = bytes; c->bufAlloc[i] = alloc;
   }
   c->W = w; c->H = h;
   return RT_OK;
@@ -290,7 +306,6 @@ int rt_run_stage(rt_ctx* c, const rt_state* st, int frames, int stage, int level
   RT_HIP(c, hipSetDevice(c->device));
   const DevFrame F = makeFrame(c, frames);
   RT_HIP(c, launchStage(c->stream, c->ds, F, *st, c->cam, stage, level, rowBegin, rowEnd));
-  c->timingValid = false;
   return RT_OK;
 }
 
@@ -300,15 +315,22 @@ int rt_render_frame(rt_ctx* c, const rt_state* st, int frames)
   if(rc) return rc;
   RT_HIP(c, hipSetDevice(c->device));
   const DevFrame F = makeFrame(c, frames);
+  if(c->evUsed == rt_ctx::MAX_SETS) { RT_HIP(c, hipStreamSynchronize(c->stream)); harvestTimings(c); }
+  if(c->evUsed == c->evSets.size()) {
+    rt_ctx::EvSet E{};
+    for(int i = 0; i < rt_ctx::MAX_EV; i++) RT_HIP(c, hipEventCreate(&E.ev[i]));
+    c->evSets.push_back(E);
+  }
+  rt_ctx::EvSet& E = c->evSets[c->evUsed];
   int k = 0;
-  RT_HIP(c, hipEventRecord(c->ev[k], c->stream));
-  c->evStage[k++] = -1;
+  RT_HIP(c, hipEventRecord(E.ev[k], c->stream));
+  E.stage[k++] = -1;
   auto run = [&](int stage, int level) -> int {
     hipError_t e = launchStage(c->stream, c->ds, F, *st, c->cam, stage, level, 0, 0);
     if(e != hipSuccess) { c->err = std::string("launchStage: ") + hipGetErrorString(e); return RT_ERR_HIP; }
-    e = hipEventRecord(c->ev[k], c->stream);
+    e = hipEventRecord(E.ev[k], c->stream);
     if(e != hipSuccess) { c->err = std::string("hipEventRecord: ") + hipGetErrorString(e); return RT_ERR_HIP; }
-    c->evStage[k++] = stage;
+    E.stage[k++] = stage;
     return RT_OK;
   };
   // Renderer::run, renderer.cpp:163-205
@@ -319,8 +341,8 @@ int rt_render_frame(rt_ctx* c, const rt_state* st, int frames)
     for(int i = 0; i < 5; i++) if((rc = run(RT_STAGE_DENOISE_INDIRECT, i))) return rc;
   }
   if((rc = run(RT_STAGE_COMPOSE, 0))) return rc;
-  c->evCount = k;
-  c->timingValid = true;
+  E.count = k;
+  c->evUsed++;
   return RT_OK;
 }
 
@@ -353,7 +375,7 @@ int rt_device_ptr(rt_ctx* c, int buffer, void** ptr, size_t* bytes, size_t* rowP
   if(!c || buffer < 0 || buffer >= RT_BUF_COUNT || !ptr) return RT_ERR_INVALID_ARG;
   if(c->W == 0) return fail(c, RT_ERR_NO_TARGET, "rt_device_ptr: rt_resize has not been called");
   *ptr = c->bufs[buffer];
-  if(bytes) *bytes = c->bufBytes[buffer];
+  if(bytes) *bytes = c->bufAlloc[buffer];
   if(rowPitch) *rowPitch = size_t(halfRes(buffer) ? c->W / 2 : c->W) * elemBytes(buffer);
   return RT_OK;
 }
@@ -364,6 +386,9 @@ int rt_set_counting(rt_ctx* c, int enable)
   RT_HIP(c, hipSetDevice(c->device));
   RT_HIP(c, hipStreamSynchronize(c->stream));
   RT_HIP(c, hipMemset(c->dCounters, 0, 8 * sizeof(unsigned long long)));
+  harvestTimings(c);
+  for(double& v : c->accStage) v = 0;
+  c->accFrame = 0; c->accFrames = 0;
   c->counting = enable != 0;
   return RT_OK;
 }
@@ -377,14 +402,10 @@ int rt_get_counters(rt_ctx* c, rt_counters* out)
   unsigned long long h[8];
   RT_HIP(c, hipMemcpy(h, c->dCounters, sizeof(h), hipMemcpyDeviceToHost));
   out->closestHitRays = h[0]; out->anyHitRays = h[1]; out->nodesVisited = h[2]; out->trisTested = h[3]; out->hitsShaded = h[4]; out->risCandidates = h[5];
-  if(c->timingValid) {
-    for(int k = 1; k < c->evCount; k++) {
-      float ms = 0.f;
-      if(hipEventElapsedTime(&ms, c->ev[k - 1], c->ev[k]) == hipSuccess && c->evStage[k] >= 0) out->stageMs[c->evStage[k]] += ms;
-    }
-    float ms = 0.f;
-    if(c->evCount > 1 && hipEventElapsedTime(&ms, c->ev[0], c->ev[c->evCount - 1]) == hipSuccess) out->frameMs = ms;
-  }
+  harvestTimings(c);
+  for(int i = 0; i < RT_STAGE_COUNT; i++) out->stageMs[i] = float(c->accStage[i]);
+  out->frameMs = float(c->accFrame);
+  out->framesTimed = c->accFrames;
   return RT_OK;
 }
 

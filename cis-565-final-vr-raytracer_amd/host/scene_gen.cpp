@@ -379,7 +379,7 @@ GltfScene makeBistro(bool interior, float scale, uint32_t seed)
   }
   // props (chairs / bikes / crockery stand-ins): high-resolution blobs, the bulk of the triangle count
   {
-    int np = std::max(2, int((interior ? 200 : 300) * s)), nu = std::max(6, int(50 * s)), nv = std::max(4, int(40 * s));
+    int np = std::max(2, int((interior ? 220 : 415) * s)), nu = std::max(6, int(50 * s)), nv = std::max(4, int(40 * s));
     int meshes[8];
     for(int k = 0; k < 8; k++) { B.beginMesh(k == 7 ? P.metal : mat(11 + k)); B.sphere({0, 0, 0}, {1.f, 0.7f + 0.1f * k, 1.f}, nu, nv, 0.35f, seed + 31u * k); meshes[k] = B.endMesh(); }
     for(int p = 0; p < np; p++) {

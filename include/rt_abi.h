@@ -266,8 +266,11 @@ typedef struct {
   uint64_t trisTested;       /* triangle records fetched (48 B + 8 B each)       */
   uint64_t hitsShaded;       /* GetState() invocations (108 B gather + 80 B material) */
   uint64_t risCandidates;    /* SampleDirectLightNoVisibility() invocations      */
-  float stageMs[RT_STAGE_COUNT]; /* last frame, HIP events on the ctx stream (denoise = sum of levels) */
+  /* HIP-event timings on the ctx stream, ACCUMULATED over the rt_render_frame calls since the last rt_set_counting()
+   * (which resets them); denoise entries sum their 4 / 5 levels. Divide by framesTimed for per-frame averages. */
+  float stageMs[RT_STAGE_COUNT];
   float frameMs;
+  uint32_t framesTimed;
 } rt_counters;
 
 typedef enum {
@@ -310,10 +313,13 @@ int rt_readback(rt_ctx* ctx, int buffer, void* dst, size_t bytes);
 int rt_upload_history(rt_ctx* ctx, int buffer, const void* src, size_t bytes);
 /* Size in bytes of a buffer's boundary layout at the current resolution. */
 size_t rt_buffer_bytes(rt_ctx* ctx, int buffer);
-/* Raw device pointer of a buffer's device-side storage (+ its byte size and bytes per row of the stage grid),
- * for RCCL halo exchange by the caller.  Device-side layout == boundary layout. */
+/* Raw device pointer of a buffer's device-side storage, its ALLOCATED byte size and the bytes per row of the stage
+ * grid, for RCCL exchanges by the caller.  Device-side layout == boundary layout; every allocation carries 128 rows
+ * (64 for the half-resolution reservoirs) of slack behind the image so equal-height row bands of up to 8 ranks can be
+ * all-gathered in place. */
 int rt_device_ptr(rt_ctx* ctx, int buffer, void** ptr, size_t* bytes, size_t* rowPitch);
-/* Enable (1) / disable (0) traversal + gather counting for subsequent frames (slower, instrumented kernels). */
+/* Enable (1) / disable (0) traversal + gather counting for subsequent frames (adds atomics to the kernels), and reset
+ * every counter and accumulated timing. */
 int rt_set_counting(rt_ctx* ctx, int enable);
 int rt_get_counters(rt_ctx* ctx, rt_counters* out);
 /* Wait for all work on the ctx stream. */

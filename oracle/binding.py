@@ -45,6 +45,7 @@ def lib():
         L.orc_readback.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         L.orc_upload_history.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         L.orc_get_counters.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_buffer_ptr.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         for n in ["orc_trace_closest", "orc_trace_any", "orc_trace_closest_brute"]:
             getattr(L, n).argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_offset_ray.argtypes = [C.c_void_p] * 3
@@ -81,6 +82,12 @@ class Oracle:
     def upload_history(self, buf, data):
         a = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
         self._chk(lib().orc_upload_history(self._h, buf, a.ctypes.data, a.nbytes), "upload_history")
+    def buffer_array(self, buf):
+        """(flat uint8 numpy view of the whole allocation incl. slack rows, row pitch in bytes) — zero copy"""
+        p, n, pitch = C.c_void_p(), C.c_size_t(), C.c_size_t()
+        self._chk(lib().orc_buffer_ptr(self._h, buf, C.byref(p), C.byref(n), C.byref(pitch)), "buffer_ptr")
+        arr = np.ctypeslib.as_array((C.c_uint8 * n.value).from_address(p.value))
+        return arr, pitch.value
     def counters(self):
         from importlib import import_module
         import sys

@@ -13,6 +13,16 @@ struct Ctx {
   bool haveScene = false;
 };
 template <class T> size_t vbytes(const std::vector<T>& v) { return v.size() * sizeof(T); }
+bool isHalfRes(int id) { return id == RT_BUF_INDIRECT_RESV0 || id == RT_BUF_INDIRECT_RESV1 || id == RT_BUF_INDIRECT_RESV_TEMP; }
+size_t elemSize(int id)
+{
+  switch(id) {
+    case RT_BUF_MOTION: case RT_BUF_LIGHT_ID0: case RT_BUF_LIGHT_ID1: return 4;
+    case RT_BUF_DIRECT_RESV0: case RT_BUF_DIRECT_RESV1: case RT_BUF_DIRECT_RESV_TEMP: return sizeof(rt_direct_reservoir);
+    case RT_BUF_INDIRECT_RESV0: case RT_BUF_INDIRECT_RESV1: case RT_BUF_INDIRECT_RESV_TEMP: return sizeof(rt_indirect_reservoir);
+    default: return 16;
+  }
+}
 
 void* bufPtr(Ctx* c, int id, size_t& bytes)
 {
@@ -87,10 +97,25 @@ int orc_run_stage(void* p, const rt_state* st, int frames, int stage, int level,
   c->frame.runStage(*st, frames, stage, level, rowBegin, rowEnd);
   return RT_OK;
 }
-size_t orc_buffer_bytes(void* p, int id) { size_t b; bufPtr(static_cast<Ctx*>(p), id, b); return b; }
+// logical size (W x H elements); the vectors carry slack rows behind it
+size_t orc_buffer_bytes(void* p, int id)
+{
+  Ctx* c = static_cast<Ctx*>(p);
+  if(id < 0 || id >= RT_BUF_COUNT) return 0;
+  return (isHalfRes(id) ? size_t(c->frame.W / 2) * (c->frame.H / 2) : size_t(c->frame.W) * c->frame.H) * elemSize(id);
+}
+int orc_buffer_ptr(void* p, int id, void** ptr, size_t* allocBytes, size_t* rowPitch)
+{
+  Ctx* c = static_cast<Ctx*>(p);
+  size_t b; void* q = bufPtr(c, id, b);
+  if(!q) return RT_ERR_INVALID_ARG;
+  *ptr = q; *allocBytes = b; *rowPitch = size_t(isHalfRes(id) ? c->frame.W / 2 : c->frame.W) * elemSize(id);
+  return RT_OK;
+}
 int orc_readback(void* p, int id, void* dst, size_t bytes)
 {
   size_t b; void* src = bufPtr(static_cast<Ctx*>(p), id, b);
+  b = orc_buffer_bytes(p, id);
   if(!src || bytes != b) return RT_ERR_INVALID_ARG;
   memcpy(dst, src, b);
   return RT_OK;
@@ -98,6 +123,7 @@ int orc_readback(void* p, int id, void* dst, size_t bytes)
 int orc_upload_history(void* p, int id, const void* src, size_t bytes)
 {
   size_t b; void* dst = bufPtr(static_cast<Ctx*>(p), id, b);
+  b = orc_buffer_bytes(p, id);
   if(!dst || bytes != b) return RT_ERR_INVALID_ARG;
   memcpy(dst, src, b);
   return RT_OK;

@@ -63,7 +63,8 @@ ivec2 Frame::loadMotion(ivec2 c) const
 void Frame::resize(int w, int h)
 {
   W = w; H = h;
-  const size_t n = size_t(w) * h, nh = size_t(w / 2) * (h / 2);
+  // + 128 rows (64 half-res) of slack like the product's allocations, so the row-tiled multi-rank tests can all-gather in place
+  const size_t n = size_t(w) * (h + 128), nh = size_t(w / 2) * (h / 2 + 64);
   for(int i = 0; i < 2; i++) {
     gbuffer[i].assign(n * 4, 0u);
     directResv[i].assign(n, rt_direct_reservoir{});

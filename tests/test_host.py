@@ -1,0 +1,78 @@
+"""Host side: Scene / HdrSampling data products (scene.cpp:179-448, 700-826; hdr_sampling.cpp:107-242)."""
+import os
+import struct
+import numpy as np
+from helpers import abi, host, make_scene
+
+
+def test_procedural_scene_sizes_match_baseline_configs():
+    want = {abi.PROC_CORNELL: (30, 40), abi.PROC_HELMET: (6.5e4, 7.5e4), abi.PROC_SPONZA: (2.4e5, 2.9e5),
+            abi.PROC_BISTRO_EXT: (2.6e6, 3.0e6), abi.PROC_BISTRO_INT: (0.9e6, 1.15e6)}
+    for kind, (lo, hi) in want.items():
+        st = host.Scene().makeProcedural(kind, 1.0, 1).getStat()
+        assert lo <= st["instancedTriangles"] <= hi, (kind, st)
+    st = host.Scene().makeProcedural(abi.PROC_BISTRO_INT, 1.0, 1).getStat()
+    assert 1500 <= st["trigLights"] <= 2500          # "~30 emissive meshes (~2 k emissive tris)", SURVEY §8d config 5
+
+
+def test_cornell_light_table():
+    sc = host.Scene().makeProcedural(abi.PROC_CORNELL)
+    p, t = sc.lightWeights
+    # luminance(17,12,4) per emissive triangle, 2 triangles, not area weighted (scene.cpp:750-756)
+    assert p == 0.0 and abs(t - 2 * (17 * 0.2126 + 12 * 0.7152 + 4 * 0.0722)) < 1e-3
+    d = sc.desc()
+    assert d.lightInfo.trigLightSize == 2 and d.lightInfo.puncLightSize == 0 and d.lightInfo.trigSampProb == 1.0
+
+
+def test_camera_history_shift():
+    sc = host.Scene().makeProcedural(abi.PROC_CORNELL)
+    sc.updateCamera(64, 64)
+    c0 = sc.getCamera()
+    assert np.allclose(np.array(c0.lastProjView.m), 0)                      # first frame has no history
+    assert tuple(np.array([c0.lastPosition.x, c0.lastPosition.y, c0.lastPosition.z])) == (0, 0, 0)  # `static eye{0,0,0}` (scene.cpp:780)
+    sc.setCamera((0.1, 1, 3.4), (0, 1, 0))
+    sc.updateCamera(64, 64)
+    c1 = sc.getCamera()
+    assert np.array_equal(np.array(c1.lastProjView.m), np.array(c0.projView.m))
+    assert np.allclose([c1.lastPosition.x, c1.lastPosition.y, c1.lastPosition.z], [0, 1, 3.4])
+    vi = np.array(c1.viewInverse.m).reshape(4, 4).T
+    assert np.allclose(vi[:3, 3], [0.1, 1, 3.4], atol=1e-6)                 # camera origin = eye
+    lv = np.array(c1.lastView.m).reshape(4, 4).T @ np.array(c0.viewInverse.m).reshape(4, 4).T
+    assert np.allclose(lv, np.eye(4), atol=1e-5)                            # lastView = inverse(previous viewInverse)
+    pj = np.array(c1.projInverse.m).reshape(4, 4).T
+    p = np.linalg.inv(pj)
+    assert abs(p[0, 2] - 0.5 / 64) < 1e-6 and abs(p[1, 2] - 0.5 / 64) < 1e-6   # half-pixel jitter (scene.cpp:783-787)
+
+
+def test_env_accel_is_a_distribution():
+    env = host.HdrSampling(); env.makeSyntheticSky(128, 64, 5e4, 7)
+    a = env.accel()
+    w, h = env.size
+    theta = (np.arange(h + 1) * np.pi / h)
+    sa = (np.cos(theta[:-1]) - np.cos(theta[1:])) * (2 * np.pi / w)          # solid angle per texel row
+    pdf = a["pdf"].reshape(h, w).astype(np.float64)
+    assert abs((pdf * sa[:, None]).sum() - 1.0) < 1e-3                       # pdf integrates to 1 over the sphere
+    # alias-table marginals reproduce importance = solid angle * max(rgb)
+    q = a["q"].astype(np.float64); al = a["alias"]
+    marg = np.minimum(q, 1.0).copy()
+    np.add.at(marg, al, 1.0 - np.minimum(q, 1.0))
+    imp = (pdf * sa[:, None]).reshape(-1)
+    assert np.allclose(marg / marg.size, imp / imp.sum(), atol=5e-5)
+    assert np.array_equal(a["aliasPdf"], a["pdf"][al])
+
+
+def test_radiance_hdr_reader(tmp_path):
+    w, h = 16, 8
+    rng = np.random.default_rng(3)
+    rgbe = rng.integers(1, 255, (h, w, 4), dtype=np.uint8); rgbe[..., 3] = rng.integers(120, 136, (h, w))
+    path = os.path.join(tmp_path, "t.hdr")
+    with open(path, "wb") as f:
+        f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w))
+        for y in range(h):                                                   # new-style RLE scanlines, literal runs only
+            f.write(bytes([2, 2, w >> 8, w & 255]))
+            for ch in range(4):
+                f.write(bytes([w])); f.write(rgbe[y, :, ch].tobytes())
+    env = host.HdrSampling()
+    assert env.loadEnvironment(path) and env.size == (w, h)
+    assert env.getIntegral() > 0
+    assert not host.HdrSampling().loadEnvironment(os.path.join(tmp_path, "missing.hdr"))

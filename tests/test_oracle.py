@@ -1,0 +1,124 @@
+"""The CPU oracle against analytic answers, its own brute force, and the invariants of the algorithm."""
+import ctypes as C
+import numpy as np
+import pytest
+from helpers import abi, host, make_scene, frame_buffers
+from oracle.binding import Oracle, lib
+
+
+def _rays(n, bbox_lo, bbox_hi, seed):
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(bbox_lo, bbox_hi, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    r = np.zeros((n, 8), dtype=np.float32)
+    r[:, 0:3], r[:, 3:6], r[:, 6] = o, d, 1e28
+    r[:, 7] = rng.integers(0, 2**31, n).astype(np.uint32).view(np.float32)
+    return r
+
+
+@pytest.mark.parametrize("kind,scale", [(abi.PROC_SPONZA, 0.02), (abi.PROC_BISTRO_EXT, 0.004)])
+def test_bvh_equals_brute_force(kind, scale):
+    sc, _ = make_scene(kind, scale)
+    o = Oracle(1)
+    o.upload_scene(sc.desc())
+    rays = _rays(3000, [-12, 0.2, -5], [12, 8, 5], 3)
+    a, b = o.trace_closest(rays), o.trace_closest(rays, brute=True)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))          # t, triangle id, barycentrics: bit-exact
+    hit = a[:, 0] < 1e27
+    assert 0.3 < hit.mean() <= 1.0
+    rays[:, 6] = np.where(hit, a[:, 0] * 1.001, 1.0)
+    assert np.array_equal(o.trace_any(rays) == 1, hit)                    # any-hit agrees with closest-hit
+    rays[:, 6] = np.where(hit, a[:, 0] * 0.999, 1.0)
+    assert (o.trace_any(rays)[hit] == 0).all()                            # nothing in front of the closest hit
+
+
+def test_cornell_analytic_gbuffer():
+    W = H = 64
+    sc, _ = make_scene(abi.PROC_CORNELL)
+    st = host.default_state(W, H, sc, None); st.environmentProb = 0.0
+    o = Oracle(2); o.upload_scene(sc.desc()); o.resize(W, H)
+    sc.updateCamera(W, H); sc.updateCamera(W, H)
+    o.set_camera(sc.getCamera())
+    o.run_stage(st, 0, abi.STAGE_DIRECT)
+    g = o.readback(abi.BUF_GBUFFER0).view(np.uint32).reshape(H, W, 4)
+    depth = g[..., 0].view(np.float32)
+    # eye (0,1,3.4) looks down -z at the back wall z=-1; the top row of pixels sees the ceiling, none misses
+    assert (depth < 1e27).all()
+    c = depth[H // 2 - 4:H // 2 + 4, 2:6]                                  # left part of the centre rows: back wall or red wall
+    assert np.all((c > 2.3) & (c < 5.0))
+    n = g[H - 2, 6, 1]                                                     # bottom left: floor, normal +y
+    out = np.zeros(3, dtype=np.float32); lib().orc_decompress_unit_vec(int(n), out.ctypes.data)
+    assert np.allclose(out, [0, 1, 0], atol=1e-3)
+    assert (g[..., 3] >> 24 != 0xff).all()                                 # every pixel carries a material hash
+    mot = o.readback(abi.BUF_MOTION).view(np.int16).reshape(H, W, 2)
+    yy, xx = np.mgrid[0:H, 0:W]
+    assert np.array_equal(mot[..., 0], xx) and np.array_equal(mot[..., 1], yy)  # static camera reprojects onto itself
+
+
+def test_frame_is_deterministic_and_thread_independent():
+    W, H = 96, 64
+    sc, env = make_scene(abi.PROC_HELMET, 0.02, env_size=(64, 32))
+    st = host.default_state(W, H, sc, env)
+    outs = []
+    for threads in (1, 5):
+        o = Oracle(threads); o.upload_scene(sc.desc(env)); o.resize(W, H)
+        s2 = host.Scene().makeProcedural(abi.PROC_HELMET, 0.02, 1)
+        s2.updateCamera(W, H)
+        for f in range(2):
+            st.time = 77 + f; s2.updateCamera(W, H); o.set_camera(s2.getCamera()); o.render_frame(st, f)
+        outs.append([o.readback(b) for b in frame_buffers(1)])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
+def test_reservoir_invariants_over_frames():
+    W = H = 48
+    sc, _ = make_scene(abi.PROC_CORNELL)
+    st = host.default_state(W, H, sc, None); st.environmentProb = 0.0; st.fireflyClampThreshold = 100.0
+    o = Oracle(4); o.upload_scene(sc.desc()); o.resize(W, H)
+    sc.updateCamera(W, H)
+    dt = np.dtype([("Li", "<f4", 3), ("wi", "<f4", 3), ("dist", "<f4"), ("num", "<u4"), ("weight", "<f4")])
+    prev_num = None
+    for f in range(90):
+        st.time = 5 + f; sc.updateCamera(W, H); o.set_camera(sc.getCamera()); o.run_stage(st, f, abi.STAGE_DIRECT)
+        resv = o.readback(abi.BUF_DIRECT_RESV0 + (f & 1)).view(dt)
+        assert (resv["num"] <= st.RISSampleNum * st.reservoirClamp).all()        # resvClamp
+        assert np.isfinite(resv["weight"]).all() and (resv["weight"] >= 0).all()  # resvCheckValidity
+        if prev_num is not None and f < 60:
+            lit = resv["num"] > 0
+            assert (resv["num"][lit] >= np.minimum(prev_num[lit], 4)).all()
+        prev_num = resv["num"].copy()
+    assert prev_num.max() == st.RISSampleNum * st.reservoirClamp                   # history saturates at M*clamp
+    lid = o.readback(abi.BUF_LIGHT_ID0 + (89 & 1)).view(np.uint32)
+    kinds = set((lid[lid != 0xffffffff] >> 28).tolist())
+    assert kinds <= {0x4}                                                          # only triangle lights in a Cornell box
+
+
+def _bsdf(fn, m, n, wo, x):
+    m, n, wo, x = (np.ascontiguousarray(v, dtype=np.float32) for v in (m, n, wo, x))
+    out = np.zeros(8, dtype=np.float32)
+    fn(m.ctypes.data, n.ctypes.data, wo.ctypes.data, x.ctypes.data, out.ctypes.data)
+    return out
+
+
+def test_bsdf_reciprocity_pdf_and_energy():
+    rng = np.random.default_rng(5)
+    n = np.array([0, 0, 1], dtype=np.float32)
+    for trial in range(20):
+        m = [*rng.uniform(0.2, 1, 3), float(rng.integers(0, 2)), rng.uniform(0.15, 1.0)]
+        wo = rng.normal(size=3); wo[2] = abs(wo[2]) + 0.2; wo /= np.linalg.norm(wo)
+        acc, cnt = np.zeros(3), 0
+        for k in range(600):
+            r = rng.uniform(0, 1, 3)
+            s = _bsdf(lib().orc_bsdf_sample, m, n, wo, r)
+            wi, pdf = s[0:3], s[3]
+            if pdf <= 1e-8:
+                cnt += 1; continue
+            e = _bsdf(lib().orc_bsdf_eval, m, n, wo, wi)
+            assert np.allclose(e[0:3], s[4:7], rtol=1e-5, atol=1e-7)                # Sample's f == Eval's f
+            assert abs(e[3] - pdf) <= 1e-5 * max(1.0, pdf)                          # Sample's pdf == Pdf(dir)
+            back = _bsdf(lib().orc_bsdf_eval, m, n, wi, wo)
+            assert np.allclose(back[0:3], e[0:3], rtol=2e-3, atol=1e-6)             # reciprocity
+            acc += e[0:3] * wi[2] / pdf; cnt += 1
+        assert (acc / cnt < 1.6).all()   # the reference BSDF (alpha = roughness, Schlick-G) is not exactly energy conserving; it stays bounded
