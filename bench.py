@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=32, help="height of the row band the CPU baseline renders")
+    ap.add_argument("--cpu-rows", type=int, default=256, help="height of the row band the CPU baseline renders")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
