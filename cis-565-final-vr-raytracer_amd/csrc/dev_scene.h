@@ -37,6 +37,24 @@ struct DevScene {
   rt_light_buf_info lightInfo;
   int32_t envW, envH;
   uint32_t numTris, numNodes;
+  int32_t stackEntries;             // LDS traversal stack entries per lane for this tree (multiple of 4, >= max depth)
+  int32_t pad0;
+};
+
+// wavefront scratch records (internal; never cross the ABI)
+struct SurfRec {   // what k_direct_resolve needs from the primary hit's shading state: 64 B
+  rt_vec3 position, normal, ffnormal, emission;
+  float roughness, metallic;
+  uint32_t matID, seed;
+};
+struct PathRec {   // one indirect path between kernels: 160 B
+  uint32_t seed, flags;
+  rt_vec3 throughput, position, ffnormal;
+  float roughness, metallic;
+  rt_vec3 albedo, pending;
+  float samplePdf, primSamplePdf;
+  rt_gi_sample gi;
+  uint32_t pad[3];
 };
 
 // per-frame screen-space state (renderer.cpp:227-302), "this"/"last" already resolved from the frame parity
@@ -49,6 +67,11 @@ struct DevFrame {
   float4* thisDirectResult; float4* thisIndirectResult;
   float4* denoiseDirA; float4* denoiseDirB; float4* denoiseIndA; float4* denoiseIndB;
   unsigned long long* counters;     // 6 x u64 (rt_counters order) or nullptr
+  // wavefront scratch (ctx-owned, sized by rt_resize)
+  float4* hitRec; SurfRec* surf; rt_direct_reservoir* cand; uint32_t* candLid;
+  float4* shadowO; float4* shadowD; uint32_t* occ; uint32_t* status; uint32_t* shadowQ;
+  PathRec* path; float4* rayCO; float4* rayCD; float4* hitC; float4* rayAO; float4* rayAD; uint32_t* occH;
+  uint32_t* qC[2]; uint32_t* qA; uint32_t* qcount;
   int32_t W, H;
 };
 

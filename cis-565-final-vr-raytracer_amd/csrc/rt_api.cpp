@@ -3,6 +3,7 @@
 // (src/renderer.cpp:62-302, src/scene.cpp:453-508, src/accelstruct.cpp:55-65, src/hdr_sampling.cpp:79-95).
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -30,6 +31,10 @@ struct rt_ctx {
   size_t bufBytes[RT_BUF_COUNT] = {};   // logical bytes (W x H elements): readback / upload size
   size_t bufAlloc[RT_BUF_COUNT] = {};   // allocated bytes: + RT_PAD_ROWS rows so equal-height row bands can be all-gathered in place
   rt_scene_camera cam{};
+  // wavefront scratch
+  std::vector<void*> scratchAllocs;
+  DevFrame scratch{};
+  int pipeline = 1;  // 1 = wavefront (default), 0 = fused stage kernels
   bool counting = false;
   unsigned long long* dCounters = nullptr;
   // timing: per frame one event set; event 0 = frame start, event k = end of launch k.  Sets are harvested lazily.
@@ -113,6 +118,7 @@ int rt_create(rt_ctx** out, int device)
   c->device = device;
   if(hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) != hipSuccess) { g_createErr = "rt_create: hipStreamCreate failed"; delete c; return RT_ERR_HIP; }
   c->stream = c->ownStream;
+  if(const char* e = getenv("RESTIR_PIPELINE")) c->pipeline = (strcmp(e, "fused") == 0) ? 0 : 1;
   if(hipMalloc(reinterpret_cast<void**>(&c->dCounters), 8 * sizeof(unsigned long long)) != hipSuccess) { g_createErr = "rt_create: hipMalloc failed"; delete c; return RT_ERR_OOM; }
   (void)hipMemset(c->dCounters, 0, 8 * sizeof(unsigned long long));
   *out = c;
@@ -124,7 +130,7 @@ int rt_destroy(rt_ctx* c)
   if(!c) return RT_ERR_INVALID_ARG;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  freePool(c->sceneAllocs); freePool(c->accelAllocs);
+  freePool(c->sceneAllocs); freePool(c->accelAllocs); freePool(c->scratchAllocs);
   for(int i = 0; i < RT_BUF_COUNT; i++) if(c->bufs[i]) (void)hipFree(c->bufs[i]);
   if(c->dCounters) (void)hipFree(c->dCounters);
   for(auto& E : c->evSets) for(int i = 0; i < rt_ctx::MAX_EV; i++) (void)hipEventDestroy(E.ev[i]);
@@ -229,13 +235,14 @@ int rt_build_accel(rt_ctx* c)
   BuildOutput bo;
   int threads = int(std::thread::hardware_concurrency());
   if(!buildBvh8(d, bo, threads > 0 ? threads : 1)) return fail(c, RT_ERR_INVALID_ARG, "rt_build_accel: BVH8 build failed");
-  if(bo.maxDepth > STACK_N) return fail(c, RT_ERR_INVALID_ARG, "rt_build_accel: BVH8 deeper than the traversal stack");
+  if(bo.maxDepth > STACK_MAX) return fail(c, RT_ERR_INVALID_ARG, "rt_build_accel: BVH8 deeper than the traversal stack");
   int rc;
   if((rc = upload(c, c->accelAllocs, bo.nodes.data(), bo.nodes.size(), &c->ds.nodes))) return rc;
   if((rc = upload(c, c->accelAllocs, bo.tris.data(), bo.tris.size(), &c->ds.tris))) return rc;
   if((rc = upload(c, c->accelAllocs, bo.triRef.data(), bo.triRef.size(), &c->ds.triRef))) return rc;
   if((rc = upload(c, c->accelAllocs, bo.instances.data(), bo.instances.size(), &c->ds.instances))) return rc;
   c->ds.numNodes = uint32_t(bo.nodes.size()); c->ds.numTris = uint32_t(bo.tris.size());
+  c->ds.stackEntries = std::max(8, ((bo.maxDepth + 1 + 3) / 4) * 4);
   c->numNodes = bo.nodes.size(); c->numTris = bo.tris.size(); c->maxDepth = bo.maxDepth;
   c->haveAccel = true;
   return RT_OK;
@@ -257,6 +264,24 @@ int rt_resize(rt_ctx* c, int w, int h)
     RT_HIP(c, hipMemset(c->bufs[i], (i == RT_BUF_LIGHT_ID0 || i == RT_BUF_LIGHT_ID1) ? 0xff : 0, alloc));
     c->bufBytes[i] = bytes; c->bufAlloc[i] = alloc;
   }
+  // wavefront scratch
+  freePool(c->scratchAllocs);
+  c->scratch = DevFrame{};
+  auto alloc = [&](size_t bytes, void** out) -> int {
+    RT_HIP(c, hipMalloc(out, std::max<size_t>(bytes, 256)));
+    c->scratchAllocs.push_back(*out);
+    RT_HIP(c, hipMemset(*out, 0, std::max<size_t>(bytes, 256)));
+    return RT_OK;
+  };
+  DevFrame& X = c->scratch;
+  int rc;
+#define RT_SCRATCH(field, count, T) if((rc = alloc(size_t(count) * sizeof(T), reinterpret_cast<void**>(&X.field)))) return rc
+  RT_SCRATCH(hitRec, n, float4); RT_SCRATCH(surf, n, SurfRec); RT_SCRATCH(cand, n, rt_direct_reservoir); RT_SCRATCH(candLid, n, uint32_t);
+  RT_SCRATCH(shadowO, n, float4); RT_SCRATCH(shadowD, n, float4); RT_SCRATCH(occ, n, uint32_t); RT_SCRATCH(status, n, uint32_t); RT_SCRATCH(shadowQ, n, uint32_t);
+  RT_SCRATCH(path, nh, PathRec); RT_SCRATCH(rayCO, nh, float4); RT_SCRATCH(rayCD, nh, float4); RT_SCRATCH(hitC, nh, float4);
+  RT_SCRATCH(rayAO, nh, float4); RT_SCRATCH(rayAD, nh, float4); RT_SCRATCH(occH, nh, uint32_t);
+  RT_SCRATCH(qC[0], nh, uint32_t); RT_SCRATCH(qC[1], nh, uint32_t); RT_SCRATCH(qA, nh, uint32_t); RT_SCRATCH(qcount, 64, uint32_t);
+#undef RT_SCRATCH
   c->W = w; c->H = h;
   return RT_OK;
 }
@@ -285,6 +310,10 @@ static DevFrame makeFrame(rt_ctx* c, int frames)
   F.denoiseIndA = static_cast<float4*>(c->bufs[RT_BUF_DENOISE_IND_A]); F.denoiseIndB = static_cast<float4*>(c->bufs[RT_BUF_DENOISE_IND_B]);
   F.counters = c->counting ? c->dCounters : nullptr;
   F.W = c->W; F.H = c->H;
+  const DevFrame& X = c->scratch;
+  F.hitRec = X.hitRec; F.surf = X.surf; F.cand = X.cand; F.candLid = X.candLid; F.shadowO = X.shadowO; F.shadowD = X.shadowD; F.occ = X.occ;
+  F.status = X.status; F.shadowQ = X.shadowQ; F.path = X.path; F.rayCO = X.rayCO; F.rayCD = X.rayCD; F.hitC = X.hitC; F.rayAO = X.rayAO;
+  F.rayAD = X.rayAD; F.occH = X.occH; F.qC[0] = X.qC[0]; F.qC[1] = X.qC[1]; F.qA = X.qA; F.qcount = X.qcount;
   return F;
 }
 
@@ -305,7 +334,7 @@ int rt_run_stage(rt_ctx* c, const rt_state* st, int frames, int stage, int level
   if(rowBegin < 0 || (rowBegin & 7)) return fail(c, RT_ERR_INVALID_ARG, "rt_run_stage: rowBegin must be a non-negative multiple of 8");
   RT_HIP(c, hipSetDevice(c->device));
   const DevFrame F = makeFrame(c, frames);
-  RT_HIP(c, launchStage(c->stream, c->ds, F, *st, c->cam, stage, level, rowBegin, rowEnd));
+  RT_HIP(c, (c->pipeline ? launchStageWavefront : launchStage)(c->stream, c->ds, F, *st, c->cam, stage, level, rowBegin, rowEnd));
   return RT_OK;
 }
 
@@ -326,7 +355,7 @@ int rt_render_frame(rt_ctx* c, const rt_state* st, int frames)
   RT_HIP(c, hipEventRecord(E.ev[k], c->stream));
   E.stage[k++] = -1;
   auto run = [&](int stage, int level) -> int {
-    hipError_t e = launchStage(c->stream, c->ds, F, *st, c->cam, stage, level, 0, 0);
+    hipError_t e = (c->pipeline ? launchStageWavefront : launchStage)(c->stream, c->ds, F, *st, c->cam, stage, level, 0, 0);
     if(e != hipSuccess) { c->err = std::string("launchStage: ") + hipGetErrorString(e); return RT_ERR_HIP; }
     e = hipEventRecord(E.ev[k], c->stream);
     if(e != hipSuccess) { c->err = std::string("hipEventRecord: ") + hipGetErrorString(e); return RT_ERR_HIP; }
@@ -406,6 +435,13 @@ int rt_get_counters(rt_ctx* c, rt_counters* out)
   for(int i = 0; i < RT_STAGE_COUNT; i++) out->stageMs[i] = float(c->accStage[i]);
   out->frameMs = float(c->accFrame);
   out->framesTimed = c->accFrames;
+  return RT_OK;
+}
+
+int rt_set_pipeline(rt_ctx* c, int pipeline)
+{
+  if(!c || pipeline < 0 || pipeline > 1) return RT_ERR_INVALID_ARG;
+  c->pipeline = pipeline;
   return RT_OK;
 }
 

@@ -1,0 +1,175 @@
+// stage_common.h — helpers shared by the fused stage kernels (stages.hip) and the wavefront pipeline (wavefront.hip).
+#pragma once
+#include "shading.h"
+#include "stages.h"
+
+namespace rt {
+
+// ---- tile / lane bookkeeping ------------------------------------------------------------------------------------
+struct TileCoord { int x, y; bool valid; };
+RT_DEV TileCoord tileOf(int tilesX, int tilesY)
+{
+  const int nTiles = tilesX * tilesY;
+  const int L = int(blockIdx.x);
+  const int chunk = (nTiles + 7) >> 3;
+  const int tile = (L & 7) * chunk + (L >> 3);
+  TileCoord t;
+  t.valid = (L >> 3) < chunk && tile < nTiles;
+  t.y = tile / tilesX;
+  t.x = tile - t.y * tilesX;
+  return t;
+}
+
+RT_DEV void flushCounters(const DevFrame& F, const Ctx& c)
+{
+  if(!F.counters) return;
+  atomicAdd(&F.counters[0], (unsigned long long)c.nClosest);
+  atomicAdd(&F.counters[1], (unsigned long long)c.nAny);
+  atomicAdd(&F.counters[2], (unsigned long long)c.tc.nodes);
+  atomicAdd(&F.counters[3], (unsigned long long)c.tc.tris);
+  atomicAdd(&F.counters[4], (unsigned long long)c.nShaded);
+  atomicAdd(&F.counters[5], (unsigned long long)c.nRis);
+}
+
+// ---- image helpers: Vulkan storage-image semantics (out-of-bounds loads return 0) ------------------------------
+RT_DEV uint4 loadG(const uint4* g, const DevFrame& F, i2 c)
+{
+  if(c.x < 0 || c.y < 0 || c.x >= F.W || c.y >= F.H) return make_uint4(0, 0, 0, 0);
+  return g[size_t(c.y) * F.W + c.x];
+}
+RT_DEV f4 loadImg(const float4* img, const DevFrame& F, i2 c)
+{
+  if(c.x < 0 || c.y < 0 || c.x >= F.W || c.y >= F.H) return mk4(0, 0, 0, 0);
+  const float4 v = img[size_t(c.y) * F.W + c.x];
+  return mk4(v.x, v.y, v.z, v.w);
+}
+RT_DEV void storeImg(float4* img, const DevFrame& F, i2 c, f4 v) { img[size_t(c.y) * F.W + c.x] = make_float4(v.x, v.y, v.z, v.w); }
+RT_DEV short sat16(int v) { return short(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+RT_DEV void storeMotion(const DevFrame& F, i2 c, i2 v) { F.motion[size_t(c.y) * F.W + c.x] = make_short2(sat16(v.x), sat16(v.y)); }  // RG16_SINT
+RT_DEV i2 loadMotion(const DevFrame& F, i2 c)
+{
+  if(c.x < 0 || c.y < 0 || c.x >= F.W || c.y >= F.H) return i2{0, 0};
+  const short2 m = F.motion[size_t(c.y) * F.W + c.x];
+  return i2{int(m.x), int(m.y)};
+}
+
+// ---- shared by the direct stages ---------------------------------------------------------------------------------
+RT_DEV uint4 encodeGeometryInfo(const State& state, float depth)  // direct_stage.comp:37-45
+{
+  uint4 g;
+  g.x = rt_f2u(depth);
+  g.y = compress_unit_vec(state.normal);
+  g.z = packUnorm4x8(mk4(state.mat.metallic, state.mat.roughness, (state.mat.ior - 1.0f) / RT_MAX_IOR_MINUS_ONE, state.mat.transmission));
+  g.w = packUnorm4x8(mk4(state.mat.albedo, 1.0f)) & 0xFFFFFFu;
+  g.w += hash8bit(state.matID);
+  return g;
+}
+RT_DEV void updateGeometryAlbedo(uint4& g, f3 albedo)  // direct_gen.comp:63-66
+{
+  uint32_t matId = g.w & 0xff000000u;
+  g.w = (packUnorm4x8(mk4(albedo, 1.0f)) & 0x00ffffffu) | matId;
+}
+RT_DEV i2 createMotionIndex(const Ctx& c, f3 wpos)  // direct_stage.comp:125-139
+{
+  f4 proj = mul(c.cam.lastProjView, mk4(wpos, 1.0f));
+  f3 ndc = xyz(proj) / proj.w;
+  f2 mv = mk2(ndc.x, ndc.y) * 0.5f + 0.5f;
+  f2 s = mv * mk2(float(c.rtx.size.x), float(c.rtx.size.y));
+  return i2{rt_ftoi(s.x), rt_ftoi(s.y)};
+}
+// direct_stage.comp:47-84 == direct_reuse.comp:52-89
+RT_DEV bool findTemporalNeighborDirect(const DevFrame& F, const rt_state& st, f3 norm, float reprojDepth, uint32_t matId, i2 lastCoord,
+                                       rt_direct_reservoir& resv, uint32_t& lid)
+{
+  const i2 size{st.size.x, st.size.y};
+  if(!inBound(lastCoord, i2{2, 0}, size)) return false;
+  const uint4 g = loadG(F.lastG, F, lastCoord);
+  const f3 pnorm = decompress_unit_vec(g.y);
+  const float pdepth = rt_u2f(g.x);
+  const uint32_t matHash = g.w & 0xFF000000u;
+  if(inBound(lastCoord, size)) {
+    if(hash8bit(matId) == matHash) {
+      if(dot(norm, pnorm) > 0.9f && reprojDepth < pdepth * 1.05f) {
+        const size_t li = size_t(lastCoord.y) * st.size.x + lastCoord.x;
+        resv = F.lastDirectResv[li];
+        lid = F.lastLightId[li];
+        return true;
+      }
+    }
+  }
+  return false;
+}
+// resvUpdate / resvMerge / resvClamp / resvCheckValidity on the AoS reservoir (reservoir.glsl:34-82, 116-128)
+RT_DEV bool resvUpdate(rt_direct_reservoir& r, const rt_light_sample& s, float w, float rr)
+{
+  r.weight += w; r.num += 1;
+  if(rr * r.weight < w) { r.lightSample = s; return true; }
+  return false;
+}
+RT_DEV bool resvMerge(rt_direct_reservoir& r, const rt_direct_reservoir& rhs, float rr)
+{
+  r.weight += rhs.weight; r.num += rhs.num;
+  if(rr * r.weight < rhs.weight) { r.lightSample = rhs.lightSample; return true; }
+  return false;
+}
+template <class R> RT_DEV void resvClamp(R& r, int clamp)
+{
+  if(r.num > uint32_t(clamp)) { r.weight *= float(clamp) / float(r.num); r.num = uint32_t(clamp); }
+}
+RT_DEV rt_direct_reservoir zeroDirectResv()
+{
+  rt_direct_reservoir r;
+  r.lightSample.Li = rt_vec3{0, 0, 0}; r.lightSample.wi = rt_vec3{0, 0, 0}; r.lightSample.dist = 0.f; r.num = 0; r.weight = 0.f;
+  return r;
+}
+
+// the M-candidate RIS loop + visibility of the winner (direct_stage.comp:189-210 == direct_gen.comp:110-132)
+RT_DEV void risCandidates(Ctx& c, const State& state, f3 wo, rt_direct_reservoir& resv, uint32_t& lid)
+{
+  for(int i = 0; i < c.rtx.RISSampleNum; i++) {
+    rt_light_sample ls;
+    float p = c.SampleDirectLightNoVisibility(state.position, ls);
+    f3 pHat = mk3(ls.Li) * metallicWorkflowBSDF(state.mat, state.ffnormal, wo, mk3(ls.wi)) * rt_abs(dot(state.ffnormal, mk3(ls.wi)));
+    float weight = resvToScalar(pHat / p);
+    if(Ctx::IsPdfInvalid(p) || rt_isnan(weight)) weight = 0.0f;
+    if(resvUpdate(resv, ls, weight, rnd(c.seed))) lid = c.lastLightId;
+  }
+  const rt_light_sample ls = resv.lightSample;
+  Ray shadowRay{OffsetRay(state.position, state.ffnormal), mk3(ls.wi)};
+  // a zero-weight reservoir cannot change here (the only effect of the shadow ray is weight := 0): skip the ray
+  if(resv.weight != 0.0f && c.Occlusion(shadowRay, state.position, ls.dist)) resv.weight = 0.0f;
+}
+
+
+struct GState { f3 position, normal, ffnormal; Material mat; uint32_t matID; };
+// getDirectStateFromGBuffer / getIndirectStateFromGBuffer, pathtrace.glsl:277-313
+RT_DEV bool stateFromGBuffer(uint4 g, const Ray& ray, GState& s, float& depth)
+{
+  depth = rt_u2f(g.x);
+  if(depth >= RT_INFINITY * 0.8f) return false;
+  s.position = ray.origin + ray.direction * depth;
+  s.normal = decompress_unit_vec(g.y);
+  s.ffnormal = dot(s.normal, ray.direction) <= 0.0f ? s.normal : -s.normal;
+  s.mat.albedo = xyz(unpackUnorm4x8(g.w));
+  s.mat.emission = mk3(0.f);
+  const f4 matInfo = unpackUnorm4x8(g.z);
+  s.mat.metallic = matInfo.x;
+  s.mat.roughness = matInfo.y;
+  s.mat.ior = matInfo.z * RT_MAX_IOR_MINUS_ONE + 1.f;
+  s.mat.transmission = matInfo.w;
+  s.matID = g.w >> 24;
+  return true;
+}
+
+
+RT_DEV rt_gi_sample newGISample()  // :110-115
+{
+  rt_gi_sample s;
+  s.L = rt_vec3{0, 0, 0}; s.xv = rt_vec3{0, 0, 0}; s.nv = rt_vec3{100.0f, 100.0f, 100.0f}; s.xs = rt_vec3{0, 0, 0}; s.ns = rt_vec3{0, 0, 0}; s.pHat = 0.f;
+  return s;
+}
+RT_DEV bool GISampleValid(const rt_gi_sample& s) { return s.nv.x < 1.1f && !hasNan(mk3(s.L)); }  // :117-119
+RT_DEV float MISw(const rt_state& st, float f, float g) { return (st.MIS > 0) ? powerHeuristic(f, g) : 1.0f; }  // :57-59
+
+
+}  // namespace rt

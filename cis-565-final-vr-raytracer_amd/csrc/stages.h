@@ -2,8 +2,11 @@
 #include <hip/hip_runtime.h>
 #include "dev_scene.h"
 namespace rt {
-constexpr int STACK_N = 32;  // LDS traversal stack entries per lane (8 B each); rt_build_accel rejects deeper trees
+constexpr int STACK_MAX = 64;  // LDS traversal stack entries per lane (8 B each) upper bound; rt_build_accel rejects deeper trees
 // one entry of Renderer::run's dispatch list (renderer.cpp:163-205) on `stream`
 hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F, const rt_state& st, const rt_scene_camera& cam, int stage, int level,
                        int rowBegin, int rowEnd);
+// the same dispatch entry as a sequence of lean trace kernels + shading kernels with ray compaction (wavefront.hip)
+hipError_t launchStageWavefront(hipStream_t stream, const DevScene& S, const DevFrame& F, const rt_state& st, const rt_scene_camera& cam, int stage, int level,
+                                int rowBegin, int rowEnd);
 }

@@ -168,7 +168,7 @@ RT_DEV bool traceRay(const DevScene& S, f3 o, f3 d, float tmax, uint32_t raySeed
       const uint32_t hits = ngroup.y;
       const uint32_t bit = 31u - uint32_t(__clz(int(hits)));
       ngroup.y &= ~(1u << bit);
-      if(ngroup.y > 0x00FFFFFFu) { if(sp < STACK_N) stack[(sp++) * 64] = ngroup; }
+      if(ngroup.y > 0x00FFFFFFu) { if(sp < S.stackEntries) stack[(sp++) * 64] = ngroup; }
       const uint32_t slot = (bit - 24u) ^ octinv;
       const uint32_t rel = uint32_t(__popc(hits & ~(0xFFFFFFFFu << slot) & 0xFFu));
       const uint4* np = reinterpret_cast<const uint4*>(S.nodes + (ngroup.x + rel));

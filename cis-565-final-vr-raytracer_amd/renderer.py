@@ -15,7 +15,7 @@ _lib = None
 # every symbol include/rt_abi.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_build_accel", "rt_resize", "rt_set_camera",
                "rt_render_frame", "rt_run_stage", "rt_readback", "rt_upload_history", "rt_buffer_bytes", "rt_device_ptr",
-               "rt_set_counting", "rt_get_counters", "rt_sync", "rt_last_error", "rt_abi_version"]
+               "rt_set_counting", "rt_get_counters", "rt_sync", "rt_last_error", "rt_abi_version", "rt_set_pipeline"]
 
 
 def hip_lib():
@@ -42,6 +42,7 @@ def hip_lib():
         L.rt_upload_history.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         L.rt_device_ptr.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         L.rt_set_counting.argtypes = [C.c_void_p, C.c_int]
+        L.rt_set_pipeline.argtypes = [C.c_void_p, C.c_int]
         L.rt_get_counters.argtypes = [C.c_void_p, C.c_void_p]
         L.rt_accel_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
         _lib = L
@@ -137,6 +138,9 @@ class Renderer:
         p, n, pitch = C.c_void_p(), C.c_size_t(), C.c_size_t()
         self._chk(hip_lib().rt_device_ptr(self._h, buf, C.byref(p), C.byref(n), C.byref(pitch)), "rt_device_ptr")
         return _DevArray(p.value, n.value, self), pitch.value
+
+    def set_pipeline(self, wavefront=True):
+        self._chk(hip_lib().rt_set_pipeline(self._h, 1 if wavefront else 0), "rt_set_pipeline")
 
     def set_counting(self, enable):
         self._chk(hip_lib().rt_set_counting(self._h, 1 if enable else 0), "rt_set_counting")

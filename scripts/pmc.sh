@@ -1,0 +1,30 @@
+#!/bin/bash
+# PMC passes for the frame kernels (run on the GPU box): scripts/pmc.sh <tag>
+# Counters are collected in their own runs (no trace domains besides kernel dispatch), one group per pass.
+TAG=${1:-pmc}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+run() { rocprofv3 --pmc $2 --output-format csv -d $OUT -o $1 -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2>&1; }
+run sq1 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM"
+run sq2 "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_INST_LEVEL_VMEM SQ_INSTS_SMEM GRBM_GUI_ACTIVE"
+run tcc1 "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"
+run tcc2 "FETCH_SIZE"
+run tcc3 "WRITE_SIZE"
+python - <<PY
+import csv, glob, collections, os
+out = "$OUT"
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.Counter()
+for f in glob.glob(out + "/*counter_collection.csv"):
+    for row in csv.DictReader(open(f)):
+        k = row["Kernel_Name"].split("(")[0]
+        agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
+        calls[(k, row["Counter_Name"])] += 1
+with open(out + "/summary.txt", "w") as fo:
+    for k, d in sorted(agg.items()):
+        if not k.startswith(("rt::", "void rt::")): continue
+        fo.write(k + "\n")
+        for c, v in sorted(d.items()):
+            fo.write("   %-28s %16.1f per launch (%d launches)\n" % (c, v / calls[(k, c)], calls[(k, c)]))
+print(open(out + "/summary.txt").read())
+PY

@@ -11,12 +11,13 @@ from helpers import abi, host, make_scene, frame_buffers, compare_buffers, Rende
 pytestmark = pytest.mark.gpu
 
 
-def _pair(sc, env, W, H):
+def _pair(sc, env, W, H, wavefront=True):
     from restir_amd.renderer import Renderer
     from oracle.binding import Oracle
     desc = sc.desc(env)
     o = Oracle(0); o.upload_scene(desc); o.resize(W, H)
     r = Renderer().setup(0); r.load_scene(desc); r.update(W, H)
+    r.set_pipeline(wavefront)   # both kernel organisations must reproduce the oracle bit for bit
     return o, r
 
 
@@ -52,13 +53,14 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("wavefront", [True, False], ids=["wavefront", "fused"])
 @pytest.mark.parametrize("name,kind,scale,W,H,frames,env_size,moving", CASES, ids=[c[0] for c in CASES])
-def test_full_frame_bit_exact(name, kind, scale, W, H, frames, env_size, moving):
+def test_full_frame_bit_exact(name, kind, scale, W, H, frames, env_size, moving, wavefront):
     sc, env = make_scene(kind, scale, 1, env_size)
     st = host.default_state(W, H, sc, env)
     if env is None:
         st.environmentProb = 0.0; st.fireflyClampThreshold = 100.0
-    o, r = _pair(sc, env, W, H)
+    o, r = _pair(sc, env, W, H, wavefront)
     _run(sc, st, o, r, W, H, frames, moving)
     img = r.readback(abi.BUF_DIRECT_RESULT0 + ((frames - 1) & 1)).view(np.float32)
     assert np.isfinite(img).all() and img.max() > 0.01       # not comparing two empty frames
@@ -74,8 +76,9 @@ def test_cornell_config2_di_only_512():
     _run(sc, st, o, r, W, H, 8, stages=[(abi.STAGE_DIRECT, 0)], buffers=bufs)
 
 
+@pytest.mark.parametrize("wavefront", [True, False], ids=["wavefront", "fused"])
 @pytest.mark.parametrize("variant", ["restir_none", "ris_only", "no_denoise", "no_modulate", "no_mis_depth2", "debug_normal", "gen_reuse_split", "m16_clamp4"])
-def test_state_variants(variant):
+def test_state_variants(variant, wavefront):
     W, H = 160, 96
     sc, env = make_scene(abi.PROC_SPONZA, 0.01, 1, (128, 64))
     st = host.default_state(W, H, sc, env)
@@ -90,7 +93,7 @@ def test_state_variants(variant):
     if variant == "gen_reuse_split":
         stages = [(abi.STAGE_DIRECT_GEN, 0), (abi.STAGE_DIRECT_REUSE, 0), (abi.STAGE_INDIRECT, 0)] + \
                  [(abi.STAGE_DENOISE_DIRECT, l) for l in range(4)] + [(abi.STAGE_DENOISE_INDIRECT, l) for l in range(5)] + [(abi.STAGE_COMPOSE, 0)]
-    o, r = _pair(sc, env, W, H)
+    o, r = _pair(sc, env, W, H, wavefront)
     _run(sc, st, o, r, W, H, 3, moving=True, stages=stages)
 
 
