@@ -215,6 +215,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
     if((rc = upload(c, c->sceneAllocs, &one, 1, &c->ds.envAccel))) return rc;
     c->ds.envW = c->ds.envH = 1;
   }
+  RT_HIP(c, hipDeviceSynchronize());
   c->haveScene = true;
   return RT_OK;
 }
@@ -244,6 +245,7 @@ int rt_build_accel(rt_ctx* c)
   c->ds.numNodes = uint32_t(bo.nodes.size()); c->ds.numTris = uint32_t(bo.tris.size());
   c->ds.stackEntries = std::max(8, ((bo.maxDepth + 1 + 3) / 4) * 4);
   c->numNodes = bo.nodes.size(); c->numTris = bo.tris.size(); c->maxDepth = bo.maxDepth;
+  RT_HIP(c, hipDeviceSynchronize());
   c->haveAccel = true;
   return RT_OK;
 }
@@ -282,6 +284,7 @@ int rt_resize(rt_ctx* c, int w, int h)
   RT_SCRATCH(rayAO, nh, float4); RT_SCRATCH(rayAD, nh, float4); RT_SCRATCH(occH, nh, uint32_t);
   RT_SCRATCH(qC[0], nh, uint32_t); RT_SCRATCH(qC[1], nh, uint32_t); RT_SCRATCH(qA, nh, uint32_t); RT_SCRATCH(qcount, 64, uint32_t);
 #undef RT_SCRATCH
+  RT_HIP(c, hipDeviceSynchronize());  // memsets above ran on the null stream; the ctx stream does not wait for it implicitly
   c->W = w; c->H = h;
   return RT_OK;
 }
@@ -396,6 +399,7 @@ int rt_upload_history(rt_ctx* c, int buffer, const void* src, size_t bytes)
   RT_HIP(c, hipSetDevice(c->device));
   RT_HIP(c, hipStreamSynchronize(c->stream));
   RT_HIP(c, hipMemcpy(c->bufs[buffer], src, bytes, hipMemcpyHostToDevice));
+  RT_HIP(c, hipDeviceSynchronize());
   return RT_OK;
 }
 
@@ -415,6 +419,7 @@ int rt_set_counting(rt_ctx* c, int enable)
   RT_HIP(c, hipSetDevice(c->device));
   RT_HIP(c, hipStreamSynchronize(c->stream));
   RT_HIP(c, hipMemset(c->dCounters, 0, 8 * sizeof(unsigned long long)));
+  RT_HIP(c, hipDeviceSynchronize());
   harvestTimings(c);
   for(double& v : c->accStage) v = 0;
   c->accFrame = 0; c->accFrames = 0;

@@ -92,7 +92,7 @@ RT_DEV float rnd(uint32_t& seed)  // rand(), random.glsl:98-102
 
 // HitTest, traceray_rq.glsl:32-102.  The stochastic draw comes from a hash of (ray seed, triangle id) instead of
 // advancing prd.seed per candidate, so the outcome does not depend on candidate order.
-__device__ __noinline__ bool hitTestAlpha(const DevScene& S, uint32_t gid, float u, float v, uint32_t raySeed)
+RT_DEV bool hitTestAlpha(const DevScene& S, uint32_t gid, float u, float v, uint32_t raySeed)
 {
   const TriRef ref = S.triRef[gid];
   const rt_prim_mesh pm = S.primMeshes[S.instances[ref.inst].primMesh];
