@@ -29,9 +29,22 @@ struct alignas(16) Tri48 {
   float e2x, e2y, e2z;  // v2 - v0
   uint32_t globalId;    // index in (instance, primitive) order: the tie-break key and the key into triRef[]
   uint32_t flags;       // TRI_*
-  uint32_t pad;
+  uint32_t alphaIdx;    // index into alphaRec[] for triangles that need the alpha test (TRI_OPAQUE clear), else 0
 };
 static_assert(sizeof(Tri48) == 48, "Tri48 must be 48 bytes");
+
+// Everything HitTest (traceray_rq.glsl:32-102) needs for one non-opaque triangle, gathered at build time so the
+// alpha test is one 64 B record + the texel fetches instead of triRef -> instance -> primMesh -> indices -> 3 vertices ->
+// material -> texture descriptor (7 dependent gathers per candidate; foliage rays test tens of candidates).
+struct alignas(16) AlphaRec {
+  float uv0x, uv0y, uv1x, uv1y, uv2x, uv2y;  // raw vertex texcoords (HitTest does not strip the handedness bit)
+  float baseAlpha;                            // pbrBaseColorFactor.a
+  float cutoff;
+  const uint8_t* bgra;                        // nullptr: no base colour texture
+  int32_t w, h, wrapS, wrapT, filter;
+  int32_t alphaMode;
+};
+static_assert(sizeof(AlphaRec) == 64, "AlphaRec must be 64 bytes");
 
 // globalId -> (instance, primitive)
 struct TriRef { uint32_t inst, prim; };

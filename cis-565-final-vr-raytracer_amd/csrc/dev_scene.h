@@ -24,6 +24,7 @@ struct DevScene {
   const Node8* nodes;
   const Tri48* tris;
   const TriRef* triRef;
+  const AlphaRec* alphaRec;         // indexed by Tri48::alphaIdx
   const DevInstance* instances;
   const rt_prim_mesh* primMeshes;   // geoInfo[] (InstanceData rows): vertex/index offsets + materialIndex
   const rt_vertex* vertices;

@@ -20,6 +20,7 @@ struct rt_ctx {
   std::string err;
   // host copy of the scene (rt_build_accel runs after rt_upload_scene returns; the caller keeps ownership of its arrays)
   std::vector<rt_prim_mesh> primMeshes; std::vector<rt_vertex> vertices; std::vector<uint32_t> indices; std::vector<rt_instance> instances;
+  std::vector<rt_material> materials; std::vector<DevTexture> devTextures;
   // device allocations of the scene
   std::vector<void*> sceneAllocs, accelAllocs;
   DevScene ds{};
@@ -176,6 +177,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
   c->vertices.assign(d->vertices, d->vertices + d->numVertices);
   c->indices.assign(d->indices, d->indices + d->numIndices);
   c->instances.assign(d->instances, d->instances + d->numInstances);
+  c->materials.assign(d->materials, d->materials + d->numMaterials);
 
   int rc;
   if((rc = upload(c, c->sceneAllocs, d->primMeshes, d->numPrimMeshes, &c->ds.primMeshes))) return rc;
@@ -198,6 +200,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
     texs[i] = DevTexture{dp, t.width, t.height, t.wrapS, t.wrapT, t.magFilter, 0};
   }
   if((rc = upload(c, c->sceneAllocs, texs.data(), texs.size(), &c->ds.textures))) return rc;
+  c->devTextures = texs;
   // environment
   if(d->envRgba32f && d->envWidth > 0 && d->envHeight > 0) {
     const size_t n = size_t(d->envWidth) * d->envHeight;
@@ -237,7 +240,27 @@ int rt_build_accel(rt_ctx* c)
   int threads = int(std::thread::hardware_concurrency());
   if(!buildBvh8(d, bo, threads > 0 ? threads : 1)) return fail(c, RT_ERR_INVALID_ARG, "rt_build_accel: BVH8 build failed");
   if(bo.maxDepth > STACK_MAX) return fail(c, RT_ERR_INVALID_ARG, "rt_build_accel: BVH8 deeper than the traversal stack");
+  // alpha records for the triangles that go through HitTest (instances without FORCE_OPAQUE)
+  std::vector<AlphaRec> alpha(1, AlphaRec{});
+  for(Tri48& T : bo.tris) {
+    if(T.flags & TRI_OPAQUE) continue;
+    const TriRef ref = bo.triRef[T.globalId];
+    const rt_prim_mesh& pm = c->primMeshes[c->instances[ref.inst].primMesh];
+    const rt_material& m = c->materials[size_t(pm.materialIndex > 0 ? pm.materialIndex : 0)];
+    const uint32_t* ix = &c->indices[pm.firstIndex + 3 * ref.prim];
+    AlphaRec a{};
+    const rt_vec2 t0 = c->vertices[pm.vertexOffset + ix[0]].texcoord, t1 = c->vertices[pm.vertexOffset + ix[1]].texcoord, t2 = c->vertices[pm.vertexOffset + ix[2]].texcoord;
+    a.uv0x = t0.x; a.uv0y = t0.y; a.uv1x = t1.x; a.uv1y = t1.y; a.uv2x = t2.x; a.uv2y = t2.y;
+    a.baseAlpha = m.pbrBaseColorFactor.w; a.cutoff = m.alphaCutoff; a.alphaMode = m.alphaMode;
+    if(m.pbrBaseColorTexture > -1 && size_t(m.pbrBaseColorTexture) < c->devTextures.size()) {
+      const DevTexture& t = c->devTextures[size_t(m.pbrBaseColorTexture)];
+      a.bgra = t.bgra; a.w = t.w; a.h = t.h; a.wrapS = t.wrapS; a.wrapT = t.wrapT; a.filter = t.filter;
+    }
+    T.alphaIdx = uint32_t(alpha.size());
+    alpha.push_back(a);
+  }
   int rc;
+  if((rc = upload(c, c->accelAllocs, alpha.data(), alpha.size(), &c->ds.alphaRec))) return rc;
   if((rc = upload(c, c->accelAllocs, bo.nodes.data(), bo.nodes.size(), &c->ds.nodes))) return rc;
   if((rc = upload(c, c->accelAllocs, bo.tris.data(), bo.tris.size(), &c->ds.tris))) return rc;
   if((rc = upload(c, c->accelAllocs, bo.triRef.data(), bo.triRef.size(), &c->ds.triRef))) return rc;
@@ -282,7 +305,7 @@ int rt_resize(rt_ctx* c, int w, int h)
   RT_SCRATCH(shadowO, n, float4); RT_SCRATCH(shadowD, n, float4); RT_SCRATCH(occ, n, uint32_t); RT_SCRATCH(status, n, uint32_t); RT_SCRATCH(shadowQ, n, uint32_t);
   RT_SCRATCH(path, nh, PathRec); RT_SCRATCH(rayCO, nh, float4); RT_SCRATCH(rayCD, nh, float4); RT_SCRATCH(hitC, nh, float4);
   RT_SCRATCH(rayAO, nh, float4); RT_SCRATCH(rayAD, nh, float4); RT_SCRATCH(occH, nh, uint32_t);
-  RT_SCRATCH(qC[0], nh, uint32_t); RT_SCRATCH(qC[1], nh, uint32_t); RT_SCRATCH(qA, nh, uint32_t); RT_SCRATCH(qcount, 64, uint32_t);
+  RT_SCRATCH(qC[0], nh, uint32_t); RT_SCRATCH(qC[1], nh, uint32_t); RT_SCRATCH(qA, nh, uint32_t); RT_SCRATCH(qcount, 256, uint32_t);
 #undef RT_SCRATCH
   RT_HIP(c, hipDeviceSynchronize());  // memsets above ran on the null stream; the ctx stream does not wait for it implicitly
   c->W = w; c->H = h;

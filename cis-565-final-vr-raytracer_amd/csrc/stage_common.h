@@ -7,17 +7,28 @@ namespace rt {
 
 // ---- tile / lane bookkeeping ------------------------------------------------------------------------------------
 struct TileCoord { int x, y; bool valid; };
+// XCD-aware tile order.  Workgroup L runs on XCD L % 8 (observed placement; used for speed only).  The screen is cut into
+// stripes of TILE_STRIPE tile rows; stripe s belongs to XCD s % 8, so every XCD's private L2 works on a few compact screen
+// regions (and the BVH subtrees under them) while expensive image regions (foliage rows vs sky rows) are spread over all XCDs.
+constexpr int TILE_STRIPE = 2;
 RT_DEV TileCoord tileOf(int tilesX, int tilesY)
 {
-  const int nTiles = tilesX * tilesY;
   const int L = int(blockIdx.x);
-  const int chunk = (nTiles + 7) >> 3;
-  const int tile = (L & 7) * chunk + (L >> 3);
+  const int xcd = L & 7, k = L >> 3;                 // k-th workgroup of this XCD
+  const int perStripe = TILE_STRIPE * tilesX;
+  const int s = k / perStripe, off = k - s * perStripe;
   TileCoord t;
-  t.valid = (L >> 3) < chunk && tile < nTiles;
-  t.y = tile / tilesX;
-  t.x = tile - t.y * tilesX;
+  t.y = (s * 8 + xcd) * TILE_STRIPE + off / tilesX;
+  t.x = off % tilesX;
+  t.valid = t.y < tilesY;
   return t;
+}
+// grid size (in workgroups) that covers tilesX x tilesY tiles with the mapping above
+inline unsigned tileGrid(int tilesX, int tilesY)
+{
+  const int stripes = (tilesY + TILE_STRIPE - 1) / TILE_STRIPE;
+  const int perXcd = (stripes + 7) / 8;
+  return unsigned(8 * perXcd * TILE_STRIPE * tilesX);
 }
 
 RT_DEV void flushCounters(const DevFrame& F, const Ctx& c)

@@ -422,7 +422,7 @@ hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F,
   if(rowBegin >= rowEnd || gw <= 0) return hipSuccess;
   const int tilesX = (gw + 7) / 8, tilesY = (rowEnd - rowBegin + 7) / 8;
   const int nTiles = tilesX * tilesY;
-  const dim3 grid(unsigned(((nTiles + 7) / 8) * 8)), block(64);
+  const dim3 grid(tileGrid(tilesX, tilesY)), block(64);
   const size_t lds = size_t(S.stackEntries) * 64 * sizeof(uint2);
   switch(stage) {
     case RT_STAGE_DIRECT: hipLaunchKernelGGL(k_direct_stage, grid, block, lds, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY); break;

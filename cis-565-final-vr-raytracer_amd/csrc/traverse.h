@@ -90,29 +90,45 @@ RT_DEV float rnd(uint32_t& seed)  // rand(), random.glsl:98-102
   return rt_u2f(0x3f800000u | (r >> 9)) - 1.0f;
 }
 
-// HitTest, traceray_rq.glsl:32-102.  The stochastic draw comes from a hash of (ray seed, triangle id) instead of
-// advancing prd.seed per candidate, so the outcome does not depend on candidate order.
-RT_DEV bool hitTestAlpha(const DevScene& S, uint32_t gid, float u, float v, uint32_t raySeed)
+// HitTest, traceray_rq.glsl:32-102, on the pre-gathered AlphaRec.  The stochastic draw comes from a hash of
+// (ray seed, triangle id) instead of advancing prd.seed per candidate, so the outcome does not depend on candidate
+// order.  Only the alpha channel of the bilinear fetch is evaluated (same arithmetic).
+RT_DEV float texelAlpha(const uint8_t* bgra, int w, int x, int y)
 {
-  const TriRef ref = S.triRef[gid];
-  const rt_prim_mesh pm = S.primMeshes[S.instances[ref.inst].primMesh];
-  const uint32_t matIndex = uint32_t(pm.materialIndex > 0 ? pm.materialIndex : 0);
-  const rt_material* mat = &S.materials[matIndex];
-  float baseColorAlpha = mat->pbrBaseColorFactor.w;
-  const int tex = mat->pbrBaseColorTexture;
-  if(tex > -1) {
-    const uint32_t* ix = &S.indices[pm.firstIndex + 3 * ref.prim];
-    const rt_vec2 t0 = S.vertices[pm.vertexOffset + ix[0]].texcoord, t1 = S.vertices[pm.vertexOffset + ix[1]].texcoord,
-                  t2 = S.vertices[pm.vertexOffset + ix[2]].texcoord;
+  return float(bgra[(size_t(y) * w + x) * 4 + 3]) / 255.0f;
+}
+RT_DEV bool hitTestAlpha(const DevScene& S, uint32_t alphaIdx, uint32_t gid, float u, float v, uint32_t raySeed)
+{
+  const uint4* rp = reinterpret_cast<const uint4*>(S.alphaRec + alphaIdx);
+  const uint4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+  float baseColorAlpha = rt_u2f(r1.z);
+  const uint8_t* bgra = reinterpret_cast<const uint8_t*>((uint64_t(r2.y) << 32) | uint64_t(r2.x));
+  if(bgra) {
     const f3 bary = mk3((1.0f - u) - v, u, v);
-    f2 uv = (mk2(t0.x, t0.y) * bary.x + mk2(t1.x, t1.y) * bary.y) + mk2(t2.x, t2.y) * bary.z;
-    baseColorAlpha = baseColorAlpha * sampleTexture(S, tex, uv).w;
+    const f2 uv = (mk2(rt_u2f(r0.x), rt_u2f(r0.y)) * bary.x + mk2(rt_u2f(r0.z), rt_u2f(r0.w)) * bary.y) + mk2(rt_u2f(r1.x), rt_u2f(r1.y)) * bary.z;
+    const int w = int(r2.z), h = int(r2.w), wrapS = int(r3.x), wrapT = int(r3.y), filter = int(r3.z);
+    float fx = uv.x * float(w), fy = uv.y * float(h);
+    float a;
+    if(filter == RT_FILTER_NEAREST) {
+      a = texelAlpha(bgra, w, wrapCoord(rt_ftoi(rt_floor(fx)), w, wrapS), wrapCoord(rt_ftoi(rt_floor(fy)), h, wrapT));
+    } else {
+      fx = fx - 0.5f; fy = fy - 0.5f;
+      const float x0f = rt_floor(fx), y0f = rt_floor(fy);
+      const float ax = fx - x0f, ay = fy - y0f;
+      const int x0 = rt_ftoi(x0f), y0 = rt_ftoi(y0f);
+      const int xa = wrapCoord(x0, w, wrapS), xb = wrapCoord(x0 + 1, w, wrapS);
+      const int ya = wrapCoord(y0, h, wrapT), yb = wrapCoord(y0 + 1, h, wrapT);
+      const float top = mixf(texelAlpha(bgra, w, xa, ya), texelAlpha(bgra, w, xb, ya), ax);
+      const float bot = mixf(texelAlpha(bgra, w, xa, yb), texelAlpha(bgra, w, xb, yb), ax);
+      a = mixf(top, bot, ay);
+    }
+    baseColorAlpha = baseColorAlpha * a;
   }
   float opacity;
-  if(mat->alphaMode == RT_ALPHA_MASK) opacity = baseColorAlpha > mat->alphaCutoff ? 1.0f : 0.0f;
+  if(int(r3.w) == RT_ALPHA_MASK) opacity = baseColorAlpha > rt_u2f(r1.w) ? 1.0f : 0.0f;
   else opacity = baseColorAlpha;
   uint32_t s = raySeed ^ (gid * 2654435761u);
-  float r = rnd(s);
+  const float r = rnd(s);
   return !(r > opacity);
 }
 
@@ -140,107 +156,135 @@ RT_DEV bool intersectTri(const Tri48& T, f3 o, f3 d, float& t, float& u, float& 
 
 RT_DEV float cvtByte(uint32_t w, int j) { return float((w >> (8 * j)) & 0xffu); }  // v_cvt_f32_ubyte{j}
 
-// ANY = false: closest hit in (0, 1e28); ANY = true: first accepted hit in (0, tmax).
-// `stack` points at this lane's column of the wave's LDS stack (stride 64 entries).
+// Traversal state of one ray, advanced one node visit (+ the triangle tests of that node) per step() so that a kernel can
+// interleave bookkeeping (persistent threads, ray refill) between steps.
+struct Trav {
+  f3 o, d;
+  float idx, idy, idz;
+  uint32_t octinv;
+  uint2 ngroup;
+  int sp;
+  float tmax;      // ANY: ray tmax; closest: unused (RT_INFINITY)
+  uint32_t seed;
+  RayHit hit;
+  bool found;
+};
+
+// ANY = false: closest hit in (0, 1e28); ANY = true: first accepted hit in (0, tmax).  Returns false when there is nothing to traverse.
+template <bool ANY>
+RT_DEV bool travInit(Trav& T, f3 o, f3 d, float tmax, uint32_t raySeed)
+{
+  T.o = o; T.d = d; T.tmax = tmax; T.seed = raySeed; T.found = false; T.sp = 0;
+  T.hit.t = ANY ? tmax : RT_INFINITY;
+  T.hit.gid = 0xffffffffu; T.hit.u = 0.f; T.hit.v = 0.f;
+  T.ngroup = make_uint2(0u, 0u);
+  if(hasNan(o) || hasNan(d) || !(T.hit.t > 0.0f)) return false;
+  // reciprocal direction with a floor on |d| (a zero component must not produce inf*0 = NaN in the slab test)
+  const float eps = 1e-20f;
+  T.idx = 1.0f / (rt_abs(d.x) > eps ? d.x : (d.x < 0.0f ? -eps : eps));
+  T.idy = 1.0f / (rt_abs(d.y) > eps ? d.y : (d.y < 0.0f ? -eps : eps));
+  T.idz = 1.0f / (rt_abs(d.z) > eps ? d.z : (d.z < 0.0f ? -eps : eps));
+  T.octinv = (((d.x < 0.0f) ? 1u : 0u) | ((d.y < 0.0f) ? 2u : 0u) | ((d.z < 0.0f) ? 4u : 0u)) ^ 7u;
+  T.ngroup = make_uint2(0u, 0x80000000u);
+  return true;
+}
+
+// One step: pop the nearest pending child (or a pure triangle group), test its 8 children, test the triangles it exposes,
+// then pop the stack if the node group is exhausted.  `stack` = this lane's LDS column (stride 64 entries).
+// Returns true while the ray still has work.
+template <bool ANY>
+RT_DEV bool travStep(const DevScene& S, Trav& T, uint2* stack, TravCounters& tc)
+{
+  const bool nx = T.d.x < 0.0f, ny = T.d.y < 0.0f, nz = T.d.z < 0.0f;
+  const uint32_t octinv = T.octinv;
+  const uint32_t octinv4 = octinv * 0x01010101u;
+  uint2 ngroup = T.ngroup;
+  uint2 tgroup;
+  if(ngroup.y > 0x00FFFFFFu) {
+    const uint32_t hits = ngroup.y;
+    const uint32_t bit = 31u - uint32_t(__clz(int(hits)));
+    ngroup.y &= ~(1u << bit);
+    if(ngroup.y > 0x00FFFFFFu) { if(T.sp < S.stackEntries) stack[(T.sp++) * 64] = ngroup; }
+    const uint32_t slot = (bit - 24u) ^ octinv;
+    const uint32_t rel = uint32_t(__popc(hits & ~(0xFFFFFFFFu << slot) & 0xFFu));
+    const uint4* np = reinterpret_cast<const uint4*>(S.nodes + (ngroup.x + rel));
+    const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+    tc.nodes++;
+    const float adjx = rt_u2f((n0.w & 0xffu) << 23) * T.idx;
+    const float adjy = rt_u2f(((n0.w >> 8) & 0xffu) << 23) * T.idy;
+    const float adjz = rt_u2f(((n0.w >> 16) & 0xffu) << 23) * T.idz;
+    const float orgx = (rt_u2f(n0.x) - T.o.x) * T.idx, orgy = (rt_u2f(n0.y) - T.o.y) * T.idy, orgz = (rt_u2f(n0.z) - T.o.z) * T.idz;
+    const uint32_t imask = n0.w >> 24;
+    uint32_t hitmask = 0;
+#pragma unroll
+    for(int half = 0; half < 2; half++) {
+      const uint32_t meta4 = half ? n1.w : n1.z;
+      const uint32_t isInner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
+      const uint32_t innerMask4 = (isInner4 >> 4) * 0xffu;
+      const uint32_t bitIndex4 = (meta4 ^ (octinv4 & innerMask4)) & 0x1F1F1F1Fu;
+      const uint32_t childBits4 = (meta4 >> 5) & 0x07070707u;
+      const uint32_t qlx = half ? n2.y : n2.x, qly = half ? n2.w : n2.z, qlz = half ? n3.y : n3.x;
+      const uint32_t qhx = half ? n3.w : n3.z, qhy = half ? n4.y : n4.x, qhz = half ? n4.w : n4.z;
+      const uint32_t nearx = nx ? qhx : qlx, farx = nx ? qlx : qhx;
+      const uint32_t neary = ny ? qhy : qly, fary = ny ? qly : qhy;
+      const uint32_t nearz = nz ? qhz : qlz, farz = nz ? qlz : qhz;
+#pragma unroll
+      for(int j = 0; j < 4; j++) {
+        const float tlx = __builtin_fmaf(cvtByte(nearx, j), adjx, orgx), thx = __builtin_fmaf(cvtByte(farx, j), adjx, orgx);
+        const float tly = __builtin_fmaf(cvtByte(neary, j), adjy, orgy), thy = __builtin_fmaf(cvtByte(fary, j), adjy, orgy);
+        const float tlz = __builtin_fmaf(cvtByte(nearz, j), adjz, orgz), thz = __builtin_fmaf(cvtByte(farz, j), adjz, orgz);
+        const float tn = fmaxf(fmaxf(tlx, tly), fmaxf(tlz, 0.0f));
+        const float tf = fminf(fminf(thx, thy), fminf(thz, T.hit.t));
+        if(tn <= tf) hitmask |= ((childBits4 >> (8 * j)) & 0xffu) << ((bitIndex4 >> (8 * j)) & 0xffu);
+      }
+    }
+    ngroup = make_uint2(n1.x, (hitmask & 0xFF000000u) | imask);
+    tgroup = make_uint2(n1.y, hitmask & 0x00FFFFFFu);
+  } else {
+    tgroup = ngroup;
+    ngroup = make_uint2(0u, 0u);
+  }
+
+  while(tgroup.y != 0u) {
+    const uint32_t bit = 31u - uint32_t(__clz(int(tgroup.y)));
+    tgroup.y &= ~(1u << bit);
+    const uint4* tp = reinterpret_cast<const uint4*>(S.tris + (tgroup.x + bit));
+    const uint4 a = tp[0], b = tp[1], c = tp[2];
+    Tri48 R;
+    R.v0x = rt_u2f(a.x); R.v0y = rt_u2f(a.y); R.v0z = rt_u2f(a.z); R.e1x = rt_u2f(a.w);
+    R.e1y = rt_u2f(b.x); R.e1z = rt_u2f(b.y); R.e2x = rt_u2f(b.z); R.e2y = rt_u2f(b.w);
+    R.e2z = rt_u2f(c.x); R.globalId = c.y; R.flags = c.z; R.alphaIdx = c.w;
+    tc.tris++;
+    float t, u, v;
+    if(!intersectTri(R, T.o, T.d, t, u, v)) continue;
+    if(ANY) {
+      if(!(t > 0.0f && t < T.tmax)) continue;
+    } else {
+      if(!(t > 0.0f && t < RT_INFINITY)) continue;
+      if(!(t < T.hit.t || (t == T.hit.t && R.globalId < T.hit.gid))) continue;
+    }
+    if(!(R.flags & TRI_OPAQUE) && !hitTestAlpha(S, R.alphaIdx, R.globalId, u, v, T.seed)) continue;
+    T.hit.t = t; T.hit.gid = R.globalId; T.hit.u = u; T.hit.v = v;
+    T.found = true;
+    if(ANY) break;
+  }
+  if(ANY && T.found) { T.ngroup = make_uint2(0u, 0u); return false; }
+  if(ngroup.y <= 0x00FFFFFFu) {
+    if(T.sp == 0) { T.ngroup = make_uint2(0u, 0u); return false; }
+    ngroup = stack[(--T.sp) * 64];
+  }
+  T.ngroup = ngroup;
+  return true;
+}
+
 template <bool ANY>
 RT_DEV bool traceRay(const DevScene& S, f3 o, f3 d, float tmax, uint32_t raySeed, uint2* stack, RayHit& hit, TravCounters& tc)
 {
-  hit.t = ANY ? tmax : RT_INFINITY;
-  hit.gid = 0xffffffffu; hit.u = 0.f; hit.v = 0.f;
-  if(hasNan(o) || hasNan(d) || !(hit.t > 0.0f)) return false;
-
-  // reciprocal direction with a floor on |d| (a zero component must not produce inf*0 = NaN in the slab test)
-  const float eps = 1e-20f;
-  const float idx = 1.0f / (rt_abs(d.x) > eps ? d.x : (d.x < 0.0f ? -eps : eps));
-  const float idy = 1.0f / (rt_abs(d.y) > eps ? d.y : (d.y < 0.0f ? -eps : eps));
-  const float idz = 1.0f / (rt_abs(d.z) > eps ? d.z : (d.z < 0.0f ? -eps : eps));
-  const bool nx = d.x < 0.0f, ny = d.y < 0.0f, nz = d.z < 0.0f;
-  const uint32_t octinv = ((nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u)) ^ 7u;
-  const uint32_t octinv4 = octinv * 0x01010101u;
-
-  uint2 ngroup = make_uint2(0u, 0x80000000u);
-  uint2 tgroup = make_uint2(0u, 0u);
-  int sp = 0;
-  bool found = false;
-
-  for(;;) {
-    if(ngroup.y > 0x00FFFFFFu) {
-      const uint32_t hits = ngroup.y;
-      const uint32_t bit = 31u - uint32_t(__clz(int(hits)));
-      ngroup.y &= ~(1u << bit);
-      if(ngroup.y > 0x00FFFFFFu) { if(sp < S.stackEntries) stack[(sp++) * 64] = ngroup; }
-      const uint32_t slot = (bit - 24u) ^ octinv;
-      const uint32_t rel = uint32_t(__popc(hits & ~(0xFFFFFFFFu << slot) & 0xFFu));
-      const uint4* np = reinterpret_cast<const uint4*>(S.nodes + (ngroup.x + rel));
-      const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-      tc.nodes++;
-
-      const float adjx = rt_u2f((n0.w & 0xffu) << 23) * idx;
-      const float adjy = rt_u2f(((n0.w >> 8) & 0xffu) << 23) * idy;
-      const float adjz = rt_u2f(((n0.w >> 16) & 0xffu) << 23) * idz;
-      const float orgx = (rt_u2f(n0.x) - o.x) * idx, orgy = (rt_u2f(n0.y) - o.y) * idy, orgz = (rt_u2f(n0.z) - o.z) * idz;
-      const uint32_t imask = n0.w >> 24;
-      uint32_t hitmask = 0;
-#pragma unroll
-      for(int half = 0; half < 2; half++) {
-        const uint32_t meta4 = half ? n1.w : n1.z;
-        const uint32_t isInner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
-        const uint32_t innerMask4 = (isInner4 >> 4) * 0xffu;
-        const uint32_t bitIndex4 = (meta4 ^ (octinv4 & innerMask4)) & 0x1F1F1F1Fu;
-        const uint32_t childBits4 = (meta4 >> 5) & 0x07070707u;
-        const uint32_t qlx = half ? n2.y : n2.x, qly = half ? n2.w : n2.z, qlz = half ? n3.y : n3.x;
-        const uint32_t qhx = half ? n3.w : n3.z, qhy = half ? n4.y : n4.x, qhz = half ? n4.w : n4.z;
-        const uint32_t nearx = nx ? qhx : qlx, farx = nx ? qlx : qhx;
-        const uint32_t neary = ny ? qhy : qly, fary = ny ? qly : qhy;
-        const uint32_t nearz = nz ? qhz : qlz, farz = nz ? qlz : qhz;
-#pragma unroll
-        for(int j = 0; j < 4; j++) {
-          const float tlx = __builtin_fmaf(cvtByte(nearx, j), adjx, orgx), thx = __builtin_fmaf(cvtByte(farx, j), adjx, orgx);
-          const float tly = __builtin_fmaf(cvtByte(neary, j), adjy, orgy), thy = __builtin_fmaf(cvtByte(fary, j), adjy, orgy);
-          const float tlz = __builtin_fmaf(cvtByte(nearz, j), adjz, orgz), thz = __builtin_fmaf(cvtByte(farz, j), adjz, orgz);
-          const float tn = fmaxf(fmaxf(tlx, tly), fmaxf(tlz, 0.0f));
-          const float tf = fminf(fminf(thx, thy), fminf(thz, hit.t));
-          if(tn <= tf) hitmask |= ((childBits4 >> (8 * j)) & 0xffu) << ((bitIndex4 >> (8 * j)) & 0xffu);
-        }
-      }
-      ngroup = make_uint2(n1.x, (hitmask & 0xFF000000u) | imask);
-      tgroup = make_uint2(n1.y, hitmask & 0x00FFFFFFu);
-    } else {
-      tgroup = ngroup;
-      ngroup = make_uint2(0u, 0u);
-    }
-
-    while(tgroup.y != 0u) {
-      const uint32_t bit = 31u - uint32_t(__clz(int(tgroup.y)));
-      tgroup.y &= ~(1u << bit);
-      const uint4* tp = reinterpret_cast<const uint4*>(S.tris + (tgroup.x + bit));
-      const uint4 a = tp[0], b = tp[1], c = tp[2];
-      Tri48 T;
-      T.v0x = rt_u2f(a.x); T.v0y = rt_u2f(a.y); T.v0z = rt_u2f(a.z); T.e1x = rt_u2f(a.w);
-      T.e1y = rt_u2f(b.x); T.e1z = rt_u2f(b.y); T.e2x = rt_u2f(b.z); T.e2y = rt_u2f(b.w);
-      T.e2z = rt_u2f(c.x); T.globalId = c.y; T.flags = c.z;
-      tc.tris++;
-      float t, u, v;
-      if(!intersectTri(T, o, d, t, u, v)) continue;
-      if(ANY) {
-        if(!(t > 0.0f && t < tmax)) continue;
-      } else {
-        if(!(t > 0.0f && t < RT_INFINITY)) continue;
-        if(!(t < hit.t || (t == hit.t && T.globalId < hit.gid))) continue;
-      }
-      if(!(T.flags & TRI_OPAQUE) && !hitTestAlpha(S, T.globalId, u, v, raySeed)) continue;
-      hit.t = t; hit.gid = T.globalId; hit.u = u; hit.v = v;
-      found = true;
-      if(ANY) break;
-    }
-    if(ANY && found) break;
-
-    if(ngroup.y <= 0x00FFFFFFu) {
-      if(sp == 0) break;
-      ngroup = stack[(--sp) * 64];
-    }
-  }
-  return found;
+  Trav T;
+  bool live = travInit<ANY>(T, o, d, tmax, raySeed);
+  while(live) live = travStep<ANY>(S, T, stack, tc);
+  hit = T.hit;
+  return T.found;
 }
 
 }  // namespace rt

@@ -13,6 +13,9 @@
 // wave-aggregated atomic per wave (ballot + mbcnt).  Per-pixel arithmetic and RNG draw order are exactly those of the
 // fused stages, so every output stays bit-identical (tests/test_gpu_parity.py runs both pipelines against the oracle).
 #include "stage_common.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 namespace rt {
 
@@ -62,6 +65,77 @@ __global__ __launch_bounds__(64) void k_trace(DevScene S, DevFrame F, const uint
 }
 
 // ================================================================================================================
+// persistent trace kernel: a fixed number of waves pulls rays from the queue; a lane whose ray terminates is refilled
+// with the next ray instead of idling until the slowest ray of its wave is done (wave lifetimes of the one-ray-per-lane
+// kernels above spread over 100x on foliage: p50 112 us, max 2.7 ms for the primary rays of the benchmark frame).
+// ================================================================================================================
+constexpr int REFILL_MIN = 20;  // refill when at least this many lanes are idle (amortises the queue atomic)
+
+template <bool ANY, bool PRIMARY>
+__global__ __launch_bounds__(64) void k_trace_p(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, const uint32_t* queue, const uint32_t* countPtr,
+                                                uint32_t fixedCount, uint32_t* head, const float4* rayO, const float4* rayD, float4* hitOut, uint32_t* occOut,
+                                                int rowBegin, int rowEnd, int tilesX)
+{
+  extern __shared__ uint2 s_stack[];
+  const uint32_t lane = threadIdx.x;
+  uint2* stack = s_stack + lane;
+  const uint32_t count = PRIMARY ? fixedCount : *countPtr;
+  Trav T;
+  T.found = false; T.hit.t = 0.f; T.hit.gid = 0xffffffffu; T.hit.u = T.hit.v = 0.f;
+  bool live = false;
+  uint32_t outIdx = 0;
+  TravCounters tc{0, 0};
+  uint32_t nRays = 0;
+  bool exhausted = false;
+  for(;;) {
+    const unsigned long long idleMask = __ballot(live ? 0 : 1);
+    const int nIdle = __popcll(idleMask);
+    if(!exhausted && (nIdle >= REFILL_MIN)) {
+      uint32_t base = 0;
+      const int leader = __ffsll((long long)idleMask) - 1;
+      if(int(lane) == leader) base = atomicAdd(head, uint32_t(nIdle));
+      base = uint32_t(__shfl(int(base), leader));
+      if(base + uint32_t(nIdle) >= count) exhausted = true;
+      if(!live) {
+        const uint32_t i = base + uint32_t(__popcll(idleMask & ((1ull << lane) - 1ull)));
+        if(i < count) {
+          f3 o, d; float tmax = RT_INFINITY; uint32_t seed; bool valid = true;
+          if(PRIMARY) {
+            const uint32_t tile = i >> 6, l = i & 63u;
+            const i2 px{int(tile % uint32_t(tilesX)) * 8 + int(l & 7u), rowBegin + int(tile / uint32_t(tilesX)) * 8 + int(l >> 3)};
+            valid = px.x < st.size.x && px.y < rowEnd;
+            Ctx c(S, st, cam, nullptr);
+            const Ray r = c.raySpawn(px, i2{st.size.x, st.size.y});
+            o = r.origin; d = r.direction;
+            seed = tea(uint32_t(st.size.x) * uint32_t(px.y) + uint32_t(px.x), st.time);
+            outIdx = uint32_t(px.y) * uint32_t(st.size.x) + uint32_t(px.x);
+          } else {
+            outIdx = queue ? queue[i] : i;
+            const float4 ro = rayO[outIdx], rd = rayD[outIdx];
+            o = mk3(ro.x, ro.y, ro.z); d = mk3(rd.x, rd.y, rd.z); tmax = ro.w; seed = rt_f2u(rd.w);
+          }
+          if(valid) {
+            nRays++;
+            live = travInit<ANY>(T, o, d, ANY ? tmax : RT_INFINITY, seed);
+            if(!live) { if(ANY) occOut[outIdx] = 0u; else hitOut[outIdx] = make_float4(T.hit.t, rt_u2f(T.hit.gid), T.hit.u, T.hit.v); }
+          }
+        }
+      }
+    }
+    if(__ballot(live ? 1 : 0) == 0ull) { if(exhausted) break; else continue; }
+    if(live) {
+      live = travStep<ANY>(S, T, stack, tc);
+      if(!live) { if(ANY) occOut[outIdx] = T.found ? 1u : 0u; else hitOut[outIdx] = make_float4(T.hit.t, rt_u2f(T.hit.gid), T.hit.u, T.hit.v); }
+    }
+  }
+  if(F.counters) {
+    atomicAdd(&F.counters[ANY ? 1 : 0], (unsigned long long)nRays);
+    atomicAdd(&F.counters[2], (unsigned long long)tc.nodes);
+    atomicAdd(&F.counters[3], (unsigned long long)tc.tris);
+  }
+}
+
+// ================================================================================================================
 // direct stage
 // ================================================================================================================
 // primary rays: raySpawn + ClosestHit (direct_stage.comp:152, 279-280); dense, tile ordered (coherent)
@@ -77,9 +151,13 @@ __global__ __launch_bounds__(64) void k_primary(DevScene S, DevFrame F, rt_state
   const uint32_t seed = tea(uint32_t(st.size.x) * uint32_t(px.y) + uint32_t(px.x), st.time);
   const Ray r = c.raySpawn(px, i2{st.size.x, st.size.y});
   RayHit hit; TravCounters tc{0, 0};
+  const unsigned long long t0 = F.counters ? wall_clock64() : 0ull;
   traceRay<false>(S, r.origin, r.direction, RT_INFINITY, seed, s_stack + lane, hit, tc);
   F.hitRec[size_t(px.y) * st.size.x + px.x] = make_float4(hit.t, rt_u2f(hit.gid), hit.u, hit.v);
   if(F.counters) {
+    // instrumented mode only: per-lane traversal statistics for profiling scripts (DirB is free during the direct stage)
+    const unsigned long long t1 = wall_clock64();
+    F.denoiseDirB[size_t(px.y) * st.size.x + px.x] = make_float4(float(t1 - t0), float(tc.nodes), float(tc.tris), float(t0 & 0xffffffull));
     atomicAdd(&F.counters[0], 1ull);
     atomicAdd(&F.counters[2], (unsigned long long)tc.nodes);
     atomicAdd(&F.counters[3], (unsigned long long)tc.tris);
@@ -479,27 +557,62 @@ hipError_t launchStageWavefront(hipStream_t stream, const DevScene& S, const Dev
   if(rowBegin >= rowEnd || gw <= 0) return hipSuccess;
   const int tilesX = (gw + 7) / 8, tilesY = (rowEnd - rowBegin + 7) / 8;
   const int nTiles = tilesX * tilesY;
-  const dim3 grid(unsigned(((nTiles + 7) / 8) * 8)), block(64);
+  const dim3 grid(tileGrid(tilesX, tilesY)), block(64);
   const size_t lds = size_t(S.stackEntries) * 64 * sizeof(uint2);
   const unsigned cap = unsigned(nTiles);  // queue capacity in waves: at most one ray per pixel of the band
-  hipError_t e = hipMemsetAsync(F.qcount, 0, 64 * sizeof(uint32_t), stream);
+  static const int persistent = getenv("RESTIR_PERSISTENT") ? atoi(getenv("RESTIR_PERSISTENT")) : 1;
+  static const int wavesPerCU = getenv("RESTIR_WAVES_PER_CU") ? atoi(getenv("RESTIR_WAVES_PER_CU")) : 16;
+  const dim3 pgrid(unsigned(std::min<long long>(256ll * wavesPerCU, (long long)cap)));
+  uint32_t* heads = F.qcount + 128;
+  if(getenv("RESTIR_DEBUG_OCC")) {
+    static bool once = false;
+    if(!once) {
+      once = true;
+      int nb = 0;
+      for(size_t l : {size_t(0), size_t(1024), lds, size_t(16384), size_t(65536)}) {
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_primary, 64, l);
+        fprintf(stderr, "[occ] k_primary block 64 lds %zu -> %d blocks/CU\n", l, nb);
+      }
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_direct_shade, 64, 0);
+      fprintf(stderr, "[occ] k_direct_shade -> %d blocks/CU\n", nb);
+      hipFuncAttributes fa; hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_primary));
+      fprintf(stderr, "[occ] k_primary regs %d shared %zu local %zu maxThreads %d\n", fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes, fa.maxThreadsPerBlock);
+    }
+  }
+  hipError_t e = hipMemsetAsync(F.qcount, 0, 256 * sizeof(uint32_t), stream);
   if(e != hipSuccess) return e;
   if(isDirect) {
     const int genOnly = stage == RT_STAGE_DIRECT_GEN ? 1 : 0;
-    hipLaunchKernelGGL(k_primary, grid, block, lds, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY);
+    if(persistent)
+      hipLaunchKernelGGL((k_trace_p<false, true>), pgrid, block, lds, stream, S, F, st, cam, (const uint32_t*)nullptr, (const uint32_t*)nullptr, uint32_t(nTiles) * 64u,
+                         heads + 1, (const float4*)nullptr, (const float4*)nullptr, F.hitRec, (uint32_t*)nullptr, rowBegin, rowEnd, tilesX);
+    else
+      hipLaunchKernelGGL(k_primary, grid, block, lds, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY);
     hipLaunchKernelGGL(k_direct_shade, grid, block, 0, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY, genOnly);
-    hipLaunchKernelGGL(k_trace<true>, dim3(cap), block, lds, stream, S, F, (const uint32_t*)F.shadowQ, (const uint32_t*)(F.qcount + CNT_SHADOW),
-                       (const float4*)F.shadowO, (const float4*)F.shadowD, (float4*)nullptr, F.occ);
+    if(persistent)
+      hipLaunchKernelGGL((k_trace_p<true, false>), pgrid, block, lds, stream, S, F, st, cam, (const uint32_t*)F.shadowQ, (const uint32_t*)(F.qcount + CNT_SHADOW), 0u,
+                         heads + 0, (const float4*)F.shadowO, (const float4*)F.shadowD, (float4*)nullptr, F.occ, 0, 0, 0);
+    else
+      hipLaunchKernelGGL(k_trace<true>, dim3(cap), block, lds, stream, S, F, (const uint32_t*)F.shadowQ, (const uint32_t*)(F.qcount + CNT_SHADOW),
+                         (const float4*)F.shadowO, (const float4*)F.shadowD, (float4*)nullptr, F.occ);
     hipLaunchKernelGGL(k_direct_resolve, grid, block, 0, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY, genOnly);
   } else {
     if(st.maxDepth > 24) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_ind_init, grid, block, 0, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY);
     for(int d = 1; d <= st.maxDepth; d++) {
-      if(d > 1)
-        hipLaunchKernelGGL(k_trace<true>, dim3(cap), block, lds, stream, S, F, (const uint32_t*)F.qA, (const uint32_t*)(F.qcount + 32 + d),
-                           (const float4*)F.rayAO, (const float4*)F.rayAD, (float4*)nullptr, F.occH);
-      hipLaunchKernelGGL(k_trace<false>, dim3(cap), block, lds, stream, S, F, (const uint32_t*)F.qC[d & 1], (const uint32_t*)(F.qcount + 1 + d),
-                         (const float4*)F.rayCO, (const float4*)F.rayCD, F.hitC, (uint32_t*)nullptr);
+      if(persistent) {
+        if(d > 1)
+          hipLaunchKernelGGL((k_trace_p<true, false>), pgrid, block, lds, stream, S, F, st, cam, (const uint32_t*)F.qA, (const uint32_t*)(F.qcount + 32 + d), 0u,
+                             heads + 32 + d, (const float4*)F.rayAO, (const float4*)F.rayAD, (float4*)nullptr, F.occH, 0, 0, 0);
+        hipLaunchKernelGGL((k_trace_p<false, false>), pgrid, block, lds, stream, S, F, st, cam, (const uint32_t*)F.qC[d & 1], (const uint32_t*)(F.qcount + 1 + d), 0u,
+                           heads + 1 + d, (const float4*)F.rayCO, (const float4*)F.rayCD, F.hitC, (uint32_t*)nullptr, 0, 0, 0);
+      } else {
+        if(d > 1)
+          hipLaunchKernelGGL(k_trace<true>, dim3(cap), block, lds, stream, S, F, (const uint32_t*)F.qA, (const uint32_t*)(F.qcount + 32 + d),
+                             (const float4*)F.rayAO, (const float4*)F.rayAD, (float4*)nullptr, F.occH);
+        hipLaunchKernelGGL(k_trace<false>, dim3(cap), block, lds, stream, S, F, (const uint32_t*)F.qC[d & 1], (const uint32_t*)(F.qcount + 1 + d),
+                           (const float4*)F.rayCO, (const float4*)F.rayCD, F.hitC, (uint32_t*)nullptr);
+      }
       hipLaunchKernelGGL(k_ind_bounce, dim3(cap), block, 0, stream, S, F, st, cam, d);
     }
     hipLaunchKernelGGL(k_ind_finish, grid, block, 0, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY);

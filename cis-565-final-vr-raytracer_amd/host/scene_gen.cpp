@@ -6,6 +6,7 @@
 #include "scene.hpp"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace rth {
 namespace {
@@ -255,6 +256,7 @@ Palette makePalette(Builder& B, int numTextured, int texSize, uint32_t seed, flo
   GltfMaterial leaf = diffuse(1, 1, 1, 0.8f);
   leaf.baseColorTexture = B.addTexture(makeTexture(texSize / 2, 3, seed + 77, leafTint));
   leaf.alphaMode = RT_ALPHA_MASK; leaf.alphaCutoff = 0.5f; leaf.doubleSided = 1;
+  if(getenv("RESTIR_DEBUG_OPAQUE_LEAVES")) leaf.alphaMode = RT_ALPHA_OPAQUE;  // experiment switch: cost of the alpha test
   P.leaf = B.addMaterial(leaf);
   GltfMaterial glass = diffuse(0.6f, 0.7f, 0.75f, 0.05f, 1.f);
   P.glass = B.addMaterial(glass);

@@ -12,6 +12,8 @@ W, H = 1920, 1080
 
 @pytest.fixture(scope="module")
 def bistro():
+    import torch
+    torch.cuda.init(); torch.zeros(1, device="cuda")   # initialise torch's HIP context on the main thread before any worker thread needs it
     sc, env = make_scene(abi.PROC_BISTRO_EXT, 1.0, 1, (2048, 1024))
     st = host.default_state(W, H, sc, env)
     sc.updateCamera(W, H); sc.updateCamera(W, H)
