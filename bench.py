@@ -28,7 +28,7 @@ import numpy as np  # noqa: E402
 STAGE_NAMES = ["direct_stage", "indirect_stage", "denoise_direct", "denoise_indirect", "compose", "direct_gen", "direct_reuse"]
 # closed-form screen traffic per stage at the reference layouts (bytes per stage-grid pixel)
 SCREEN_BYTES = {0: 124.0, 1: 204.0, 2: 192.0, 3: 240.0, 4: 68.0}
-NODE_B, TRI_B, HIT_B, RIS_B = 80, 48, 12 + 96 + 80, 16 + 96  # bvh8.h node / triangle; hit gathers; RIS candidate gathers
+NODE_B, TRI_B, HIT_B, RIS_B = 80, 64, 12 + 96 + 80, 16 + 96  # bvh8.h node / triangle record; hit gathers; RIS candidate gathers
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E
 
 

@@ -156,7 +156,7 @@ bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads)
       T.v0x = w[0][0]; T.v0y = w[0][1]; T.v0z = w[0][2];
       T.e1x = w[1][0] - w[0][0]; T.e1y = w[1][1] - w[0][1]; T.e1z = w[1][2] - w[0][2];
       T.e2x = w[2][0] - w[0][0]; T.e2y = w[2][1] - w[0][1]; T.e2z = w[2][2] - w[0][2];
-      T.globalId = uint32_t(g); T.flags = f; T.alphaIdx = 0;
+      T.globalId = uint32_t(g); T.flags = f; T.alphaIdx = 0; T.omm[0] = T.omm[1] = T.omm[2] = T.omm[3] = 0;
       out.triRef[g] = TriRef{i, p};
     }
   }

@@ -2,7 +2,10 @@
 // Stands where the reference has Renderer / Scene / AccelStructure / HdrSampling talking to Vulkan
 // (src/renderer.cpp:62-302, src/scene.cpp:453-508, src/accelstruct.cpp:55-65, src/hdr_sampling.cpp:79-95).
 #include <hip/hip_runtime.h>
+#include <array>
+#include <cmath>
 #include <cstdio>
+#include <map>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -21,6 +24,7 @@ struct rt_ctx {
   // host copy of the scene (rt_build_accel runs after rt_upload_scene returns; the caller keeps ownership of its arrays)
   std::vector<rt_prim_mesh> primMeshes; std::vector<rt_vertex> vertices; std::vector<uint32_t> indices; std::vector<rt_instance> instances;
   std::vector<rt_material> materials; std::vector<DevTexture> devTextures;
+  std::vector<std::vector<uint8_t>> hostAlpha;  // alpha channel of every texture (opacity micro-map build)
   // device allocations of the scene
   std::vector<void*> sceneAllocs, accelAllocs;
   DevScene ds{};
@@ -70,6 +74,61 @@ static thread_local std::string g_createErr;
       return (e_ == hipErrorOutOfMemory) ? RT_ERR_OOM : RT_ERR_HIP;                                                         \
     }                                                                                                                       \
   } while(0)
+
+// ---- opacity micro-map ---------------------------------------------------------------------------------------------
+// Cell (i,j) covers barycentrics u in [i/8,(i+1)/8], v in [j/8,(j+1)/8].  Its texture footprint is the bounding box of the
+// four corners' texcoords, widened by the bilinear footprint and one texel of slack for float rounding; the cell is
+// classified only when min/max alpha over that footprint decide HitTest (traceray_rq.glsl:86-101) with a safety margin.
+static int wrapTexel(int i, int n, int mode)
+{
+  if(mode == RT_WRAP_CLAMP) return i < 0 ? 0 : (i >= n ? n - 1 : i);
+  if(mode == RT_WRAP_MIRROR) { int p = 2 * n; int m = i % p; if(m < 0) m += p; return m < n ? m : p - 1 - m; }
+  int m = i % n; if(m < 0) m += n;
+  return m;
+}
+static void buildOpacityMap(const AlphaRec& a, const std::vector<uint8_t>* alpha, uint32_t omm[4])
+{
+  omm[0] = omm[1] = omm[2] = omm[3] = 0;
+  const bool mask = a.alphaMode == RT_ALPHA_MASK;
+  for(int j = 0; j < 8; j++)
+    for(int i = 0; i + j < 8; i++) {
+      double amin = 1.0, amax = 1.0;
+      if(alpha && a.w > 0 && a.h > 0) {
+        double fx0 = 1e300, fx1 = -1e300, fy0 = 1e300, fy1 = -1e300;
+        for(int c = 0; c < 4; c++) {
+          const double u = (i + (c & 1)) / 8.0, v = (j + (c >> 1)) / 8.0, w0 = 1.0 - u - v;
+          const double tx = a.uv0x * w0 + a.uv1x * u + a.uv2x * v, ty = a.uv0y * w0 + a.uv1y * u + a.uv2y * v;
+          fx0 = std::min(fx0, tx * a.w); fx1 = std::max(fx1, tx * a.w); fy0 = std::min(fy0, ty * a.h); fy1 = std::max(fy1, ty * a.h);
+        }
+        if(!(fx1 - fx0 < 4096.0 && fy1 - fy0 < 4096.0) || !std::isfinite(fx0 + fx1 + fy0 + fy1)) continue;  // unknown
+        const long long x0 = (long long)std::floor(fx0 - 0.5) - 1, x1 = (long long)std::floor(fx1 - 0.5) + 2;
+        const long long y0 = (long long)std::floor(fy0 - 0.5) - 1, y1 = (long long)std::floor(fy1 - 0.5) + 2;
+        if((x1 - x0 + 1) * (y1 - y0 + 1) > 65536) continue;  // footprint too large to scan: leave unknown
+        int lo = 255, hi = 0;
+        for(long long y = y0; y <= y1; y++) {
+          const int yy = wrapTexel(int(y), a.h, a.wrapT);
+          for(long long x = x0; x <= x1; x++) {
+            const int t = (*alpha)[size_t(yy) * a.w + wrapTexel(int(x), a.w, a.wrapS)];
+            lo = std::min(lo, t); hi = std::max(hi, t);
+          }
+        }
+        amin = lo / 255.0; amax = hi / 255.0;
+      }
+      const double omin = double(a.baseAlpha) * amin, omax = double(a.baseAlpha) * amax;
+      uint32_t state = 0;
+      if(a.baseAlpha >= 0.f) {
+        if(mask) {
+          if(omin > double(a.cutoff) + 1e-4) state = 1;        // opacity 1 everywhere: rand > 1 never
+          else if(omax < double(a.cutoff) - 1e-4) state = 2;   // opacity 0 everywhere
+        } else {
+          if(omin >= 1.0 + 1e-4) state = 1;                    // blend: rand in [0,1) never exceeds opacity >= 1
+          else if(omax <= 0.0) state = 2;                      // exactly zero alpha
+        }
+      }
+      const int cell = j * 8 + i;
+      omm[cell >> 4] |= state << ((cell & 15) * 2);
+    }
+}
 
 static int fail(rt_ctx* c, int code, const char* msg) { c->err = msg; return code; }
 
@@ -190,6 +249,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
   if(!d->puncLights) c->ds.lightInfo.puncLightSize = 0;
   if(!d->trigLights) c->ds.lightInfo.trigLightSize = 0;
   // textures (BGRA8, LOD 0)
+  c->hostAlpha.clear();
   std::vector<DevTexture> texs(std::max<uint32_t>(d->numTextures, 1));
   static const uint8_t white[4] = {255, 255, 255, 255};
   for(uint32_t i = 0; i < uint32_t(texs.size()); i++) {
@@ -198,6 +258,8 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
     const uint8_t* dp = nullptr;
     if((rc = upload(c, c->sceneAllocs, t.bgra8, size_t(t.width) * t.height * 4, &dp))) return rc;
     texs[i] = DevTexture{dp, t.width, t.height, t.wrapS, t.wrapT, t.magFilter, 0};
+    c->hostAlpha.emplace_back(size_t(t.width) * t.height);
+    for(size_t k = 0; k < c->hostAlpha.back().size(); k++) c->hostAlpha.back()[k] = t.bgra8[k * 4 + 3];
   }
   if((rc = upload(c, c->sceneAllocs, texs.data(), texs.size(), &c->ds.textures))) return rc;
   c->devTextures = texs;
@@ -242,6 +304,7 @@ int rt_build_accel(rt_ctx* c)
   if(bo.maxDepth > STACK_MAX) return fail(c, RT_ERR_INVALID_ARG, "rt_build_accel: BVH8 deeper than the traversal stack");
   // alpha records for the triangles that go through HitTest (instances without FORCE_OPAQUE)
   std::vector<AlphaRec> alpha(1, AlphaRec{});
+  std::map<std::array<uint32_t, 12>, std::array<uint32_t, 4>> ommCache;
   for(Tri48& T : bo.tris) {
     if(T.flags & TRI_OPAQUE) continue;
     const TriRef ref = bo.triRef[T.globalId];
@@ -258,6 +321,18 @@ int rt_build_accel(rt_ctx* c)
     }
     T.alphaIdx = uint32_t(alpha.size());
     alpha.push_back(a);
+    // opacity micro-map, cached per distinct (texture, uv triple, alpha parameters)
+    std::array<uint32_t, 12> key{};
+    memcpy(key.data(), &a.uv0x, 8 * sizeof(float));
+    key[8] = uint32_t(m.pbrBaseColorTexture); key[9] = uint32_t(a.alphaMode); key[10] = uint32_t(a.wrapS) ^ (uint32_t(a.wrapT) << 16); key[11] = uint32_t(a.filter);
+    auto it = ommCache.find(key);
+    if(it == ommCache.end()) {
+      std::array<uint32_t, 4> o{};
+      const std::vector<uint8_t>* al = (a.bgra && size_t(m.pbrBaseColorTexture) < c->hostAlpha.size()) ? &c->hostAlpha[size_t(m.pbrBaseColorTexture)] : nullptr;
+      buildOpacityMap(a, al, o.data());
+      it = ommCache.emplace(key, o).first;
+    }
+    memcpy(T.omm, it->second.data(), sizeof(T.omm));
   }
   int rc;
   if((rc = upload(c, c->accelAllocs, alpha.data(), alpha.size(), &c->ds.alphaRec))) return rc;

@@ -123,9 +123,10 @@ __global__ __launch_bounds__(64) void k_trace_p(DevScene S, DevFrame F, rt_state
       }
     }
     if(__ballot(live ? 1 : 0) == 0ull) { if(exhausted) break; else continue; }
-    if(live) {
-      live = travStep<ANY>(S, T, stack, tc);
-      if(!live) { if(ANY) occOut[outIdx] = T.found ? 1u : 0u; else hitOut[outIdx] = make_float4(T.hit.t, rt_u2f(T.hit.gid), T.hit.u, T.hit.v); }
+    {
+      const bool was = live;
+      live = travRound<ANY>(S, T, live, stack, tc);
+      if(was && !live) { if(ANY) occOut[outIdx] = T.found ? 1u : 0u; else hitOut[outIdx] = make_float4(T.hit.t, rt_u2f(T.hit.gid), T.hit.u, T.hit.v); }
     }
   }
   if(F.counters) {
@@ -564,21 +565,6 @@ hipError_t launchStageWavefront(hipStream_t stream, const DevScene& S, const Dev
   static const int wavesPerCU = getenv("RESTIR_WAVES_PER_CU") ? atoi(getenv("RESTIR_WAVES_PER_CU")) : 16;
   const dim3 pgrid(unsigned(std::min<long long>(256ll * wavesPerCU, (long long)cap)));
   uint32_t* heads = F.qcount + 128;
-  if(getenv("RESTIR_DEBUG_OCC")) {
-    static bool once = false;
-    if(!once) {
-      once = true;
-      int nb = 0;
-      for(size_t l : {size_t(0), size_t(1024), lds, size_t(16384), size_t(65536)}) {
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_primary, 64, l);
-        fprintf(stderr, "[occ] k_primary block 64 lds %zu -> %d blocks/CU\n", l, nb);
-      }
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_direct_shade, 64, 0);
-      fprintf(stderr, "[occ] k_direct_shade -> %d blocks/CU\n", nb);
-      hipFuncAttributes fa; hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_primary));
-      fprintf(stderr, "[occ] k_primary regs %d shared %zu local %zu maxThreads %d\n", fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes, fa.maxThreadsPerBlock);
-    }
-  }
   hipError_t e = hipMemsetAsync(F.qcount, 0, 256 * sizeof(uint32_t), stream);
   if(e != hipSuccess) return e;
   if(isDirect) {
