@@ -73,6 +73,8 @@ struct DevFrame {
   float4* shadowO; float4* shadowD; uint32_t* occ; uint32_t* status; uint32_t* shadowQ;
   PathRec* path; float4* rayCO; float4* rayCD; float4* hitC; float4* rayAO; float4* rayAD; uint32_t* occH;
   uint32_t* qC[2]; uint32_t* qA; uint32_t* qcount;
+  // A-Trous geometry decoded once per frame: (normal.xyz, matHash bits) and (world position.xyz, 0); full-res and half-res grids
+  float4* geomN; float4* geomP; float4* geomNh; float4* geomPh;
   int32_t W, H;
 };
 

@@ -39,7 +39,7 @@ struct rt_ctx {
   // wavefront scratch
   std::vector<void*> scratchAllocs;
   DevFrame scratch{};
-  int pipeline = 1;  // 1 = wavefront (default), 0 = fused stage kernels
+  int pipeline = 0;  // 0 = one fused kernel per reference stage (default, fastest measured), 1 = wavefront
   bool counting = false;
   unsigned long long* dCounters = nullptr;
   // timing: per frame one event set; event 0 = frame start, event k = end of launch k.  Sets are harvested lazily.
@@ -178,7 +178,7 @@ int rt_create(rt_ctx** out, int device)
   c->device = device;
   if(hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) != hipSuccess) { g_createErr = "rt_create: hipStreamCreate failed"; delete c; return RT_ERR_HIP; }
   c->stream = c->ownStream;
-  if(const char* e = getenv("RESTIR_PIPELINE")) c->pipeline = (strcmp(e, "fused") == 0) ? 0 : 1;
+  if(const char* e = getenv("RESTIR_PIPELINE")) c->pipeline = (strcmp(e, "wavefront") == 0) ? 1 : 0;
   if(hipMalloc(reinterpret_cast<void**>(&c->dCounters), 8 * sizeof(unsigned long long)) != hipSuccess) { g_createErr = "rt_create: hipMalloc failed"; delete c; return RT_ERR_OOM; }
   (void)hipMemset(c->dCounters, 0, 8 * sizeof(unsigned long long));
   *out = c;
@@ -381,6 +381,7 @@ int rt_resize(rt_ctx* c, int w, int h)
   RT_SCRATCH(path, nh, PathRec); RT_SCRATCH(rayCO, nh, float4); RT_SCRATCH(rayCD, nh, float4); RT_SCRATCH(hitC, nh, float4);
   RT_SCRATCH(rayAO, nh, float4); RT_SCRATCH(rayAD, nh, float4); RT_SCRATCH(occH, nh, uint32_t);
   RT_SCRATCH(qC[0], nh, uint32_t); RT_SCRATCH(qC[1], nh, uint32_t); RT_SCRATCH(qA, nh, uint32_t); RT_SCRATCH(qcount, 256, uint32_t);
+  RT_SCRATCH(geomN, n, float4); RT_SCRATCH(geomP, n, float4); RT_SCRATCH(geomNh, nh, float4); RT_SCRATCH(geomPh, nh, float4);
 #undef RT_SCRATCH
   RT_HIP(c, hipDeviceSynchronize());  // memsets above ran on the null stream; the ctx stream does not wait for it implicitly
   c->W = w; c->H = h;
@@ -415,6 +416,7 @@ static DevFrame makeFrame(rt_ctx* c, int frames)
   F.hitRec = X.hitRec; F.surf = X.surf; F.cand = X.cand; F.candLid = X.candLid; F.shadowO = X.shadowO; F.shadowD = X.shadowD; F.occ = X.occ;
   F.status = X.status; F.shadowQ = X.shadowQ; F.path = X.path; F.rayCO = X.rayCO; F.rayCD = X.rayCD; F.hitC = X.hitC; F.rayAO = X.rayAO;
   F.rayAD = X.rayAD; F.occH = X.occH; F.qC[0] = X.qC[0]; F.qC[1] = X.qC[1]; F.qA = X.qA; F.qcount = X.qcount;
+  F.geomN = X.geomN; F.geomP = X.geomP; F.geomNh = X.geomNh; F.geomPh = X.geomPh;
   return F;
 }
 

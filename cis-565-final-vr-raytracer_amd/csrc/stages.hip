@@ -11,6 +11,7 @@
 // an XCD-aware tile order: consecutive workgroup ids land on different XCDs (observed b % 8), so XCD x gets the x-th
 // contiguous band of tile rows and its private 4 MiB L2 sees one compact screen region + the BVH subtrees under it.
 #include "stage_common.h"
+#include <algorithm>
 
 namespace rt {
 
@@ -330,9 +331,29 @@ RT_DEV f3 cameraPosDenoise(const rt_scene_camera& cam, i2 coord, float dist, i2 
   return xyz(origin) + xyz(direction) * dist;
 }
 
+// loadThisGeometry (denoise_common.glsl:42-55) hoisted out of the 25-tap loop: every pixel's normal, material hash and
+// reconstructed position are decoded once per frame instead of once per tap per level (the reference re-derives them
+// 25 x 9 times per pixel: 2 mat-vec + 2 normalisations each).  Same expressions => same bits.
 template <bool IND>
-__global__ __launch_bounds__(64) void k_denoise(DevFrame F, rt_state st, rt_scene_camera cam, const float4* src, float4* dst, int level, int rowBegin, int rowEnd,
-                                                int tilesX, int tilesY)
+__global__ __launch_bounds__(64) void k_denoise_geom(DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY)
+{
+  const TileCoord tile = tileOf(tilesX, tilesY);
+  if(!tile.valid) return;
+  const int lane = int(threadIdx.x);
+  const i2 bound = IND ? i2{st.size.x / 2, st.size.y / 2} : i2{st.size.x, st.size.y};
+  const i2 coord{tile.x * 8 + (lane & 7), rowBegin + tile.y * 8 + (lane >> 3)};
+  if(coord.x >= bound.x || coord.y >= bound.y || coord.y >= rowEnd) return;
+  const i2 gc = IND ? i2{coord.x * 2, coord.y * 2} : coord;
+  const uint4 g = loadG(F.thisG, F, gc);
+  const f3 norm = decompress_unit_vec(g.y);
+  const f3 pos = cameraPosDenoise(cam, gc, rt_u2f(g.x), bound);
+  const size_t idx = size_t(coord.y) * bound.x + coord.x;
+  (IND ? F.geomNh : F.geomN)[idx] = make_float4(norm.x, norm.y, norm.z, rt_u2f(g.w & 0xFF000000u));
+  (IND ? F.geomPh : F.geomP)[idx] = make_float4(pos.x, pos.y, pos.z, 0.f);
+}
+
+template <bool IND>
+__global__ __launch_bounds__(64) void k_denoise(DevFrame F, rt_state st, const float4* src, float4* dst, int level, int rowBegin, int rowEnd, int tilesX, int tilesY)
 {
   const TileCoord tile = tileOf(tilesX, tilesY);
   if(!tile.valid) return;
@@ -344,12 +365,13 @@ __global__ __launch_bounds__(64) void k_denoise(DevFrame F, rt_state st, rt_scen
   const float sigNormal = IND ? st.sigNormalIndirect : st.sigNormalDirect;
   const float sigDepth = IND ? st.sigDepthIndirect : st.sigDepthDirect;
   const int last = IND ? 4 : 3;
+  const float4* gN = IND ? F.geomNh : F.geomN;
+  const float4* gP = IND ? F.geomPh : F.geomP;
 
-  const i2 gc = IND ? i2{coord.x * 2, coord.y * 2} : coord;
-  const uint4 g = loadG(F.thisG, F, gc);
-  const f3 norm = decompress_unit_vec(g.y);
-  const f3 pos = cameraPosDenoise(cam, gc, rt_u2f(g.x), bound);
-  const uint32_t matHash = g.w & 0xFF000000u;
+  const size_t ci = size_t(coord.y) * bound.x + coord.x;
+  const float4 cN = gN[ci], cP = gP[ci];
+  const f3 norm = mk3(cN.x, cN.y, cN.z), pos = mk3(cP.x, cP.y, cP.z);
+  const uint32_t matHash = rt_f2u(cN.w);
 
   f3 res = mk3(0.0f);
   if(matHash != RT_INVALID_MAT_ID) {  // waveletFilter, denoise_direct.comp:19-71 / denoise_indirect.comp:23-75
@@ -361,12 +383,12 @@ __global__ __launch_bounds__(64) void k_denoise(DevFrame F, rt_state st, rt_scen
       for(int i = -2; i <= 2; i++) {
         const i2 q{coord.x + i * step, coord.y + j * step};
         if(q.x >= bound.x || q.y >= bound.y || q.x < 0 || q.y < 0) continue;
-        const i2 gq = IND ? i2{q.x * 2, q.y * 2} : q;
-        const uint4 gQ = loadG(F.thisG, F, gq);
-        const uint32_t matHashQ = gQ.w & 0xFF000000u;
+        const size_t qi = size_t(q.y) * bound.x + q.x;
+        const float4 qN = gN[qi];
+        const uint32_t matHashQ = rt_f2u(qN.w);
         if(matHash != matHashQ || matHashQ == RT_INVALID_MAT_ID) continue;
-        const f3 normQ = decompress_unit_vec(gQ.y);
-        const f3 posQ = cameraPosDenoise(cam, gq, rt_u2f(gQ.x), bound);
+        const float4 qP = gP[qi];
+        const f3 normQ = mk3(qN.x, qN.y, qN.z), posQ = mk3(qP.x, qP.y, qP.z);
         const f3 colorQ = xyz(loadImg(src, F, q));
         const float distColor = IND ? dot(color - colorQ, color - colorQ) : rt_abs(luminance(color) - luminance(colorQ));
         const float wColor = rt_exp(-distColor / sigLumin) + 1e-2f;
@@ -434,7 +456,12 @@ hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F,
       const float4* src[4] = {F.thisDirectResult, F.denoiseDirA, F.denoiseDirB, F.denoiseDirA};
       float4* dst[4] = {F.denoiseDirA, F.denoiseDirB, F.denoiseDirA, F.thisDirectResult};
       if(level < 0 || level > 3) return hipErrorInvalidValue;
-      hipLaunchKernelGGL(k_denoise<false>, grid, block, 0, stream, F, st, cam, src[level], dst[level], level, rowBegin, rowEnd, tilesX, tilesY);
+      if(level == 0) {  // decode the band's geometry plus the halo rows the widest level (2*2^3) will tap
+        const int g0 = std::max(0, rowBegin - 16) & ~7, g1 = std::min(gh, rowEnd + 16);
+        const int gty = (g1 - g0 + 7) / 8;
+        hipLaunchKernelGGL(k_denoise_geom<false>, dim3(tileGrid(tilesX, gty)), block, 0, stream, F, st, cam, g0, g1, tilesX, gty);
+      }
+      hipLaunchKernelGGL(k_denoise<false>, grid, block, 0, stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, tilesX, tilesY);
       break;
     }
     case RT_STAGE_DENOISE_INDIRECT: {
@@ -443,7 +470,12 @@ hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F,
       const float4* src[5] = {F.denoiseIndA, F.denoiseIndB, F.denoiseIndA, F.thisIndirectResult, F.denoiseIndA};
       float4* dst[5] = {F.denoiseIndB, F.denoiseIndA, F.thisIndirectResult, F.denoiseIndA, F.denoiseIndB};
       if(level < 0 || level > 4) return hipErrorInvalidValue;
-      hipLaunchKernelGGL(k_denoise<true>, grid, block, 0, stream, F, st, cam, src[level], dst[level], level, rowBegin, rowEnd, tilesX, tilesY);
+      if(level == 0) {  // halo = 2*2^4 half-res rows
+        const int g0 = std::max(0, rowBegin - 32) & ~7, g1 = std::min(gh, rowEnd + 32);
+        const int gty = (g1 - g0 + 7) / 8;
+        hipLaunchKernelGGL(k_denoise_geom<true>, dim3(tileGrid(tilesX, gty)), block, 0, stream, F, st, cam, g0, g1, tilesX, gty);
+      }
+      hipLaunchKernelGGL(k_denoise<true>, grid, block, 0, stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, tilesX, tilesY);
       break;
     }
     case RT_STAGE_COMPOSE: hipLaunchKernelGGL(k_compose, grid, block, 0, stream, F, st, rowBegin, rowEnd, tilesX, tilesY); break;

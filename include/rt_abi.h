@@ -322,9 +322,9 @@ int rt_device_ptr(rt_ctx* ctx, int buffer, void** ptr, size_t* bytes, size_t* ro
  * every counter and accumulated timing. */
 int rt_set_counting(rt_ctx* ctx, int enable);
 int rt_get_counters(rt_ctx* ctx, rt_counters* out);
-/* Kernel organisation of the direct / indirect stages: 1 = wavefront (default: lean trace kernels + shading kernels with
- * ray compaction), 0 = one fused kernel per reference stage.  Outputs are bit-identical; this is an A/B performance switch
- * (also settable with the environment variable RESTIR_PIPELINE=fused|wavefront before rt_create). */
+/* Kernel organisation of the direct / indirect stages: 0 = one fused kernel per reference stage (default, the fastest
+ * measured), 1 = wavefront (lean trace kernels + shading kernels with ray compaction).  Outputs are bit-identical; this is
+ * an A/B performance switch (also settable with the environment variable RESTIR_PIPELINE=fused|wavefront before rt_create). */
 int rt_set_pipeline(rt_ctx* ctx, int pipeline);
 /* Wait for all work on the ctx stream. */
 int rt_sync(rt_ctx* ctx);
