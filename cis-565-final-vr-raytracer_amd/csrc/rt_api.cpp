@@ -20,6 +20,9 @@ using namespace rt;
 struct rt_ctx {
   int device = 0;
   hipStream_t ownStream = nullptr, stream = nullptr;
+  hipStream_t sideStream = nullptr;           // direct A-Trous runs here, concurrently with the indirect stage
+  hipEvent_t evFork = nullptr, evJoin = nullptr;
+  int overlap = 1;
   std::string err;
   // host copy of the scene (rt_build_accel runs after rt_upload_scene returns; the caller keeps ownership of its arrays)
   std::vector<rt_prim_mesh> primMeshes; std::vector<rt_vertex> vertices; std::vector<uint32_t> indices; std::vector<rt_instance> instances;
@@ -43,8 +46,8 @@ struct rt_ctx {
   bool counting = false;
   unsigned long long* dCounters = nullptr;
   // timing: per frame one event set; event 0 = frame start, event k = end of launch k.  Sets are harvested lazily.
-  static constexpr int MAX_EV = 16, MAX_SETS = 1024;
-  struct EvSet { hipEvent_t ev[MAX_EV]; int stage[MAX_EV]; int count; };
+  static constexpr int MAX_EV = 20, MAX_SETS = 1024;
+  struct EvSet { hipEvent_t ev[MAX_EV]; int stage[MAX_EV]; int prev[MAX_EV]; int count; int last; };
   std::vector<EvSet> evSets;
   size_t evUsed = 0;
   double accStage[RT_STAGE_COUNT] = {}; double accFrame = 0; uint32_t accFrames = 0;
@@ -56,10 +59,10 @@ static void harvestTimings(rt_ctx* c)
     rt_ctx::EvSet& E = c->evSets[s];
     for(int k = 1; k < E.count; k++) {
       float ms = 0.f;
-      if(hipEventElapsedTime(&ms, E.ev[k - 1], E.ev[k]) == hipSuccess && E.stage[k] >= 0) c->accStage[E.stage[k]] += ms;
+      if(E.stage[k] >= 0 && hipEventElapsedTime(&ms, E.ev[E.prev[k]], E.ev[k]) == hipSuccess) c->accStage[E.stage[k]] += ms;
     }
     float ms = 0.f;
-    if(E.count > 1 && hipEventElapsedTime(&ms, E.ev[0], E.ev[E.count - 1]) == hipSuccess) { c->accFrame += ms; c->accFrames++; }
+    if(E.count > 1 && hipEventElapsedTime(&ms, E.ev[0], E.ev[E.last]) == hipSuccess) { c->accFrame += ms; c->accFrames++; }
   }
   c->evUsed = 0;
 }
@@ -178,6 +181,10 @@ int rt_create(rt_ctx** out, int device)
   c->device = device;
   if(hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) != hipSuccess) { g_createErr = "rt_create: hipStreamCreate failed"; delete c; return RT_ERR_HIP; }
   c->stream = c->ownStream;
+  (void)hipStreamCreateWithFlags(&c->sideStream, hipStreamNonBlocking);
+  (void)hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming);
+  (void)hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming);
+  if(const char* e = getenv("RESTIR_OVERLAP")) c->overlap = atoi(e);
   if(const char* e = getenv("RESTIR_PIPELINE")) c->pipeline = (strcmp(e, "wavefront") == 0) ? 1 : 0;
   if(hipMalloc(reinterpret_cast<void**>(&c->dCounters), 8 * sizeof(unsigned long long)) != hipSuccess) { g_createErr = "rt_create: hipMalloc failed"; delete c; return RT_ERR_OOM; }
   (void)hipMemset(c->dCounters, 0, 8 * sizeof(unsigned long long));
@@ -195,6 +202,9 @@ int rt_destroy(rt_ctx* c)
   if(c->dCounters) (void)hipFree(c->dCounters);
   for(auto& E : c->evSets) for(int i = 0; i < rt_ctx::MAX_EV; i++) (void)hipEventDestroy(E.ev[i]);
   if(c->ownStream) (void)hipStreamDestroy(c->ownStream);
+  if(c->sideStream) (void)hipStreamDestroy(c->sideStream);
+  if(c->evFork) (void)hipEventDestroy(c->evFork);
+  if(c->evJoin) (void)hipEventDestroy(c->evJoin);
   delete c;
   return RT_OK;
 }
@@ -454,26 +464,40 @@ int rt_render_frame(rt_ctx* c, const rt_state* st, int frames)
     c->evSets.push_back(E);
   }
   rt_ctx::EvSet& E = c->evSets[c->evUsed];
-  int k = 0;
+  int k = 0, lastMain = 0, lastSide = 0;
   RT_HIP(c, hipEventRecord(E.ev[k], c->stream));
-  E.stage[k++] = -1;
-  auto run = [&](int stage, int level) -> int {
-    hipError_t e = (c->pipeline ? launchStageWavefront : launchStage)(c->stream, c->ds, F, *st, c->cam, stage, level, 0, 0);
+  E.stage[k] = -1; E.prev[k] = 0; k++;
+  auto run = [&](hipStream_t strm, int stage, int level, bool stamp) -> int {
+    hipError_t e = (c->pipeline ? launchStageWavefront : launchStage)(strm, c->ds, F, *st, c->cam, stage, level, 0, 0);
     if(e != hipSuccess) { c->err = std::string("launchStage: ") + hipGetErrorString(e); return RT_ERR_HIP; }
-    e = hipEventRecord(E.ev[k], c->stream);
+    (void)stamp;
+    e = hipEventRecord(E.ev[k], strm);
     if(e != hipSuccess) { c->err = std::string("hipEventRecord: ") + hipGetErrorString(e); return RT_ERR_HIP; }
-    E.stage[k++] = stage;
+    int& last = (strm == c->stream) ? lastMain : lastSide;
+    E.stage[k] = stage; E.prev[k] = last; last = k; k++;
     return RT_OK;
   };
-  // Renderer::run, renderer.cpp:163-205
-  if((rc = run(RT_STAGE_DIRECT, 0))) return rc;
-  if((rc = run(RT_STAGE_INDIRECT, 0))) return rc;
-  if(st->denoise > 0) {
-    for(int i = 0; i < 4; i++) if((rc = run(RT_STAGE_DENOISE_DIRECT, i))) return rc;
-    for(int i = 0; i < 5; i++) if((rc = run(RT_STAGE_DENOISE_INDIRECT, i))) return rc;
+  // Renderer::run, renderer.cpp:163-205.  The direct A-Trous chain only depends on the direct stage and the indirect stage
+  // + its A-Trous chain only on the G-buffer, so the two chains run on two streams and join before compose: the direct
+  // filter (ALU bound, full occupancy) fills the CUs that the indirect stage's long tail of multi-bounce tiles leaves idle.
+  const bool fork = c->overlap && st->denoise > 0 && c->sideStream;
+  if((rc = run(c->stream, RT_STAGE_DIRECT, 0, true))) return rc;
+  if(fork) {
+    RT_HIP(c, hipEventRecord(c->evFork, c->stream));
+    RT_HIP(c, hipStreamWaitEvent(c->sideStream, c->evFork, 0));
+    RT_HIP(c, hipEventRecord(E.ev[k], c->sideStream));
+    E.stage[k] = -1; E.prev[k] = k; lastSide = k; k++;
+    for(int i = 0; i < 4; i++) if((rc = run(c->sideStream, RT_STAGE_DENOISE_DIRECT, i, false))) return rc;
+    RT_HIP(c, hipEventRecord(c->evJoin, c->sideStream));
   }
-  if((rc = run(RT_STAGE_COMPOSE, 0))) return rc;
-  E.count = k;
+  if((rc = run(c->stream, RT_STAGE_INDIRECT, 0, true))) return rc;
+  if(st->denoise > 0) {
+    if(!fork) for(int i = 0; i < 4; i++) if((rc = run(c->stream, RT_STAGE_DENOISE_DIRECT, i, true))) return rc;
+    for(int i = 0; i < 5; i++) if((rc = run(c->stream, RT_STAGE_DENOISE_INDIRECT, i, true))) return rc;
+  }
+  if(fork) RT_HIP(c, hipStreamWaitEvent(c->stream, c->evJoin, 0));
+  if((rc = run(c->stream, RT_STAGE_COMPOSE, 0, true))) return rc;
+  E.count = k; E.last = lastMain;
   c->evUsed++;
   return RT_OK;
 }
