@@ -392,6 +392,7 @@ int rt_resize(rt_ctx* c, int w, int h)
   RT_SCRATCH(rayAO, nh, float4); RT_SCRATCH(rayAD, nh, float4); RT_SCRATCH(occH, nh, uint32_t);
   RT_SCRATCH(qC[0], nh, uint32_t); RT_SCRATCH(qC[1], nh, uint32_t); RT_SCRATCH(qA, nh, uint32_t); RT_SCRATCH(qcount, 256, uint32_t);
   RT_SCRATCH(geomN, n, float4); RT_SCRATCH(geomP, n, float4); RT_SCRATCH(geomNh, nh, float4); RT_SCRATCH(geomPh, nh, float4);
+  RT_SCRATCH(tileOrder, (size_t(w / 2 + 7) / 8) * (size_t(h / 2 + 7) / 8 + 16 * 2) + 64, uint32_t);
 #undef RT_SCRATCH
   RT_HIP(c, hipDeviceSynchronize());  // memsets above ran on the null stream; the ctx stream does not wait for it implicitly
   c->W = w; c->H = h;
@@ -426,7 +427,7 @@ static DevFrame makeFrame(rt_ctx* c, int frames)
   F.hitRec = X.hitRec; F.surf = X.surf; F.cand = X.cand; F.candLid = X.candLid; F.shadowO = X.shadowO; F.shadowD = X.shadowD; F.occ = X.occ;
   F.status = X.status; F.shadowQ = X.shadowQ; F.path = X.path; F.rayCO = X.rayCO; F.rayCD = X.rayCD; F.hitC = X.hitC; F.rayAO = X.rayAO;
   F.rayAD = X.rayAD; F.occH = X.occH; F.qC[0] = X.qC[0]; F.qC[1] = X.qC[1]; F.qA = X.qA; F.qcount = X.qcount;
-  F.geomN = X.geomN; F.geomP = X.geomP; F.geomNh = X.geomNh; F.geomPh = X.geomPh;
+  F.geomN = X.geomN; F.geomP = X.geomP; F.geomNh = X.geomNh; F.geomPh = X.geomPh; F.tileOrder = X.tileOrder;
   return F;
 }
 

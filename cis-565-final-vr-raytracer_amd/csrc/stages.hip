@@ -166,10 +166,36 @@ __global__ __launch_bounds__(64) void k_direct_reuse(DevScene S, DevFrame F, rt_
 // ------------------------------------------------------------------------------------------------------------
 // indirect_stage.comp
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_indirect_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY)
+// Longest-first tile order for the indirect stage: the 25 % multi-bounce tiles (indirect_stage.comp:283-288) run up to
+// maxDepth bounces while the rest stop after one, so they are dispatched first and the short tiles fill the tail.
+// One thread per tile recomputes the tile flag exactly as the stage does and appends the tile to its XCD's list
+// (multi-bounce from the front, single-bounce from the back).  Only the order changes, never a result.
+__global__ void k_ind_tile_order(rt_state st, int rowBegin, int tilesX, int tilesY, int cap, uint32_t* lists, uint32_t* counts)
+{
+  const int t = int(blockIdx.x * blockDim.x + threadIdx.x);
+  if(t >= tilesX * tilesY) return;
+  const int ty = t / tilesX, tx = t - ty * tilesX;
+  const int indW = st.size.x / 2;
+  uint32_t seed = tea(uint32_t(indW) * uint32_t(rowBegin + ty * 8) + uint32_t(tx * 8), st.time);
+  const bool mb = rnd(seed) < 0.25f;
+  const int xcd = (ty / TILE_STRIPE) & 7;
+  uint32_t* list = lists + size_t(xcd) * cap;
+  if(mb) list[atomicAdd(&counts[xcd * 2], 1u)] = uint32_t(t);
+  else list[cap - 1 - int(atomicAdd(&counts[xcd * 2 + 1], 1u))] = uint32_t(t);
+}
+
+__global__ __launch_bounds__(64, 4) void k_indirect_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY, int cap,
+                                                          const uint32_t* lists, const uint32_t* counts)
 {
   extern __shared__ uint2 s_stack[];
-  const TileCoord tile = tileOf(tilesX, tilesY);
+  TileCoord tile;
+  {
+    const int L = int(blockIdx.x), xcd = L & 7, k = L >> 3;
+    const int nf = int(counts[xcd * 2]), nb = int(counts[xcd * 2 + 1]);
+    tile.valid = k < nf + nb;
+    const uint32_t t = tile.valid ? lists[size_t(xcd) * cap + (k < nf ? k : cap - 1 - (k - nf))] : 0u;
+    tile.y = int(t) / tilesX; tile.x = int(t) - tile.y * tilesX;
+  }
   if(!tile.valid) return;
   const int lane = int(threadIdx.x);
   const i2 indSize{st.size.x / 2, st.size.y / 2};
@@ -450,7 +476,16 @@ hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F,
     case RT_STAGE_DIRECT: hipLaunchKernelGGL(k_direct_stage, grid, block, lds, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY); break;
     case RT_STAGE_DIRECT_GEN: hipLaunchKernelGGL(k_direct_gen, grid, block, lds, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY); break;
     case RT_STAGE_DIRECT_REUSE: hipLaunchKernelGGL(k_direct_reuse, grid, block, 0, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY); break;
-    case RT_STAGE_INDIRECT: hipLaunchKernelGGL(k_indirect_stage, grid, block, lds, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY); break;
+    case RT_STAGE_INDIRECT: {
+      // per-XCD tile lists: capacity = the tiles one XCD can own under the striped mapping
+      const int cap = int(tileGrid(tilesX, tilesY) / 8);
+      hipError_t e = hipMemsetAsync(F.qcount + 192, 0, 16 * sizeof(uint32_t), stream);
+      if(e != hipSuccess) return e;
+      hipLaunchKernelGGL(k_ind_tile_order, dim3(unsigned((nTiles + 255) / 256)), dim3(256), 0, stream, st, rowBegin, tilesX, tilesY, cap, F.tileOrder, F.qcount + 192);
+      hipLaunchKernelGGL(k_indirect_stage, grid, block, lds, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY, cap, (const uint32_t*)F.tileOrder,
+                         (const uint32_t*)(F.qcount + 192));
+      break;
+    }
     case RT_STAGE_DENOISE_DIRECT: {
       // DirectResult -> DirA -> DirB -> DirA -> DirectResult (denoise_direct.comp:152-172)
       const float4* src[4] = {F.thisDirectResult, F.denoiseDirA, F.denoiseDirB, F.denoiseDirA};

@@ -9,7 +9,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB_PATH = os.path.join(_HERE, "csrc", "librestir_hip.so")
+HIP_LIB_PATH = os.environ.get("RESTIR_HIP_LIB") or os.path.join(_HERE, "csrc", "librestir_hip.so")  # env override: A/B builds
 _lib = None
 
 # every symbol include/rt_abi.h declares (tests check that the library exports all of them)
