@@ -23,6 +23,14 @@ def hip_lib():
     if _lib is None:
         if not os.path.exists(HIP_LIB_PATH):
             raise RuntimeError(f"{HIP_LIB_PATH} is missing — build it with __graft_entry__.build(); this package has no fallback path")
+        # PyTorch-ROCm wheels bundle their own HIP runtime (torch/lib/libamdhip64.so, same SONAME as /opt/rocm's).  If torch
+        # is loaded first, librestir_hip.so binds to that one runtime and streams / device pointers can be shared with
+        # torch.distributed (RCCL).  Loaded the other way round the process ends up with two HIP runtimes and torch then
+        # reports "No HIP GPUs are available".  So: when torch is installed, load it first.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         L = C.CDLL(HIP_LIB_PATH)
         L.rt_last_error.restype = C.c_char_p
         L.rt_last_error.argtypes = [C.c_void_p]

@@ -127,3 +127,40 @@ def test_tiled_three_ranks_equals_untiled(bistro):
         want = ref.readback(b)
         for rank in range(world):
             assert np.array_equal(rs[rank].readback(b), want), (abi.BUFFER_NAMES[b], rank)
+
+
+def test_nccl_single_rank_collectives_on_ctx_buffers():
+    """The RCCL code path of restir_amd/tiled.py with world_size 1: in-place all-gathers on the ctx-owned HBM buffers wrapped
+    as torch tensors, kernels on torch's current stream.  (Multi-rank logic is covered by tests/test_tiled_gloo.py.)"""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from restir_amd import tiled
+    from restir_amd.renderer import Renderer
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        Ws, Hs = 256, 144
+        sc, env = make_scene(abi.PROC_SPONZA, 0.01, 1, (128, 64))
+        st = host.default_state(Ws, Hs, sc, env)
+        outs = []
+        for tiled_mode in (False, True):
+            r = Renderer().setup(0); r.load_scene(sc.desc(env)); r.update(Ws, Hs)
+            r.set_stream(torch.cuda.current_stream().cuda_stream)
+            fr = tiled.TiledFrame(tiled.RendererTensors(r), tiled.TorchComm(), Ws, Hs) if tiled_mode else None
+            s2, _ = make_scene(abi.PROC_SPONZA, 0.01, 1, None)
+            s2.updateCamera(Ws, Hs)
+            for f in range(3):
+                st.time = 321 + f; s2.updateCamera(Ws, Hs); r.set_camera(s2.getCamera())
+                if fr is None: r.run(st, f)
+                else: fr.render_frame(st, f)
+            if fr is not None: fr.finish()
+            torch.cuda.synchronize()
+            outs.append([r.readback(b) for b in frame_buffers(2)])
+        for a, b in zip(*outs):
+            assert np.array_equal(a, b)
+    finally:
+        dist.destroy_process_group()
