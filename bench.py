@@ -75,7 +75,11 @@ def main():
     r.load_scene(desc)
     build_s = time.time() - t0
     r.update(W, H)
-    r.set_stream(torch.cuda.current_stream().cuda_stream)  # kernels and RCCL ops are ordered by torch's stream semantics
+    # kernels and RCCL ops share one HIP runtime (torch's) and one stream: ordered by torch's stream semantics, no host syncs
+    stream = torch.cuda.Stream() if world > 1 else None
+    if stream is not None:
+        torch.cuda.set_stream(stream)
+        r.set_stream(stream.cuda_stream)
     comm = tiled.TorchComm() if world > 1 else tiled.LocalComm()
     frame = tiled.TiledFrame(tiled.RendererTensors(r), comm, W, H) if world > 1 else None
 

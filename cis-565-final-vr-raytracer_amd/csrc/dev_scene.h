@@ -77,6 +77,11 @@ struct DevFrame {
   float4* geomN; float4* geomP; float4* geomNh; float4* geomPh;
   uint32_t* tileOrder;              // 8 per-XCD lists of half-res tile ids, longest (multi-bounce) first
   int32_t W, H;
+  // rows of the LAST-frame buffers that are valid on this GPU (row-tiled multi-GPU: own band + received halos).  A temporal
+  // lookup that lands inside the image but outside [histRow0, histRow1) raises *histMiss so the host can fetch the full
+  // history and redo the frame; single-GPU: [0, H) and the flag never fires.
+  int32_t histRow0, histRow1;
+  uint32_t* histMiss;
 };
 
 }  // namespace rt

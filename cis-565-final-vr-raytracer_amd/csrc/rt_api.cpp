@@ -42,6 +42,7 @@ struct rt_ctx {
   // wavefront scratch
   std::vector<void*> scratchAllocs;
   DevFrame scratch{};
+  int histRow0 = 0, histRow1 = 1 << 30;  // rt_set_history_rows
   int pipeline = 0;  // 0 = one fused kernel per reference stage (default, fastest measured), 1 = wavefront
   bool counting = false;
   unsigned long long* dCounters = nullptr;
@@ -427,6 +428,7 @@ static DevFrame makeFrame(rt_ctx* c, int frames)
   F.hitRec = X.hitRec; F.surf = X.surf; F.cand = X.cand; F.candLid = X.candLid; F.shadowO = X.shadowO; F.shadowD = X.shadowD; F.occ = X.occ;
   F.status = X.status; F.shadowQ = X.shadowQ; F.path = X.path; F.rayCO = X.rayCO; F.rayCD = X.rayCD; F.hitC = X.hitC; F.rayAO = X.rayAO;
   F.rayAD = X.rayAD; F.occH = X.occH; F.qC[0] = X.qC[0]; F.qC[1] = X.qC[1]; F.qA = X.qA; F.qcount = X.qcount;
+  F.histRow0 = c->histRow0; F.histRow1 = c->histRow1; F.histMiss = X.qcount + 250;
   F.geomN = X.geomN; F.geomP = X.geomP; F.geomNh = X.geomNh; F.geomPh = X.geomPh; F.tileOrder = X.tileOrder;
   return F;
 }
@@ -565,6 +567,26 @@ int rt_get_counters(rt_ctx* c, rt_counters* out)
   for(int i = 0; i < RT_STAGE_COUNT; i++) out->stageMs[i] = float(c->accStage[i]);
   out->frameMs = float(c->accFrame);
   out->framesTimed = c->accFrames;
+  return RT_OK;
+}
+
+int rt_set_history_rows(rt_ctx* c, int row0, int row1)
+{
+  if(!c || row0 < 0 || row1 < row0) return RT_ERR_INVALID_ARG;
+  c->histRow0 = row0; c->histRow1 = row1;
+  return RT_OK;
+}
+
+int rt_history_miss(rt_ctx* c, int* missed)
+{
+  if(!c || !missed) return RT_ERR_INVALID_ARG;
+  if(c->W == 0) return fail(c, RT_ERR_NO_TARGET, "rt_history_miss: rt_resize has not been called");
+  RT_HIP(c, hipSetDevice(c->device));
+  uint32_t v = 0;
+  RT_HIP(c, hipMemcpyAsync(&v, c->scratch.qcount + 250, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+  RT_HIP(c, hipMemsetAsync(c->scratch.qcount + 250, 0, sizeof(v), c->stream));
+  RT_HIP(c, hipStreamSynchronize(c->stream));
+  *missed = v ? 1 : 0;
   return RT_OK;
 }
 

@@ -94,6 +94,7 @@ RT_DEV bool findTemporalNeighborDirect(const DevFrame& F, const rt_state& st, f3
 {
   const i2 size{st.size.x, st.size.y};
   if(!inBound(lastCoord, i2{2, 0}, size)) return false;
+  if(lastCoord.y < F.histRow0 || lastCoord.y >= F.histRow1) *F.histMiss = 1u;
   const uint4 g = loadG(F.lastG, F, lastCoord);
   const f3 pnorm = decompress_unit_vec(g.y);
   const float pdepth = rt_u2f(g.x);

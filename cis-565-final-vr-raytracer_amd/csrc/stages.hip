@@ -296,6 +296,7 @@ __global__ __launch_bounds__(64, 4) void k_indirect_stage(DevScene S, DevFrame F
   if(st.ReSTIRState == RT_RESTIR_TEMPORAL || st.ReSTIRState == RT_RESTIR_SPATIOTEMPORAL) {
     const float reprojDepth = length(mk3(cam.lastPosition) - primState.position);
     const i2 motionIdx = loadMotion(F, i2{px.x * 2, px.y * 2});
+    if(motionIdx.x >= 0 && motionIdx.x < F.W && motionIdx.y >= 0 && motionIdx.y < F.H && (motionIdx.y < F.histRow0 || motionIdx.y >= F.histRow1)) *F.histMiss = 1u;
     const uint4 lg = loadG(F.lastG, F, motionIdx);
     const f3 pnorm = decompress_unit_vec(lg.y);
     const float pdepth = rt_u2f(lg.x);

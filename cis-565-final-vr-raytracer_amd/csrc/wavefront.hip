@@ -505,6 +505,7 @@ __global__ __launch_bounds__(64) void k_ind_finish(DevScene S, DevFrame F, rt_st
   if(st.ReSTIRState == RT_RESTIR_TEMPORAL || st.ReSTIRState == RT_RESTIR_SPATIOTEMPORAL) {
     const float reprojDepth = length(mk3(cam.lastPosition) - primState.position);
     const i2 motionIdx = loadMotion(F, i2{px.x * 2, px.y * 2});
+    if(motionIdx.x >= 0 && motionIdx.x < F.W && motionIdx.y >= 0 && motionIdx.y < F.H && (motionIdx.y < F.histRow0 || motionIdx.y >= F.histRow1)) *F.histMiss = 1u;
     const uint4 lg = loadG(F.lastG, F, motionIdx);
     const f3 pnorm = decompress_unit_vec(lg.y);
     const float pdepth = rt_u2f(lg.x);
@@ -565,7 +566,7 @@ hipError_t launchStageWavefront(hipStream_t stream, const DevScene& S, const Dev
   static const int wavesPerCU = getenv("RESTIR_WAVES_PER_CU") ? atoi(getenv("RESTIR_WAVES_PER_CU")) : 16;
   const dim3 pgrid(unsigned(std::min<long long>(256ll * wavesPerCU, (long long)cap)));
   uint32_t* heads = F.qcount + 128;
-  hipError_t e = hipMemsetAsync(F.qcount, 0, 256 * sizeof(uint32_t), stream);
+  hipError_t e = hipMemsetAsync(F.qcount, 0, 192 * sizeof(uint32_t), stream);  // slots 192.. belong to the tile lists / history-miss flag
   if(e != hipSuccess) return e;
   if(isDirect) {
     const int genOnly = stage == RT_STAGE_DIRECT_GEN ? 1 : 0;

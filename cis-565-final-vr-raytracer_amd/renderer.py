@@ -15,7 +15,7 @@ _lib = None
 # every symbol include/rt_abi.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_build_accel", "rt_resize", "rt_set_camera",
                "rt_render_frame", "rt_run_stage", "rt_readback", "rt_upload_history", "rt_buffer_bytes", "rt_device_ptr",
-               "rt_set_counting", "rt_get_counters", "rt_sync", "rt_last_error", "rt_abi_version", "rt_set_pipeline"]
+               "rt_set_counting", "rt_get_counters", "rt_sync", "rt_last_error", "rt_abi_version", "rt_set_pipeline", "rt_set_history_rows", "rt_history_miss"]
 
 
 def hip_lib():
@@ -51,6 +51,8 @@ def hip_lib():
         L.rt_device_ptr.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         L.rt_set_counting.argtypes = [C.c_void_p, C.c_int]
         L.rt_set_pipeline.argtypes = [C.c_void_p, C.c_int]
+        L.rt_set_history_rows.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.rt_history_miss.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.rt_get_counters.argtypes = [C.c_void_p, C.c_void_p]
         L.rt_accel_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
         _lib = L
@@ -149,6 +151,14 @@ class Renderer:
 
     def set_pipeline(self, wavefront=True):
         self._chk(hip_lib().rt_set_pipeline(self._h, 1 if wavefront else 0), "rt_set_pipeline")
+
+    def set_history_rows(self, row0, row1):
+        self._chk(hip_lib().rt_set_history_rows(self._h, row0, row1), "rt_set_history_rows")
+
+    def history_miss(self):
+        m = C.c_int()
+        self._chk(hip_lib().rt_history_miss(self._h, C.byref(m)), "rt_history_miss")
+        return bool(m.value)
 
     def set_counting(self, enable):
         self._chk(hip_lib().rt_set_counting(self._h, 1 if enable else 0), "rt_set_counting")

@@ -322,6 +322,13 @@ int rt_device_ptr(rt_ctx* ctx, int buffer, void** ptr, size_t* bytes, size_t* ro
  * every counter and accumulated timing. */
 int rt_set_counting(rt_ctx* ctx, int enable);
 int rt_get_counters(rt_ctx* ctx, rt_counters* out);
+/* Row-tiled multi-GPU: declare which rows [row0,row1) of the LAST-frame buffers (G-buffer, reservoirs, light ids; full-res
+ * rows, the half-res reservoirs use row/2) hold valid data on this GPU — its own band plus the halo rows received from its
+ * neighbours.  Temporal reuse that reprojects inside the image but outside this range sets a flag instead of silently
+ * reading stale rows; rt_history_miss() returns and clears the flag (synchronises the ctx stream) so the caller can
+ * gather the full history and redo the frame.  Default: every row is valid. */
+int rt_set_history_rows(rt_ctx* ctx, int row0, int row1);
+int rt_history_miss(rt_ctx* ctx, int* missed);
 /* Kernel organisation of the direct / indirect stages: 0 = one fused kernel per reference stage (default, the fastest
  * measured), 1 = wavefront (lean trace kernels + shading kernels with ray compaction).  Outputs are bit-identical; this is
  * an A/B performance switch (also settable with the environment variable RESTIR_PIPELINE=fused|wavefront before rt_create). */

@@ -45,6 +45,8 @@ def lib():
         L.orc_readback.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         L.orc_upload_history.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         L.orc_get_counters.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_set_history_rows.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_history_miss.argtypes = [C.c_void_p]
         L.orc_buffer_ptr.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         for n in ["orc_trace_closest", "orc_trace_any", "orc_trace_closest_brute"]:
             getattr(L, n).argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -82,6 +84,8 @@ class Oracle:
     def upload_history(self, buf, data):
         a = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
         self._chk(lib().orc_upload_history(self._h, buf, a.ctypes.data, a.nbytes), "upload_history")
+    def set_history_rows(self, r0, r1): lib().orc_set_history_rows(self._h, r0, r1)
+    def history_miss(self): return bool(lib().orc_history_miss(self._h))
     def buffer_array(self, buf):
         """(flat uint8 numpy view of the whole allocation incl. slack rows, row pitch in bytes) — zero copy"""
         p, n, pitch = C.c_void_p(), C.c_size_t(), C.c_size_t()

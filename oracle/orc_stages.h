@@ -1,6 +1,7 @@
 // orc_stages.h — CPU oracle frame state (screen-space buffers of renderer.cpp:227-302) and stage entry points.
 // TEST INFRASTRUCTURE, not product code.
 #pragma once
+#include <atomic>
 #include <vector>
 #include "orc_shading.h"
 
@@ -11,6 +12,9 @@ struct Frame {
   rt_scene_camera cam{};
   int W = 0, H = 0;
   int threads = 1;
+  // row-tiled runs: rows of the last-frame buffers valid on this rank; lookups outside raise histMiss (rt_abi.h rt_set_history_rows)
+  int histRow0 = 0, histRow1 = 1 << 30;
+  mutable std::atomic<uint32_t> histMiss{0};
 
   // boundary layouts == reference layouts (rt_abi.h rt_buffer_id)
   std::vector<uint32_t> gbuffer[2];                 // RGBA32UI

@@ -74,16 +74,26 @@ class ThreadComm:
                 tensor[p * chunk_bytes:(p + 1) * chunk_bytes].copy_(self.s["slot"][p][p * chunk_bytes:(p + 1) * chunk_bytes])
         torch.cuda.synchronize(); self.s["barrier"].wait()
         return None
-    def halo_exchange(self, tensor, pitch, y0, y1, halo, H_, B):
+    def halo_exchange(self, items, async_op=False):
         import torch
-        self.s["slot"][self.rank] = tensor
-        self._sync()
-        for p, (a, b) in ((self.rank - 1, (max(0, y0 - halo), y0)), (self.rank + 1, (y1, min(H_, y1 + halo)))):
-            if 0 <= p < self.world and b > a:
-                tensor[a * pitch:b * pitch].copy_(self.s["slot"][p][a * pitch:b * pitch])
-        torch.cuda.synchronize(); self.s["barrier"].wait()
-        return None
+        for (tensor, pitch, y0, y1, halo, H_, B) in items:   # every rank passes the same item list => barriers line up
+            if halo <= 0:
+                continue
+            self.s["slot"][self.rank] = tensor
+            self._sync()
+            if y1 > y0:
+                for p, (a, b) in ((self.rank - 1, (max(0, y0 - halo), y0)), (self.rank + 1, (y1, min(H_, y1 + halo)))):
+                    if 0 <= p < self.world and b > a:
+                        tensor[a * pitch:b * pitch].copy_(self.s["slot"][p][a * pitch:b * pitch])
+            torch.cuda.synchronize(); self.s["barrier"].wait()
+        return []
     def gather_rows_to(self, tensor, chunk_bytes, dst=0, async_op=False): return self.all_gather_rows(tensor, chunk_bytes)
+    def any_flag(self, flag):
+        self.s["flags"][self.rank] = bool(flag)
+        self.s["barrier"].wait()
+        r = any(self.s["flags"])
+        self.s["barrier"].wait()
+        return r
     def wait(self, work): pass
     def barrier(self): self.s["barrier"].wait()
 
@@ -95,7 +105,7 @@ def test_tiled_three_ranks_equals_untiled(bistro):
     world, frames = 3, 2
     ref = _renderer(sc, env)
     rs = [_renderer(sc, env) for _ in range(world)]
-    shared = {"renderers": rs, "barrier": threading.Barrier(world), "slot": [None] * world}
+    shared = {"renderers": rs, "barrier": threading.Barrier(world), "slot": [None] * world, "flags": [False] * world}
     cams = []
     s2, _ = make_scene(abi.PROC_BISTRO_EXT, 1.0, 1, None)
     eye, center, up, fov = s2.cameraPose()
@@ -122,11 +132,17 @@ def test_tiled_three_ranks_equals_untiled(bistro):
     for f in range(frames):
         st.time = 500 + f; ref.set_camera(cams[f]); ref.run(st, f)
     cur = (frames - 1) & 1
-    for b in [abi.BUF_GBUFFER0 + cur, abi.BUF_DIRECT_RESV0 + cur, abi.BUF_LIGHT_ID0 + cur, abi.BUF_INDIRECT_RESV0 + cur,
-              abi.BUF_DIRECT_RESULT0 + cur, abi.BUF_INDIRECT_RESULT0 + cur]:
+    for b in [abi.BUF_DIRECT_RESULT0 + cur, abi.BUF_INDIRECT_RESULT0 + cur]:   # gathered on rank 0
+        assert np.array_equal(rs[0].readback(b), ref.readback(b)), abi.BUFFER_NAMES[b]
+    B = tiled.band_height(H, world)
+    for b, elem, half in [(abi.BUF_GBUFFER0 + cur, 16, False), (abi.BUF_DIRECT_RESV0 + cur, 36, False), (abi.BUF_LIGHT_ID0 + cur, 4, False),
+                          (abi.BUF_INDIRECT_RESV0 + cur, 76, True)]:
         want = ref.readback(b)
-        for rank in range(world):
-            assert np.array_equal(rs[rank].readback(b), want), (abi.BUFFER_NAMES[b], rank)
+        for rank in range(world):   # the frame's history stays distributed: each rank owns its band
+            w, Bb, Hb = (W // 2, B // 2, H // 2) if half else (W, B, H)
+            a, e = min(rank * Bb, Hb), min((rank + 1) * Bb, Hb)
+            got = rs[rank].readback(b).reshape(-1, w * elem)[a:e]
+            assert np.array_equal(got, want.reshape(-1, w * elem)[a:e]), (abi.BUFFER_NAMES[b], rank)
 
 
 def test_nccl_single_rank_collectives_on_ctx_buffers():
