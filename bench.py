@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--emulate-world", type=int, default=0, help="(1 GPU) time ONE rank of an N-way row-tiled frame with communication stubbed out")
+    ap.add_argument("--emulate-rank", type=int, default=-1)
     ap.add_argument("--cpu-rows", type=int, default=256, help="height of the row band the CPU baseline renders")
     args = ap.parse_args()
 
@@ -82,6 +84,15 @@ def main():
         r.set_stream(stream.cuda_stream)
     comm = tiled.TorchComm() if world > 1 else tiled.LocalComm()
     frame = tiled.TiledFrame(tiled.RendererTensors(r), comm, W, H) if world > 1 else None
+    if world == 1 and args.emulate_world > 1:
+        class StubComm(tiled.LocalComm):   # per-rank compute + host overhead of the tiled schedule, no real peers
+            world = args.emulate_world
+            rank = args.emulate_rank if args.emulate_rank >= 0 else args.emulate_world // 2
+            def all_gather_rows(self, *a, **k): return None
+            def halo_exchange(self, items, async_op=False): return []
+            def gather_rows_to(self, *a, **k): return None
+            def any_flag(self, flag): return False
+        frame = tiled.TiledFrame(tiled.RendererTensors(r), StubComm(), W, H)
 
     scene.updateCamera(W, H)  # prime the camera history (static camera: SURVEY.md §8d)
 
@@ -147,11 +158,11 @@ def main():
             "config": {"workload": f"bistro-exterior-class procedural scene, {scene.getStat()['instancedTriangles']} triangles, {W}x{H}, "
                                    "ReSTIR DI (temporal, M=4) + GI (maxDepth 4, MIS) + A-Trous 4+5 levels + compose, static camera, "
                                    "2048x1024 synthetic HDR sky", "width": W, "height": H, "scene_scale": args.scale,
-                       "parallelism": "single GPU" if world == 1 else f"row-tiled x{world}, in-place all-gather + neighbour halos over RCCL",
+                       "parallelism": ("single GPU" if frame is None else f"ONE rank of an emulated {args.emulate_world}-way row tiling, communication stubbed (not a benchmark result)") if world == 1 else f"row-tiled x{world}, in-place all-gather + neighbour halos over RCCL",
                        "rays_per_frame": round(rays_per_frame), "fps": round(1e3 / ms_per_step, 2), "bvh8_build_s": round(build_s, 2),
                        "accel": r.accel_stats()},
         }
-    if world == 1:
+    if world == 1 and timing.framesTimed > 0:
         stage_ms = [timing.stageMs[i] / max(1, timing.framesTimed) for i in range(5)]
         dom = int(np.argmax(stage_ms))
         launches = {0: 1, 1: 1, 2: 4, 3: 5, 4: 1}[dom]

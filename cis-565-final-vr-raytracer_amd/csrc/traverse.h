@@ -291,6 +291,8 @@ RT_DEV bool travRound(const DevScene& S, Trav& T, bool live, uint2* stack, TravC
   const bool wantTri = live && travHasTris(T);
   const bool wantNode = live && !wantTri;
   const int nT = __popcll(__ballot(wantTri ? 1 : 0)), nN = __popcll(__ballot(wantNode ? 1 : 0));
+  // (running both kinds every round, or the minority kind above a 25 % threshold, measured 5-10 % slower in both the
+  // throughput-bound full frame and the latency-bound row-band case)
   if(nT >= nN) { if(wantTri) travTri<ANY>(S, T, tc); }
   else { if(wantNode) travNode(S, T, stack, tc); }
   return live && (travHasTris(T) || travHasNodes(T));
