@@ -49,15 +49,33 @@ def build_hip(force=False, verbose=False):
 def build_host(force=False, verbose=False):
     d = os.path.join(_HERE, "host")
     if force or _stale(HOST_LIB, _deps(d, (".cpp", ".h", ".hpp"))):
-        cmd = [os.environ.get("CXX", "g++")] + HOST_FLAGS + [os.path.join(d, s) for s in HOST_SRC] + ["-o", HOST_LIB]
+        cmd = [os.environ.get("CXX", "g++")] + HOST_FLAGS + [os.path.join(d, s) for s in HOST_SRC] + ["-o", HOST_LIB, "-lz"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
     return HOST_LIB
 
 
+DEMO_BIN = os.path.join(_HERE, "host", "restir_demo")
+
+
+def build_demo(force=False, verbose=False):
+    """C++ example application over host/renderer.hpp (the reference's main.cpp call order); needs both libraries."""
+    d = os.path.join(_HERE, "host")
+    src = os.path.join(d, "restir_demo.cpp")
+    if force or _stale(DEMO_BIN, [src, os.path.join(d, "renderer.hpp"), HIP_LIB, HOST_LIB]):
+        cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", src, "-o", DEMO_BIN, "-L" + os.path.join(_HERE, "csrc"), "-L" + d,
+               "-lrestir_hip", "-lrestir_host", "-Wl,-rpath,$ORIGIN/../csrc:$ORIGIN:/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return DEMO_BIN
+
+
 def build_all(force=False, verbose=False):
-    return build_host(force, verbose), build_hip(force, verbose)
+    out = build_host(force, verbose), build_hip(force, verbose)
+    build_demo(force, verbose)
+    return out
 
 
 if __name__ == "__main__":

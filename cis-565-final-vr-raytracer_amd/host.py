@@ -24,7 +24,7 @@ def host_lib():
         L.rth_env_average.restype = C.c_float
         for name, args in {
             "rth_scene_destroy": [C.c_void_p], "rth_scene_load": [C.c_void_p, C.c_char_p],
-            "rth_scene_make_procedural": [C.c_void_p, C.c_int, C.c_float, C.c_uint32],
+            "rth_scene_make_procedural": [C.c_void_p, C.c_int, C.c_float, C.c_uint32], "rth_scene_save_gltf": [C.c_void_p, C.c_char_p],
             "rth_scene_set_camera": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float],
             "rth_scene_get_camera_pose": [C.c_void_p, C.c_void_p], "rth_scene_update_camera": [C.c_void_p, C.c_int, C.c_int],
             "rth_scene_get_camera": [C.c_void_p, C.c_void_p], "rth_scene_light_weights": [C.c_void_p, C.c_void_p, C.c_void_p],
@@ -74,6 +74,9 @@ class Scene:
             host_lib().rth_scene_destroy(self._h); self._h = None
     def load(self, filename):
         return host_lib().rth_scene_load(self._h, filename.encode()) == 0
+    def saveGltf(self, filename):
+        """Write the loaded scene as a self-contained .gltf (host/gltf_loader.cpp writer; exchange/test utility)."""
+        return host_lib().rth_scene_save_gltf(self._h, filename.encode()) == 0
     def makeProcedural(self, kind, scale=1.0, seed=1):
         if host_lib().rth_scene_make_procedural(self._h, kind, scale, seed) != 0:
             raise RuntimeError("procedural scene generation failed")

@@ -10,6 +10,13 @@ extern "C" {
 void* rth_scene_create() { return new(std::nothrow) Scene(); }
 void rth_scene_destroy(void* s) { delete static_cast<Scene*>(s); }
 int rth_scene_load(void* s, const char* path) { return static_cast<Scene*>(s)->load(path) ? 0 : -1; }
+int rth_scene_save_gltf(void* s, const char* path)
+{
+  std::string err;
+  if(saveGltfFile(path, static_cast<Scene*>(s)->getScene(), err)) return 0;
+  fprintf(stderr, "rth_scene_save_gltf: %s\n", err.c_str());
+  return -1;
+}
 int rth_scene_make_procedural(void* s, int kind, float scale, uint32_t seed)
 {
   const char* names[] = {"cornell", "helmet-class", "sponza-class", "bistro-exterior-class", "bistro-interior-class"};

@@ -116,5 +116,7 @@ GltfScene makeProceduralScene(ProcScene kind, float scale, uint32_t seed);
 
 // gltf_loader.cpp — tinygltf + nvh::GltfScene::importMaterials/importDrawableNodes stand-in (scene.cpp:72-74, 130-173)
 bool loadGltfFile(const std::string& filename, GltfScene& out, std::string& error);
+// self-contained .gltf (base64 buffers + PNG images) from an in-memory scene; exchange/test utility, no reference counterpart
+bool saveGltfFile(const std::string& filename, const GltfScene& g, std::string& error);
 
 }  // namespace rth
