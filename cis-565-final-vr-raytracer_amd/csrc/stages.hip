@@ -170,18 +170,29 @@ __global__ __launch_bounds__(64) void k_direct_reuse(DevScene S, DevFrame F, rt_
 // maxDepth bounces while the rest stop after one, so they are dispatched first and the short tiles fill the tail.
 // One thread per tile recomputes the tile flag exactly as the stage does and appends the tile to its XCD's list
 // (multi-bounce from the front, single-bounce from the back).  Only the order changes, never a result.
-__global__ void k_ind_tile_order(rt_state st, int rowBegin, int tilesX, int tilesY, int cap, uint32_t* lists, uint32_t* counts)
+__global__ __launch_bounds__(256) void k_ind_tile_order(rt_state st, int rowBegin, int tilesX, int tilesY, int cap, uint32_t* lists, uint32_t* counts)
 {
-  const int t = int(blockIdx.x * blockDim.x + threadIdx.x);
-  if(t >= tilesX * tilesY) return;
-  const int ty = t / tilesX, tx = t - ty * tilesX;
-  const int indW = st.size.x / 2;
-  uint32_t seed = tea(uint32_t(indW) * uint32_t(rowBegin + ty * 8) + uint32_t(tx * 8), st.time);
-  const bool mb = rnd(seed) < 0.25f;
-  const int xcd = (ty / TILE_STRIPE) & 7;
+  // one workgroup per XCD list; list positions come from LDS counters (8 k global atomics on 16 addresses cost 95 us)
+  __shared__ uint32_t s_cnt[2];
+  const int xcd = int(blockIdx.x);
+  if(threadIdx.x < 2) s_cnt[threadIdx.x] = 0u;
+  __syncthreads();
   uint32_t* list = lists + size_t(xcd) * cap;
-  if(mb) list[atomicAdd(&counts[xcd * 2], 1u)] = uint32_t(t);
-  else list[cap - 1 - int(atomicAdd(&counts[xcd * 2 + 1], 1u))] = uint32_t(t);
+  const int indW = st.size.x / 2;
+  const int stripes = (tilesY + TILE_STRIPE - 1) / TILE_STRIPE;
+  for(int s = xcd; s < stripes; s += 8) {
+    for(int i = int(threadIdx.x); i < TILE_STRIPE * tilesX; i += int(blockDim.x)) {
+      const int ty = s * TILE_STRIPE + i / tilesX, tx = i % tilesX;
+      if(ty >= tilesY) continue;
+      uint32_t seed = tea(uint32_t(indW) * uint32_t(rowBegin + ty * 8) + uint32_t(tx * 8), st.time);
+      const bool mb = rnd(seed) < 0.25f;
+      const uint32_t t = uint32_t(ty * tilesX + tx);
+      if(mb) list[atomicAdd(&s_cnt[0], 1u)] = t;
+      else list[cap - 1 - int(atomicAdd(&s_cnt[1], 1u))] = t;
+    }
+  }
+  __syncthreads();
+  if(threadIdx.x < 2) counts[xcd * 2 + threadIdx.x] = s_cnt[threadIdx.x];
 }
 
 __global__ __launch_bounds__(64, 4) void k_indirect_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY, int cap,
@@ -208,18 +219,22 @@ __global__ __launch_bounds__(64, 4) void k_indirect_stage(DevScene S, DevFrame F
   int mb = 0;
   if(lane == 0) mb = rnd(c.seed) < 0.25f ? 1 : 0;
   const bool multiBounce = __builtin_amdgcn_readfirstlane(mb) != 0;
-  if(px.x >= indSize.x || px.y >= indSize.y || px.y >= rowEnd) return;
+  // Lanes without a pixel / without a surface stay in the kernel: they trace rays of the other lanes (tracePool).
+  float4* pool = reinterpret_cast<float4*>(s_stack + size_t(S.stackEntries) * 64);
+  const bool inImage = !(px.x >= indSize.x || px.y >= indSize.y || px.y >= rowEnd);
   Ray ray = c.raySpawn(px, indSize);
 
   GState g0; float depth;
-  if(!stateFromGBuffer(loadG(F.thisG, F, i2{px.x * 2, px.y * 2}), ray, g0, depth)) {
-    storeImg(F.denoiseIndA, F, px, mk4(0, 0, 0, 0));
-    flushCounters(F, c);
-    return;
-  }
+  bool alive = inImage && stateFromGBuffer(loadG(F.thisG, F, i2{px.x * 2, px.y * 2}), ray, g0, depth);
+  const bool hasSurface = alive;
+  if(inImage && !hasSurface) storeImg(F.denoiseIndA, F, px, mk4(0, 0, 0, 0));
+  if(!alive) { g0 = GState{}; }
   g0.position += g0.ffnormal * 2e-2f;  // :299
 
   // ---- pathTraceIndirect, :129-226 --------------------------------------------------------------------------
+  // Per path vertex the reference traces the NEE shadow ray, then samples the BSDF and traces the bounce ray.  Neither
+  // trace advances prd.seed here (DESIGN.md deviation 1), so both rays of a vertex are known before either is traced:
+  // they go to the wave's ray pool together, and the results are applied in the reference's order afterwards.
   f3 throughput = mk3(multiBounce ? 4.0f : 1.0f);
   const f3 primWo = -ray.direction;
   const GState primState = g0;
@@ -228,64 +243,80 @@ __global__ __launch_bounds__(64, 4) void k_indirect_stage(DevScene S, DevFrame F
   State state = zeroState();
   state.position = g0.position; state.normal = g0.normal; state.ffnormal = g0.ffnormal; state.mat = g0.mat; state.matID = g0.matID;
   state.mat.albedo = mk3(1.0f);
-  bool earlyReturn = false;
   for(int depthI = 1; depthI <= st.maxDepth; depthI++) {
-    const f3 wo = -ray.direction;
-    if(depthI > 1 && st.MIS > 0) {
-      f3 Li = mk3(0.0f), wi = mk3(0.0f);
-      const float lightPdf = c.SampleDirectLight(state, Li, wi);
-      if(!Ctx::IsPdfInvalid(lightPdf)) {
-        const float BSDFPdf = metallicWorkflowPdf(state.mat, state.ffnormal, wo, wi);
-        const float weight = MISw(st, lightPdf, BSDFPdf);
-        const f3 add = Li * metallicWorkflowBSDF(state.mat, state.ffnormal, wo, wi) * absDot(state.ffnormal, wi) * throughput / lightPdf * weight;
-        gi.L = toR(mk3(gi.L) + add);
-      }
-    }
-    f3 sampleWi = mk3(0.0f);
+    bool hasShadow = false, hasBounce = false;
+    f3 pendingAdd = mk3(0.0f), sampleWi = mk3(0.0f);
     float samplePdf = 0.0f;
-    const f3 sampleBSDF = c.Sample(state.mat, wo, state.ffnormal, sampleWi, samplePdf);
-    if(Ctx::IsPdfInvalid(samplePdf)) break;
-    if(depthI > 1) {
-      if(!multiBounce) { earlyReturn = true; break; }
-      throughput *= sampleBSDF / samplePdf * absDot(state.ffnormal, sampleWi);
-    } else {
-      primSamplePdf = samplePdf;
-      gi.xv = toR(state.position);
-      gi.nv = toR(state.ffnormal);
-    }
-    ray.origin = OffsetRay(state.position, state.ffnormal);
-    ray.direction = sampleWi;
-    c.ClosestHit(ray);
-    if(c.hit.t >= RT_INFINITY - 1e-4f) {
-      if(depthI > 1) {
-        float lightPdf;
-        const f3 Li = c.EnvEval(sampleWi, lightPdf);
-        const float weight = MISw(st, samplePdf, lightPdf);
-        gi.L = toR(mk3(gi.L) + Li * throughput * weight);
-      } else {
-        gi.xs = toR(state.position + sampleWi * RT_INFINITY * 0.8f);
-        gi.ns = toR(-sampleWi);
+    if(alive) {
+      const f3 wo = -ray.direction;
+      if(depthI > 1 && st.MIS > 0) {  // SampleDirectLight (pathtrace.glsl:185-203) minus its visibility test
+        rt_light_sample ls;
+        const float lightPdf = c.SampleDirectLightNoVisibility(state.position, ls);
+        if(!Ctx::IsPdfInvalid(lightPdf)) {
+          const f3 wi = mk3(ls.wi);
+          const f3 so = OffsetRay(state.position, state.ffnormal);
+          const float maxDist = ((ls.dist - rt_abs(so.x - state.position.x)) - rt_abs(so.y - state.position.y)) - rt_abs(so.z - state.position.z);  // Occlusion :18-22
+          c.nAny++;
+          poolPut(pool, lane * 2 + 1, so, wi, maxDist, c.seed);
+          hasShadow = true;
+          const float BSDFPdf = metallicWorkflowPdf(state.mat, state.ffnormal, wo, wi);
+          const float weight = MISw(st, lightPdf, BSDFPdf);
+          pendingAdd = mk3(ls.Li) * metallicWorkflowBSDF(state.mat, state.ffnormal, wo, wi) * absDot(state.ffnormal, wi) * throughput / lightPdf * weight;
+        }
       }
-      break;
-    }
-    state = c.GetState(ray.direction);
-    c.GetMaterials(state, ray);
-    if(state.isEmitter) {
-      if(depthI > 1) {
-        float lightPdf;
-        const f3 Li = c.LightEval(state, c.hit.t, sampleWi, lightPdf);
-        const float weight = MISw(st, samplePdf, lightPdf);
-        gi.L = toR(mk3(gi.L) + Li * throughput * weight);
-      } else {
-        gi.xs = toR(state.position);
-        gi.ns = toR(state.ffnormal);
+      const f3 sampleBSDF = c.Sample(state.mat, wo, state.ffnormal, sampleWi, samplePdf);
+      if(Ctx::IsPdfInvalid(samplePdf)) alive = false;
+      else if(depthI > 1 && !multiBounce) alive = false;
+      else {
+        if(depthI > 1) throughput *= sampleBSDF / samplePdf * absDot(state.ffnormal, sampleWi);
+        else {
+          primSamplePdf = samplePdf;
+          gi.xv = toR(state.position);
+          gi.nv = toR(state.ffnormal);
+        }
+        ray.origin = OffsetRay(state.position, state.ffnormal);
+        ray.direction = sampleWi;
+        c.nClosest++;
+        poolPut(pool, lane * 2, ray.origin, ray.direction, RT_INFINITY, c.seed);
+        hasBounce = true;
       }
-      break;
     }
-    if(depthI == 1) { gi.xs = toR(state.position); gi.ns = toR(state.ffnormal); }
+    if(__ballot((hasShadow || hasBounce) ? 1 : 0) == 0ull) break;  // wave-uniform
+    tracePool(S, pool, hasBounce, hasShadow, c.stack, c.tc);
+    if(hasShadow && poolGet(pool, lane * 2 + 1).gid == 0xffffffffu) gi.L = toR(mk3(gi.L) + pendingAdd);  // not occluded
+    if(hasBounce) {
+      c.hit = poolGet(pool, lane * 2);
+      if(c.hit.t >= RT_INFINITY - 1e-4f) {
+        if(depthI > 1) {
+          float lightPdf;
+          const f3 Li = c.EnvEval(sampleWi, lightPdf);
+          const float weight = MISw(st, samplePdf, lightPdf);
+          gi.L = toR(mk3(gi.L) + Li * throughput * weight);
+        } else {
+          gi.xs = toR(state.position + sampleWi * RT_INFINITY * 0.8f);
+          gi.ns = toR(-sampleWi);
+        }
+        alive = false;
+      } else {
+        state = c.GetState(ray.direction);
+        c.GetMaterials(state, ray);
+        if(state.isEmitter) {
+          if(depthI > 1) {
+            float lightPdf;
+            const f3 Li = c.LightEval(state, c.hit.t, sampleWi, lightPdf);
+            const float weight = MISw(st, samplePdf, lightPdf);
+            gi.L = toR(mk3(gi.L) + Li * throughput * weight);
+          } else {
+            gi.xs = toR(state.position);
+            gi.ns = toR(state.ffnormal);
+          }
+          alive = false;
+        } else if(depthI == 1) { gi.xs = toR(state.position); gi.ns = toR(state.ffnormal); }
+      }
+    }
     // Russian roulette (:218-224) is compiled out in the reference (`#ifndef RR`, pathtrace.glsl:2)
   }
-  (void)earlyReturn;
+  if(!hasSurface) { flushCounters(F, c); return; }
 
   // ---- ReSTIRIndirect, :228-268 (+ findTemporalNeighbor :74-108) -------------------------------------------------
   f3 indirect = mk3(0.0f);
@@ -470,7 +501,6 @@ hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F,
   if(rowBegin < 0) rowBegin = 0;
   if(rowBegin >= rowEnd || gw <= 0) return hipSuccess;
   const int tilesX = (gw + 7) / 8, tilesY = (rowEnd - rowBegin + 7) / 8;
-  const int nTiles = tilesX * tilesY;
   const dim3 grid(tileGrid(tilesX, tilesY)), block(64);
   const size_t lds = size_t(S.stackEntries) * 64 * sizeof(uint2);
   switch(stage) {
@@ -480,10 +510,8 @@ hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F,
     case RT_STAGE_INDIRECT: {
       // per-XCD tile lists: capacity = the tiles one XCD can own under the striped mapping
       const int cap = int(tileGrid(tilesX, tilesY) / 8);
-      hipError_t e = hipMemsetAsync(F.qcount + 192, 0, 16 * sizeof(uint32_t), stream);
-      if(e != hipSuccess) return e;
-      hipLaunchKernelGGL(k_ind_tile_order, dim3(unsigned((nTiles + 255) / 256)), dim3(256), 0, stream, st, rowBegin, tilesX, tilesY, cap, F.tileOrder, F.qcount + 192);
-      hipLaunchKernelGGL(k_indirect_stage, grid, block, lds, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY, cap, (const uint32_t*)F.tileOrder,
+      hipLaunchKernelGGL(k_ind_tile_order, dim3(8), dim3(256), 0, stream, st, rowBegin, tilesX, tilesY, cap, F.tileOrder, F.qcount + 192);
+      hipLaunchKernelGGL(k_indirect_stage, grid, block, lds + POOL_BYTES, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY, cap, (const uint32_t*)F.tileOrder,
                          (const uint32_t*)(F.qcount + 192));
       break;
     }

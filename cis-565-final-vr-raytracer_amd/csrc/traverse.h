@@ -171,15 +171,18 @@ struct Trav {
   uint32_t seed;
   RayHit hit;
   bool found;
+  bool isAny;      // MODE 2 only (rays of both kinds in one wave: tracePool)
 };
 
 RT_DEV bool travHasTris(const Trav& T) { return T.tgroup.y != 0u; }
 RT_DEV bool travHasNodes(const Trav& T) { return T.ngroup.y > 0x00FFFFFFu || T.sp > 0; }
 
 // ANY = false: closest hit in (0, 1e28); ANY = true: first accepted hit in (0, tmax).  Returns false when there is nothing to traverse.
-template <bool ANY>
+// MODE 2: the kind is a per-ray run-time property (T.isAny, set by the caller before travInit).
+template <int MODE>
 RT_DEV bool travInit(Trav& T, f3 o, f3 d, float tmax, uint32_t raySeed)
 {
+  const bool ANY = MODE == 2 ? T.isAny : MODE == 1;
   T.o = o; T.d = d; T.tmax = tmax; T.seed = raySeed; T.found = false; T.sp = 0;
   T.hit.t = ANY ? tmax : RT_INFINITY;
   T.hit.gid = 0xffffffffu; T.hit.u = 0.f; T.hit.v = 0.f;
@@ -246,9 +249,10 @@ RT_DEV void travNode(const DevScene& S, Trav& T, uint2* stack, TravCounters& tc)
 }
 
 // Triangle step (precondition: travHasTris): test one pending triangle.
-template <bool ANY>
+template <int MODE>
 RT_DEV void travTri(const DevScene& S, Trav& T, TravCounters& tc)
 {
+  const bool ANY = MODE == 2 ? T.isAny : MODE == 1;
   const uint32_t bit = 31u - uint32_t(__clz(int(T.tgroup.y)));
   T.tgroup.y &= ~(1u << bit);
   const uint4* tp = reinterpret_cast<const uint4*>(S.tris + (T.tgroup.x + bit));
@@ -285,7 +289,7 @@ RT_DEV void travTri(const DevScene& S, Trav& T, TravCounters& tc)
 
 // One scheduling round for a (partial) wave: every lane that is `live` votes for the kind of step it is ready for; the
 // majority kind runs, the other lanes wait one round.  Returns whether this lane still has work.
-template <bool ANY>
+template <int ANY>
 RT_DEV bool travRound(const DevScene& S, Trav& T, bool live, uint2* stack, TravCounters& tc)
 {
   const bool wantTri = live && travHasTris(T);
@@ -298,7 +302,7 @@ RT_DEV bool travRound(const DevScene& S, Trav& T, bool live, uint2* stack, TravC
   return live && (travHasTris(T) || travHasNodes(T));
 }
 
-template <bool ANY>
+template <int ANY>
 RT_DEV bool traceRay(const DevScene& S, f3 o, f3 d, float tmax, uint32_t raySeed, uint2* stack, RayHit& hit, TravCounters& tc)
 {
   Trav T;
@@ -307,6 +311,68 @@ RT_DEV bool traceRay(const DevScene& S, f3 o, f3 d, float tmax, uint32_t raySeed
   while(__ballot(live ? 1 : 0) != 0ull) live = travRound<ANY>(S, T, live, stack, tc);
   hit = T.hit;
   return T.found;
+}
+
+// ---- wave-level ray pool ---------------------------------------------------------------------------------------
+// A path vertex spawns up to two independent rays (the NEE shadow ray and the BSDF bounce ray); in a multi-bounce tile many
+// lanes are dead (path left the scene) while the live ones would trace their two rays back to back.  tracePool() lets the 64
+// lanes of the wave share the wave's rays: lane L parks its rays in LDS slots 2L (closest-hit) and 2L+1 (any-hit), the set
+// slots are compacted into a work list, and every lane — dead or alive — pulls the next ray whenever its current one
+// finishes.  Results come back through the same slots.  A ray's result does not depend on the lane that traced it (the
+// HitTest RNG is keyed by ray seed and triangle id), so the frame is unchanged bit for bit.
+constexpr int POOL_SLOT_F4 = 2;                 // 32 B per slot: ray (o.xyz, d.x | d.yz, tmax, seed) then result (t, gid, u, v)
+constexpr int POOL_BYTES = 128 * 32 + 128;      // 128 slots + the work list (u8 slot ids)
+
+RT_DEV void poolPut(float4* pool, int slot, f3 o, f3 d, float tmax, uint32_t seed)
+{
+  pool[slot * POOL_SLOT_F4] = make_float4(o.x, o.y, o.z, d.x);
+  pool[slot * POOL_SLOT_F4 + 1] = make_float4(d.y, d.z, tmax, rt_u2f(seed));
+}
+RT_DEV RayHit poolGet(const float4* pool, int slot)
+{
+  const float4 r = pool[slot * POOL_SLOT_F4];
+  RayHit h; h.t = r.x; h.gid = rt_f2u(r.y); h.u = r.z; h.v = r.w;
+  return h;
+}
+RT_DEV void waveLdsSync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+// Every lane of the wave must call this (uniform control flow).  hasC / hasS: this lane parked a closest-hit / any-hit ray.
+RT_DEV void tracePool(const DevScene& S, float4* pool, bool hasC, bool hasS, uint2* stack, TravCounters& tc)
+{
+  unsigned char* list = reinterpret_cast<unsigned char*>(pool + 128 * POOL_SLOT_F4);
+  const int lane = int(threadIdx.x) & 63;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const unsigned long long mC = __ballot(hasC ? 1 : 0), mS = __ballot(hasS ? 1 : 0);
+  const int nC = __popcll(mC), n = nC + __popcll(mS);
+  if(n == 0) return;
+  if(hasC) list[__popcll(mC & lt)] = (unsigned char)(lane * 2);
+  if(hasS) list[nC + __popcll(mS & lt)] = (unsigned char)(lane * 2 + 1);
+  waveLdsSync();
+  int next = 0, mySlot = 0;
+  bool live = false;
+  Trav T;
+  for(;;) {
+    const unsigned long long idle = __ballot(live ? 0 : 1);
+    if(next < n && idle != 0ull) {
+      const int item = next + __popcll(idle & lt);
+      if(!live && item < n) {
+        mySlot = int(list[item]);
+        const float4 a = pool[mySlot * POOL_SLOT_F4], b = pool[mySlot * POOL_SLOT_F4 + 1];
+        T.isAny = (mySlot & 1) != 0;
+        live = travInit<2>(T, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), b.z, rt_f2u(b.w));
+        if(!live) pool[mySlot * POOL_SLOT_F4] = make_float4(T.hit.t, rt_u2f(T.hit.gid), T.hit.u, T.hit.v);
+      }
+      next = min(n, next + __popcll(idle));
+    }
+    if(__ballot(live ? 1 : 0) == 0ull) {
+      if(next >= n) break;
+      continue;
+    }
+    const bool still = travRound<2>(S, T, live, stack, tc);
+    if(live && !still) pool[mySlot * POOL_SLOT_F4] = make_float4(T.hit.t, rt_u2f(T.hit.gid), T.hit.u, T.hit.v);
+    live = still;
+  }
+  waveLdsSync();
 }
 
 }  // namespace rt
