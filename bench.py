@@ -164,6 +164,23 @@ def main():
         }
     if world == 1 and timing.framesTimed > 0:
         stage_ms = [timing.stageMs[i] / max(1, timing.framesTimed) for i in range(5)]
+        frame_latency_ms = timing.frameMs / max(1, timing.framesTimed)
+        # The timed region runs with frames in flight (rt_set_overlap mode 2): kernels of consecutive frames share the chip,
+        # so each launch is stretched while the frame rate goes up.  A short extra pass with every launch alone on one
+        # stream gives the un-overlapped duration of the same kernels on the same frames.
+        serial_ms = None
+        if frame is None:
+            r.set_overlap(0)
+            for k in range(2):
+                step(first_timed + k)
+            r.sync(); r.set_counting(False)
+            ns = min(10, args.steps)
+            for k in range(ns):
+                step(first_timed + k)
+            r.sync()
+            ts = r.counters()
+            serial_ms = [ts.stageMs[i] / max(1, ts.framesTimed) for i in range(5)]
+            r.set_overlap(2 if os.environ.get("RESTIR_OVERLAP") is None else int(os.environ["RESTIR_OVERLAP"]))
         dom = int(np.argmax(stage_ms))
         launches = {0: 1, 1: 1, 2: 4, 3: 5, 4: 1}[dom]
         # counts of the dominant stage alone
@@ -184,7 +201,25 @@ def main():
         out["roofline"] = {"bound": "hbm", "kernel": STAGE_NAMES[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                            "algorithmic_bytes_per_launch": round(b_screen + b_trav), "screen_bytes": round(b_screen), "traversal_bytes": round(b_trav),
-                           "launch_ms": round(dur_ms, 4), "stage_ms_per_frame": {STAGE_NAMES[i]: round(stage_ms[i], 4) for i in range(5)}}
+                           "launch_ms": round(dur_ms, 4), "stage_ms_per_frame": {STAGE_NAMES[i]: round(stage_ms[i], 4) for i in range(5)},
+                           "frame_latency_ms": round(frame_latency_ms, 4)}
+        # HBM traffic of the same kernel from the PMC passes (scripts/pmc.sh: separate rocprofv3 --pmc runs of this command;
+        # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950's FETCH_SIZE counts wide reads at half their size — MI355X_MICROARCH.md,
+        # HBM section — so it is doubled; WRITE_SIZE is taken as reported).  The file is refreshed with the profiles.
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as fh:
+                t = json.load(fh).get({0: "k_direct_stage", 1: "k_indirect_stage", 2: "k_denoise", 3: "k_denoise", 4: "k_compose"}[dom])
+            if t and dom in (0, 1, 4):
+                out["roofline"]["traffic"] = round(2 * t["FETCH_SIZE_KB"] * 1024 + t["WRITE_SIZE_KB"] * 1024)
+                out["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch, separate run)"
+        except (OSError, ValueError, KeyError):
+            pass
+        if serial_ms is not None:  # same kernel, same bytes, launched alone (no other frame's kernels beside it)
+            sdur = serial_ms[dom] / launches
+            out["roofline"]["serial"] = {"launch_ms": round(sdur, 4), "achieved": round((b_screen + b_trav) / (sdur * 1e-3) / 1e9, 2),
+                                         "frac": round((b_screen + b_trav) / (sdur * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                         "stage_ms_per_frame": {STAGE_NAMES[i]: round(serial_ms[i], 4) for i in range(5)},
+                                         "frame_ms": round(sum(serial_ms), 4)}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(abi, host, scene, env, st, desc, W, H, args.cpu_rows, first_timed)
     if rank == 0:

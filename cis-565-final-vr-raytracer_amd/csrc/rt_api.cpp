@@ -21,8 +21,14 @@ struct rt_ctx {
   int device = 0;
   hipStream_t ownStream = nullptr, stream = nullptr;
   hipStream_t sideStream = nullptr;           // direct A-Trous runs here, concurrently with the indirect stage
+  hipStream_t indStream = nullptr;            // overlap 2: the indirect stage of frame f runs here, next to direct(f+1) on `stream`
   hipEvent_t evFork = nullptr, evJoin = nullptr;
-  int overlap = 1;
+  // overlap 2 (frames in flight): ring of per-frame dependency events — direct done / indirect done / frame done
+  hipEvent_t evD[4] = {}, evI[4] = {}, evDone[4] = {};
+  uint64_t seq = 0;          // frames submitted through the pipelined path since the last join
+  bool inFlight = false;     // work may be pending on indStream / sideStream
+  void* spareG = nullptr; void* spareMotion = nullptr;   // third G-buffer / second motion buffer (rotated per pipelined frame)
+  int overlap = 2;           // 0 = one stream; 1 = direct A-Trous beside the indirect stage; 2 = 1 + consecutive frames overlap
   std::string err;
   // host copy of the scene (rt_build_accel runs after rt_upload_scene returns; the caller keeps ownership of its arrays)
   std::vector<rt_prim_mesh> primMeshes; std::vector<rt_vertex> vertices; std::vector<uint32_t> indices; std::vector<rt_instance> instances;
@@ -47,7 +53,7 @@ struct rt_ctx {
   bool counting = false;
   unsigned long long* dCounters = nullptr;
   // timing: per frame one event set; event 0 = frame start, event k = end of launch k.  Sets are harvested lazily.
-  static constexpr int MAX_EV = 20, MAX_SETS = 1024;
+  static constexpr int MAX_EV = 24, MAX_SETS = 1024;
   struct EvSet { hipEvent_t ev[MAX_EV]; int stage[MAX_EV]; int prev[MAX_EV]; int count; int last; };
   std::vector<EvSet> evSets;
   size_t evUsed = 0;
@@ -66,6 +72,27 @@ static void harvestTimings(rt_ctx* c)
     if(E.count > 1 && hipEventElapsedTime(&ms, E.ev[0], E.ev[E.last]) == hipSuccess) { c->accFrame += ms; c->accFrames++; }
   }
   c->evUsed = 0;
+}
+
+// Wait (host) for everything this context has submitted.
+static hipError_t syncAll(rt_ctx* c)
+{
+  hipError_t e = hipStreamSynchronize(c->stream);
+  if(e == hipSuccess && c->indStream) e = hipStreamSynchronize(c->indStream);
+  if(e == hipSuccess && c->sideStream) e = hipStreamSynchronize(c->sideStream);
+  c->inFlight = false; c->seq = 0;
+  return e;
+}
+// Make `stream` (device side) wait for the frames in flight on the internal streams: needed before work that is submitted
+// to `stream` alone (rt_run_stage, the non-pipelined rt_render_frame) may touch the frame buffers.
+static hipError_t joinInFlight(rt_ctx* c)
+{
+  if(!c->inFlight) return hipSuccess;
+  const int r = int((c->seq - 1) & 3);
+  hipError_t e = hipStreamWaitEvent(c->stream, c->evI[r], 0);
+  if(e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->evDone[r], 0);
+  c->inFlight = false; c->seq = 0;
+  return e;
 }
 
 static thread_local std::string g_createErr;
@@ -182,7 +209,25 @@ int rt_create(rt_ctx** out, int device)
   c->device = device;
   if(hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) != hipSuccess) { g_createErr = "rt_create: hipStreamCreate failed"; delete c; return RT_ERR_HIP; }
   c->stream = c->ownStream;
-  (void)hipStreamCreateWithFlags(&c->sideStream, hipStreamNonBlocking);
+  {
+    // older work first: the streams that finish frame f outrank the one that starts frame f+1 (RESTIR_PRIO=0 disables)
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    const char* pe = getenv("RESTIR_PRIO");
+    const bool prio = !(pe && atoi(pe) == 0) && hi < lo;
+    if(prio) {
+      (void)hipStreamCreateWithPriority(&c->sideStream, hipStreamNonBlocking, hi);
+      (void)hipStreamCreateWithPriority(&c->indStream, hipStreamNonBlocking, hi);
+    } else {
+      (void)hipStreamCreateWithFlags(&c->sideStream, hipStreamNonBlocking);
+      (void)hipStreamCreateWithFlags(&c->indStream, hipStreamNonBlocking);
+    }
+  }
+  for(int i = 0; i < 4; i++) {
+    (void)hipEventCreateWithFlags(&c->evD[i], hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&c->evI[i], hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&c->evDone[i], hipEventDisableTiming);
+  }
   (void)hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming);
   if(const char* e = getenv("RESTIR_OVERLAP")) c->overlap = atoi(e);
@@ -197,9 +242,13 @@ int rt_destroy(rt_ctx* c)
 {
   if(!c) return RT_ERR_INVALID_ARG;
   (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream);
+  (void)syncAll(c);
   freePool(c->sceneAllocs); freePool(c->accelAllocs); freePool(c->scratchAllocs);
   for(int i = 0; i < RT_BUF_COUNT; i++) if(c->bufs[i]) (void)hipFree(c->bufs[i]);
+  if(c->spareG) (void)hipFree(c->spareG);
+  if(c->spareMotion) (void)hipFree(c->spareMotion);
+  if(c->indStream) (void)hipStreamDestroy(c->indStream);
+  for(int i = 0; i < 4; i++) { if(c->evD[i]) (void)hipEventDestroy(c->evD[i]); if(c->evI[i]) (void)hipEventDestroy(c->evI[i]); if(c->evDone[i]) (void)hipEventDestroy(c->evDone[i]); }
   if(c->dCounters) (void)hipFree(c->dCounters);
   for(auto& E : c->evSets) for(int i = 0; i < rt_ctx::MAX_EV; i++) (void)hipEventDestroy(E.ev[i]);
   if(c->ownStream) (void)hipStreamDestroy(c->ownStream);
@@ -221,7 +270,7 @@ int rt_sync(rt_ctx* c)
 {
   if(!c) return RT_ERR_INVALID_ARG;
   RT_HIP(c, hipSetDevice(c->device));
-  RT_HIP(c, hipStreamSynchronize(c->stream));
+  RT_HIP(c, syncAll(c));
   return RT_OK;
 }
 
@@ -239,7 +288,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
     if(pm.materialIndex >= int32_t(d->numMaterials)) return fail(c, RT_ERR_INVALID_ARG, "rt_upload_scene: material index out of range");
   }
   RT_HIP(c, hipSetDevice(c->device));
-  RT_HIP(c, hipStreamSynchronize(c->stream));
+  RT_HIP(c, syncAll(c));
   freePool(c->sceneAllocs); freePool(c->accelAllocs);
   c->haveScene = c->haveAccel = false;
   c->ds = DevScene{};
@@ -301,7 +350,7 @@ int rt_build_accel(rt_ctx* c)
   if(!c) return RT_ERR_INVALID_ARG;
   if(!c->haveScene) return fail(c, RT_ERR_NO_SCENE, "rt_build_accel: no scene uploaded");
   RT_HIP(c, hipSetDevice(c->device));
-  RT_HIP(c, hipStreamSynchronize(c->stream));
+  RT_HIP(c, syncAll(c));
   freePool(c->accelAllocs);
   c->haveAccel = false;
   rt_scene_desc d{};
@@ -364,8 +413,10 @@ int rt_resize(rt_ctx* c, int w, int h)
   if(!c) return RT_ERR_INVALID_ARG;
   if(w <= 0 || h <= 0 || w > 32767 || h > 32767) return fail(c, RT_ERR_INVALID_ARG, "rt_resize: size must be in 1..32767 (RG16_SINT motion vectors)");
   RT_HIP(c, hipSetDevice(c->device));
-  RT_HIP(c, hipStreamSynchronize(c->stream));
+  RT_HIP(c, syncAll(c));
   for(int i = 0; i < RT_BUF_COUNT; i++) { if(c->bufs[i]) (void)hipFree(c->bufs[i]); c->bufs[i] = nullptr; c->bufBytes[i] = 0; }
+  if(c->spareG) { (void)hipFree(c->spareG); c->spareG = nullptr; }
+  if(c->spareMotion) { (void)hipFree(c->spareMotion); c->spareMotion = nullptr; }
   c->W = c->H = 0;
   const size_t n = size_t(w) * h, nh = size_t(w / 2) * (h / 2);
   for(int i = 0; i < RT_BUF_COUNT; i++) {
@@ -374,6 +425,11 @@ int rt_resize(rt_ctx* c, int w, int h)
     RT_HIP(c, hipMalloc(&c->bufs[i], alloc));
     RT_HIP(c, hipMemset(c->bufs[i], (i == RT_BUF_LIGHT_ID0 || i == RT_BUF_LIGHT_ID1) ? 0xff : 0, alloc));
     c->bufBytes[i] = bytes; c->bufAlloc[i] = alloc;
+    if(i == RT_BUF_GBUFFER0 || i == RT_BUF_MOTION) {  // rotation partners for frames in flight (rt_render_frame, overlap 2)
+      void** spare = (i == RT_BUF_MOTION) ? &c->spareMotion : &c->spareG;
+      RT_HIP(c, hipMalloc(spare, alloc));
+      RT_HIP(c, hipMemset(*spare, 0, alloc));
+    }
   }
   // wavefront scratch
   freePool(c->scratchAllocs);
@@ -449,6 +505,7 @@ int rt_run_stage(rt_ctx* c, const rt_state* st, int frames, int stage, int level
   if(stage < 0 || stage >= RT_STAGE_COUNT) return fail(c, RT_ERR_INVALID_ARG, "rt_run_stage: unknown stage");
   if(rowBegin < 0 || (rowBegin & 7)) return fail(c, RT_ERR_INVALID_ARG, "rt_run_stage: rowBegin must be a non-negative multiple of 8");
   RT_HIP(c, hipSetDevice(c->device));
+  RT_HIP(c, joinInFlight(c));
   const DevFrame F = makeFrame(c, frames);
   RT_HIP(c, (c->pipeline ? launchStageWavefront : launchStage)(c->stream, c->ds, F, *st, c->cam, stage, level, rowBegin, rowEnd));
   return RT_OK;
@@ -459,47 +516,100 @@ int rt_render_frame(rt_ctx* c, const rt_state* st, int frames)
   int rc = checkReady(c, st);
   if(rc) return rc;
   RT_HIP(c, hipSetDevice(c->device));
-  const DevFrame F = makeFrame(c, frames);
-  if(c->evUsed == rt_ctx::MAX_SETS) { RT_HIP(c, hipStreamSynchronize(c->stream)); harvestTimings(c); }
+  if(c->evUsed == rt_ctx::MAX_SETS) { RT_HIP(c, syncAll(c)); harvestTimings(c); }
   if(c->evUsed == c->evSets.size()) {
     rt_ctx::EvSet E{};
     for(int i = 0; i < rt_ctx::MAX_EV; i++) RT_HIP(c, hipEventCreate(&E.ev[i]));
     c->evSets.push_back(E);
   }
   rt_ctx::EvSet& E = c->evSets[c->evUsed];
-  int k = 0, lastMain = 0, lastSide = 0;
-  RT_HIP(c, hipEventRecord(E.ev[k], c->stream));
-  E.stage[k] = -1; E.prev[k] = 0; k++;
-  auto run = [&](hipStream_t strm, int stage, int level, bool stamp) -> int {
+  const bool pipelined = c->overlap >= 2 && c->pipeline == 0 && c->sideStream && c->indStream && c->spareG && c->spareMotion;
+  if(pipelined) {
+    // Rotate the G-buffer (3 physical buffers) and the motion buffer (2): direct(f+1) must not overwrite what indirect(f)
+    // still reads (its own G-buffer + motion, and G(f-1) for temporal reprojection).  The boundary ids keep their meaning:
+    // RT_BUF_GBUFFER0 + (frames & 1) / RT_BUF_MOTION are this frame's buffers once the call returns.
+    std::swap(c->bufs[RT_BUF_GBUFFER0 + (frames & 1)], c->spareG);
+    std::swap(c->bufs[RT_BUF_MOTION], c->spareMotion);
+  } else {
+    RT_HIP(c, joinInFlight(c));
+  }
+  const DevFrame F = makeFrame(c, frames);
+  int k = 0, lastMain = 0, lastSide = 0, lastInd = 0;
+  auto run = [&](hipStream_t strm, int stage, int level) -> int {
     hipError_t e = (c->pipeline ? launchStageWavefront : launchStage)(strm, c->ds, F, *st, c->cam, stage, level, 0, 0);
     if(e != hipSuccess) { c->err = std::string("launchStage: ") + hipGetErrorString(e); return RT_ERR_HIP; }
-    (void)stamp;
     e = hipEventRecord(E.ev[k], strm);
     if(e != hipSuccess) { c->err = std::string("hipEventRecord: ") + hipGetErrorString(e); return RT_ERR_HIP; }
-    int& last = (strm == c->stream) ? lastMain : lastSide;
+    int& last = (strm == c->stream) ? lastMain : (strm == c->indStream ? lastInd : lastSide);
     E.stage[k] = stage; E.prev[k] = last; last = k; k++;
     return RT_OK;
   };
+  auto mark = [&](hipStream_t strm, int& last) -> hipError_t {  // start-of-chain timestamp on a stream (after its waits)
+    hipError_t e = hipEventRecord(E.ev[k], strm);
+    E.stage[k] = -1; E.prev[k] = k; last = k; k++;
+    return e;
+  };
+
+  if(pipelined) {
+    // Frames in flight.  Three in-order streams:
+    //   stream    : direct(f)                                      -> evD
+    //   indStream : wait evD; indirect(f)                          -> evI
+    //   sideStream: wait evD; direct A-Trous x4; wait evI; indirect A-Trous x5; compose -> evDone
+    // so that direct(f+1), submitted by the next call, runs beside indirect(f) and the filters of frame f: the long
+    // tail of multi-bounce tiles no longer leaves the chip idle, and the bandwidth-bound filters hide behind traversal.
+    // Buffer reuse across frames is ordered explicitly:
+    //   direct(f) overwrites G(f-3) [read by indirect(f-2)], motion(f-2) [indirect(f-2)] and the result image of f-2 [compose(f-2)];
+    //   indirect(f) overwrites the noisy-indirect scratch that the indirect A-Trous of f-1 reads.
+    const uint64_t s = c->seq;
+    const int r = int(s & 3);
+    if(s >= 2) {
+      RT_HIP(c, hipStreamWaitEvent(c->stream, c->evI[(s - 2) & 3], 0));
+      RT_HIP(c, hipStreamWaitEvent(c->stream, c->evDone[(s - 2) & 3], 0));
+    }
+    RT_HIP(c, mark(c->stream, lastMain));
+    if((rc = run(c->stream, RT_STAGE_DIRECT, 0))) return rc;
+    RT_HIP(c, hipEventRecord(c->evD[r], c->stream));
+
+    RT_HIP(c, hipStreamWaitEvent(c->indStream, c->evD[r], 0));
+    if(s >= 1) RT_HIP(c, hipStreamWaitEvent(c->indStream, c->evDone[(s - 1) & 3], 0));
+    RT_HIP(c, mark(c->indStream, lastInd));
+    if((rc = run(c->indStream, RT_STAGE_INDIRECT, 0))) return rc;
+    RT_HIP(c, hipEventRecord(c->evI[r], c->indStream));
+
+    RT_HIP(c, hipStreamWaitEvent(c->sideStream, c->evD[r], 0));
+    RT_HIP(c, mark(c->sideStream, lastSide));
+    if(st->denoise > 0) for(int i = 0; i < 4; i++) if((rc = run(c->sideStream, RT_STAGE_DENOISE_DIRECT, i))) return rc;
+    RT_HIP(c, hipStreamWaitEvent(c->sideStream, c->evI[r], 0));
+    RT_HIP(c, mark(c->sideStream, lastSide));
+    if(st->denoise > 0) for(int i = 0; i < 5; i++) if((rc = run(c->sideStream, RT_STAGE_DENOISE_INDIRECT, i))) return rc;
+    if((rc = run(c->sideStream, RT_STAGE_COMPOSE, 0))) return rc;
+    RT_HIP(c, hipEventRecord(c->evDone[r], c->sideStream));
+    c->seq = s + 1; c->inFlight = true;
+    E.count = k; E.last = lastSide;
+    c->evUsed++;
+    return RT_OK;
+  }
+
+  RT_HIP(c, mark(c->stream, lastMain));
   // Renderer::run, renderer.cpp:163-205.  The direct A-Trous chain only depends on the direct stage and the indirect stage
   // + its A-Trous chain only on the G-buffer, so the two chains run on two streams and join before compose: the direct
   // filter (ALU bound, full occupancy) fills the CUs that the indirect stage's long tail of multi-bounce tiles leaves idle.
   const bool fork = c->overlap && st->denoise > 0 && c->sideStream;
-  if((rc = run(c->stream, RT_STAGE_DIRECT, 0, true))) return rc;
+  if((rc = run(c->stream, RT_STAGE_DIRECT, 0))) return rc;
   if(fork) {
     RT_HIP(c, hipEventRecord(c->evFork, c->stream));
     RT_HIP(c, hipStreamWaitEvent(c->sideStream, c->evFork, 0));
-    RT_HIP(c, hipEventRecord(E.ev[k], c->sideStream));
-    E.stage[k] = -1; E.prev[k] = k; lastSide = k; k++;
-    for(int i = 0; i < 4; i++) if((rc = run(c->sideStream, RT_STAGE_DENOISE_DIRECT, i, false))) return rc;
+    RT_HIP(c, mark(c->sideStream, lastSide));
+    for(int i = 0; i < 4; i++) if((rc = run(c->sideStream, RT_STAGE_DENOISE_DIRECT, i))) return rc;
     RT_HIP(c, hipEventRecord(c->evJoin, c->sideStream));
   }
-  if((rc = run(c->stream, RT_STAGE_INDIRECT, 0, true))) return rc;
+  if((rc = run(c->stream, RT_STAGE_INDIRECT, 0))) return rc;
   if(st->denoise > 0) {
-    if(!fork) for(int i = 0; i < 4; i++) if((rc = run(c->stream, RT_STAGE_DENOISE_DIRECT, i, true))) return rc;
-    for(int i = 0; i < 5; i++) if((rc = run(c->stream, RT_STAGE_DENOISE_INDIRECT, i, true))) return rc;
+    if(!fork) for(int i = 0; i < 4; i++) if((rc = run(c->stream, RT_STAGE_DENOISE_DIRECT, i))) return rc;
+    for(int i = 0; i < 5; i++) if((rc = run(c->stream, RT_STAGE_DENOISE_INDIRECT, i))) return rc;
   }
   if(fork) RT_HIP(c, hipStreamWaitEvent(c->stream, c->evJoin, 0));
-  if((rc = run(c->stream, RT_STAGE_COMPOSE, 0, true))) return rc;
+  if((rc = run(c->stream, RT_STAGE_COMPOSE, 0))) return rc;
   E.count = k; E.last = lastMain;
   c->evUsed++;
   return RT_OK;
@@ -513,7 +623,7 @@ int rt_readback(rt_ctx* c, int buffer, void* dst, size_t bytes)
   if(c->W == 0) return fail(c, RT_ERR_NO_TARGET, "rt_readback: rt_resize has not been called");
   if(bytes != c->bufBytes[buffer]) return fail(c, RT_ERR_INVALID_ARG, "rt_readback: size mismatch (see rt_buffer_bytes)");
   RT_HIP(c, hipSetDevice(c->device));
-  RT_HIP(c, hipStreamSynchronize(c->stream));
+  RT_HIP(c, syncAll(c));
   RT_HIP(c, hipMemcpy(dst, c->bufs[buffer], bytes, hipMemcpyDeviceToHost));
   return RT_OK;
 }
@@ -524,7 +634,7 @@ int rt_upload_history(rt_ctx* c, int buffer, const void* src, size_t bytes)
   if(c->W == 0) return fail(c, RT_ERR_NO_TARGET, "rt_upload_history: rt_resize has not been called");
   if(bytes != c->bufBytes[buffer]) return fail(c, RT_ERR_INVALID_ARG, "rt_upload_history: size mismatch (see rt_buffer_bytes)");
   RT_HIP(c, hipSetDevice(c->device));
-  RT_HIP(c, hipStreamSynchronize(c->stream));
+  RT_HIP(c, syncAll(c));
   RT_HIP(c, hipMemcpy(c->bufs[buffer], src, bytes, hipMemcpyHostToDevice));
   RT_HIP(c, hipDeviceSynchronize());
   return RT_OK;
@@ -544,7 +654,7 @@ int rt_set_counting(rt_ctx* c, int enable)
 {
   if(!c) return RT_ERR_INVALID_ARG;
   RT_HIP(c, hipSetDevice(c->device));
-  RT_HIP(c, hipStreamSynchronize(c->stream));
+  RT_HIP(c, syncAll(c));
   RT_HIP(c, hipMemset(c->dCounters, 0, 8 * sizeof(unsigned long long)));
   RT_HIP(c, hipDeviceSynchronize());
   harvestTimings(c);
@@ -559,7 +669,7 @@ int rt_get_counters(rt_ctx* c, rt_counters* out)
   if(!c || !out) return RT_ERR_INVALID_ARG;
   memset(out, 0, sizeof(*out));
   RT_HIP(c, hipSetDevice(c->device));
-  RT_HIP(c, hipStreamSynchronize(c->stream));
+  RT_HIP(c, syncAll(c));
   unsigned long long h[8];
   RT_HIP(c, hipMemcpy(h, c->dCounters, sizeof(h), hipMemcpyDeviceToHost));
   out->closestHitRays = h[0]; out->anyHitRays = h[1]; out->nodesVisited = h[2]; out->trisTested = h[3]; out->hitsShaded = h[4]; out->risCandidates = h[5];
@@ -585,7 +695,7 @@ int rt_history_miss(rt_ctx* c, int* missed)
   uint32_t v = 0;
   RT_HIP(c, hipMemcpyAsync(&v, c->scratch.qcount + 250, sizeof(v), hipMemcpyDeviceToHost, c->stream));
   RT_HIP(c, hipMemsetAsync(c->scratch.qcount + 250, 0, sizeof(v), c->stream));
-  RT_HIP(c, hipStreamSynchronize(c->stream));
+  RT_HIP(c, syncAll(c));
   *missed = v ? 1 : 0;
   return RT_OK;
 }
@@ -594,6 +704,15 @@ int rt_set_pipeline(rt_ctx* c, int pipeline)
 {
   if(!c || pipeline < 0 || pipeline > 1) return RT_ERR_INVALID_ARG;
   c->pipeline = pipeline;
+  return RT_OK;
+}
+
+int rt_set_overlap(rt_ctx* c, int mode)
+{
+  if(!c || mode < 0 || mode > 2) return RT_ERR_INVALID_ARG;
+  RT_HIP(c, hipSetDevice(c->device));
+  RT_HIP(c, syncAll(c));
+  c->overlap = mode;
   return RT_OK;
 }
 

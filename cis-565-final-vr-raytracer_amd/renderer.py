@@ -15,7 +15,7 @@ _lib = None
 # every symbol include/rt_abi.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_build_accel", "rt_resize", "rt_set_camera",
                "rt_render_frame", "rt_run_stage", "rt_readback", "rt_upload_history", "rt_buffer_bytes", "rt_device_ptr",
-               "rt_set_counting", "rt_get_counters", "rt_sync", "rt_last_error", "rt_abi_version", "rt_set_pipeline", "rt_set_history_rows", "rt_history_miss"]
+               "rt_set_counting", "rt_get_counters", "rt_sync", "rt_last_error", "rt_abi_version", "rt_set_pipeline", "rt_set_history_rows", "rt_history_miss", "rt_set_overlap"]
 
 
 def hip_lib():
@@ -51,6 +51,7 @@ def hip_lib():
         L.rt_device_ptr.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         L.rt_set_counting.argtypes = [C.c_void_p, C.c_int]
         L.rt_set_pipeline.argtypes = [C.c_void_p, C.c_int]
+        L.rt_set_overlap.argtypes = [C.c_void_p, C.c_int]
         L.rt_set_history_rows.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.rt_history_miss.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.rt_get_counters.argtypes = [C.c_void_p, C.c_void_p]
@@ -151,6 +152,10 @@ class Renderer:
 
     def set_pipeline(self, wavefront=True):
         self._chk(hip_lib().rt_set_pipeline(self._h, 1 if wavefront else 0), "rt_set_pipeline")
+
+    def set_overlap(self, mode):
+        """0 = serial launches, 1 = direct A-Trous beside the indirect stage, 2 = 1 + frames in flight (default)."""
+        self._chk(hip_lib().rt_set_overlap(self._h, int(mode)), "rt_set_overlap")
 
     def set_history_rows(self, row0, row1):
         self._chk(hip_lib().rt_set_history_rows(self._h, row0, row1), "rt_set_history_rows")

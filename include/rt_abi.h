@@ -333,6 +333,16 @@ int rt_history_miss(rt_ctx* ctx, int* missed);
  * measured), 1 = wavefront (lean trace kernels + shading kernels with ray compaction).  Outputs are bit-identical; this is
  * an A/B performance switch (also settable with the environment variable RESTIR_PIPELINE=fused|wavefront before rt_create). */
 int rt_set_pipeline(rt_ctx* ctx, int pipeline);
+/* Stream-level concurrency of rt_render_frame (results are identical in every mode):
+ *   0 = every launch of Renderer::run's list (renderer.cpp:163-205) in order on the ctx stream;
+ *   1 = the direct A-Trous chain runs beside the indirect stage on an internal stream and joins before compose;
+ *   2 = (default) 1 + frames in flight: the call returns after enqueueing and the next frame's direct stage runs beside
+ *       this frame's indirect stage and filters (internally triple-buffered G-buffer, double-buffered motion vectors).
+ *       Throughput mode of a renderer that keeps submitting; one frame's latency is higher than in mode 1.
+ * rt_sync / rt_readback / rt_get_counters wait for everything in flight.  In mode 2, rt_device_ptr results for the
+ * G-buffers and the motion buffer are invalidated by rt_render_frame (rt_run_stage never rotates buffers).
+ * Also settable with RESTIR_OVERLAP=0|1|2 before rt_create. */
+int rt_set_overlap(rt_ctx* ctx, int mode);
 /* Wait for all work on the ctx stream. */
 int rt_sync(rt_ctx* ctx);
 /* Last error message of this ctx (or of rt_create when ctx == NULL). Never NULL. */

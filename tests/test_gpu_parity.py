@@ -82,6 +82,28 @@ def test_gltf_file_scene_bit_exact(wavefront):
     assert (g != g.flat[0]).any()                            # the camera from the file sees geometry
 
 
+def test_back_to_back_frames_vs_oracle():
+    """Frames submitted without any synchronisation in between (the pipelined path of rt_render_frame) against the oracle."""
+    W, H = 320, 180
+    sc, env = make_scene(abi.PROC_SPONZA, 0.02, 1, (512, 256))
+    st = host.default_state(W, H, sc, env)
+    o, r = _pair(sc, env, W, H, wavefront=False)
+    gpu = RendererBackend(r)
+    eye, center, up, fov = sc.cameraPose()
+    sc.updateCamera(W, H)
+    N = 6
+    for f in range(N):
+        st.time = 1000 + f
+        sc.setCamera(eye + np.array([0.04 * f, 0.01 * f, -0.03 * f], dtype=np.float32), center, up, fov)
+        sc.updateCamera(W, H)
+        cam = sc.getCamera()
+        o.set_camera(cam); gpu.set_camera(cam)
+        o.render_frame(st, f); gpu.render_frame(st, f)
+    cmp = compare_buffers(o, gpu, frame_buffers(N - 1) + [abi.BUF_GBUFFER0 + (N & 1), abi.BUF_DIRECT_RESV0 + (N & 1), abi.BUF_INDIRECT_RESV0 + (N & 1)])
+    bad = {k: v for k, v in cmp.items() if v[0]}
+    assert not bad, bad
+
+
 def test_cornell_config2_di_only_512():
     """BASELINE config 2: Cornell box 512x512, ReSTIR DI only (temporal, M=4, clamp 80), time = 1000+frame, 8 frames."""
     W = H = 512
