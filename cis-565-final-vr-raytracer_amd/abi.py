@@ -32,6 +32,18 @@ class SceneDesc(C.Structure):  # rt_scene_desc
                 ("puncLights", C.c_void_p), ("trigLights", C.c_void_p), ("lightInfo", LightBufInfo),
                 ("envWidth", C.c_int32), ("envHeight", C.c_int32), ("envRgba32f", C.c_void_p), ("envAccel", C.c_void_p)]
 
+class Tonemapper(C.Structure):  # rt_tonemapper (host_device.h:336-351); defaults = RenderOutput::m_tm (render_output.hpp:44-55)
+    _fields_ = [("brightness", C.c_float), ("contrast", C.c_float), ("saturation", C.c_float), ("vignette", C.c_float), ("avgLum", C.c_float), ("zoom", C.c_float),
+                ("renderingRatio", C.c_float * 2), ("autoExposure", C.c_int32), ("Ywhite", C.c_float), ("key", C.c_float), ("pad", C.c_int32)]
+
+    def __init__(self, **kw):
+        super().__init__()
+        self.brightness = self.contrast = self.saturation = 1.0; self.vignette = 0.0; self.avgLum = 1.0; self.zoom = 1.0
+        self.renderingRatio[0] = self.renderingRatio[1] = 1.0; self.autoExposure = 0; self.Ywhite = 0.5; self.key = 0.5
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+assert C.sizeof(Tonemapper) == 48
 RT_STAGE_COUNT = 7
 class Counters(C.Structure):  # rt_counters
     _fields_ = [("closestHitRays", C.c_uint64), ("anyHitRays", C.c_uint64), ("nodesVisited", C.c_uint64), ("trisTested", C.c_uint64),
@@ -42,10 +54,10 @@ assert C.sizeof(SceneCamera) == 336 and C.sizeof(RtxState) == 100
 # rt_buffer_id
 (BUF_GBUFFER0, BUF_GBUFFER1, BUF_MOTION, BUF_DIRECT_RESV0, BUF_DIRECT_RESV1, BUF_DIRECT_RESV_TEMP, BUF_INDIRECT_RESV0,
  BUF_INDIRECT_RESV1, BUF_INDIRECT_RESV_TEMP, BUF_DENOISE_DIR_A, BUF_DENOISE_DIR_B, BUF_DENOISE_IND_A, BUF_DENOISE_IND_B,
- BUF_DIRECT_RESULT0, BUF_DIRECT_RESULT1, BUF_INDIRECT_RESULT0, BUF_INDIRECT_RESULT1, BUF_LIGHT_ID0, BUF_LIGHT_ID1, BUF_COUNT) = range(20)
+ BUF_DIRECT_RESULT0, BUF_DIRECT_RESULT1, BUF_INDIRECT_RESULT0, BUF_INDIRECT_RESULT1, BUF_LIGHT_ID0, BUF_LIGHT_ID1, BUF_LDR, BUF_COUNT) = range(21)
 BUFFER_NAMES = ["gbuffer0", "gbuffer1", "motion", "direct_resv0", "direct_resv1", "direct_resv_temp", "indirect_resv0", "indirect_resv1",
                 "indirect_resv_temp", "denoise_dir_a", "denoise_dir_b", "denoise_ind_a", "denoise_ind_b", "direct_result0", "direct_result1",
-                "indirect_result0", "indirect_result1", "light_id0", "light_id1"]
+                "indirect_result0", "indirect_result1", "light_id0", "light_id1", "ldr"]
 # rt_stage_id
 (STAGE_DIRECT, STAGE_INDIRECT, STAGE_DENOISE_DIRECT, STAGE_DENOISE_INDIRECT, STAGE_COMPOSE, STAGE_DIRECT_GEN, STAGE_DIRECT_REUSE) = range(7)
 # rt_restir_state

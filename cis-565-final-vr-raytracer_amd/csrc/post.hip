@@ -1,0 +1,123 @@
+// post.hip — the display pass: shaders/post.frag:103-175 + tonemapping.glsl:25-105 as compute kernels writing RGBA8.
+//   k_post_rowsum / k_post_mean  image mean for auto-exposure (stands in for textureLod(.., 20) on the mip pyramid that
+//                                RenderOutput::genMipmap builds, render_output.cpp:243-254)
+//   k_tonemap                    one thread per output pixel
+// Arithmetic follows include/rt_detmath.h (rt_pow for every pow) and the left-to-right evaluation rule, like every other stage.
+#include "stage_common.h"
+
+namespace rt {
+
+// Mean in a fixed association order (double precision): lane L of a row accumulates x = L, L+64, ... ; lane 0 adds the 64
+// partial sums in lane order; one thread adds the rows top to bottom.
+__global__ __launch_bounds__(64) void k_post_rowsum(const float4* direct, const float4* indirect, int W, int H, double* rowSums)
+{
+  __shared__ double part[64][3];
+  const int y = int(blockIdx.x) % H, img = int(blockIdx.x) / H, lane = int(threadIdx.x);
+  const float4* src = (img ? indirect : direct) + size_t(y) * W;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for(int x = lane; x < W; x += 64) { const float4 v = src[x]; s0 += double(v.x); s1 += double(v.y); s2 += double(v.z); }
+  part[lane][0] = s0; part[lane][1] = s1; part[lane][2] = s2;
+  __syncthreads();
+  if(lane == 0) {
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+    for(int l = 0; l < 64; l++) { t0 += part[l][0]; t1 += part[l][1]; t2 += part[l][2]; }
+    double* o = rowSums + (size_t(img) * H + y) * 3;
+    o[0] = t0; o[1] = t1; o[2] = t2;
+  }
+}
+__global__ void k_post_mean(const double* rowSums, int W, int H, float* mean /* [2][4] */)
+{
+  const int img = int(threadIdx.x) / 3, ch = int(threadIdx.x) % 3;
+  if(img >= 2) return;
+  double t = 0.0;
+  for(int y = 0; y < H; y++) t += rowSums[(size_t(img) * H + y) * 3 + ch];
+  mean[img * 4 + ch] = float(t / (double(W) * double(H)));
+}
+
+RT_DEV f3 pow3(f3 c, float e) { return mk3(rt_pow(c.x, e), rt_pow(c.y, e), rt_pow(c.z, e)); }
+RT_DEV f3 linearTosRGB(f3 c) { return pow3(c, 1.0f / 2.2f); }  // tonemapping.glsl:25-33
+RT_DEV f3 sRGBToLinear(f3 c) { return pow3(c, 2.2f); }         // :37-40
+RT_DEV f3 uncharted2Impl(f3 color)                             // :50-59
+{
+  const float A = 0.15f, B = 0.50f, C = 0.10f, D = 0.20f, E = 0.02f, F = 0.30f;
+  return ((color * (color * A + C * B) + D * E) / (color * (color * A + B) + D * F)) + (-(E / F));  // x - c == x + (-c) in IEEE arithmetic
+}
+RT_DEV f3 toneMapUncharted(f3 color)  // :61-67
+{
+  color = uncharted2Impl(color * 2.0f);
+  const f3 whiteScale = mk3(1.0f) / uncharted2Impl(mk3(11.2f));
+  return linearTosRGB(color * whiteScale);
+}
+RT_DEV float postLuminance(f3 c) { return (c.x * 0.2126f + c.y * 0.7152f) + c.z * 0.0722f; }  // post.frag:59-61
+RT_DEV f3 toneExposure(const rt_tonemapper& tm, f3 RGB, float logAvgLum)                       // post.frag:63-68
+{
+  const float XYZy = (0.3575761f * RGB.x + 0.7151522f * RGB.y) + 0.1191920f * RGB.z;  // second row of the column-major RGB2XYZ (post.frag:58)
+  const float Y = (tm.key / logAvgLum) * XYZy;
+  const float Yd = (Y * (1.0f + Y / (tm.Ywhite * tm.Ywhite))) / (1.0f + Y);
+  return RGB / XYZy * Yd;
+}
+RT_DEV f3 ditherColor(f3 linear, f3 noise, float quant)  // post.frag:50-55
+{
+  const f3 s = linearTosRGB(linear) / quant;
+  const f3 c0 = mk3(rt_floor(s.x), rt_floor(s.y), rt_floor(s.z)) * quant;
+  const f3 c1 = c0 + quant;
+  const f3 a = sRGBToLinear(c0), b = sRGBToLinear(c1);
+  const f3 discr = mk3(a.x * (1.0f - noise.x) + b.x * noise.x, a.y * (1.0f - noise.y) + b.y * noise.y, a.z * (1.0f - noise.z) + b.z * noise.z);
+  return mk3(discr.x < linear.x ? c1.x : c0.x, discr.y < linear.y ? c1.y : c0.y, discr.z < linear.z ? c1.z : c0.z);
+}
+RT_DEV uint32_t toUnorm8(float c) { return rt_ftou(rt_floor(rt_clamp(c, 0.0f, 1.0f) * 255.0f + 0.5f)); }
+
+__global__ __launch_bounds__(256) void k_tonemap(const float4* direct, const float4* indirect, const float* mean, rt_tonemapper tm, int dbg, int W, int H, uint32_t* ldr)
+{
+  const int x = int(blockIdx.x * 64 + (threadIdx.x & 63)), y = int(blockIdx.y * 4 + (threadIdx.x >> 6));
+  if(x >= W || y >= H) return;
+  const float u = (float(x) + 0.5f) / float(W), v = (float(y) + 0.5f) / float(H);
+  const int sx = min(max(rt_ftoi(u * tm.zoom * float(W)), 0), W - 1), sy = min(max(rt_ftoi(v * tm.zoom * float(H)), 0), H - 1);
+  const float4 D = direct[size_t(sy) * W + sx], I = indirect[size_t(sy) * W + sx];
+  f3 color;
+  if(dbg == RT_DBG_DEPTH) {  // post.frag:106-112
+    float depth = D.w;
+    depth *= rt_pow(2.0f, tm.brightness);
+    depth += tm.saturation;
+    depth = rt_clamp(rt_pow(depth, 1.0f / tm.contrast), 0.0f, 1.0f);
+    color = mk3(depth);
+  } else if(dbg > RT_DBG_INDIRECT_STAGE) {  // :113-118
+    color = mk3(D.x, D.y, D.z);
+    if(dbg == RT_DBG_BASECOLOR) { const f3 p = pow3(color, 0.45454545454545f); color = mk3(rt_clamp(p.x, 0.f, 1.f), rt_clamp(p.y, 0.f, 1.f), rt_clamp(p.z, 0.f, 1.f)); }
+  } else {
+    f3 hdr = (dbg == RT_DBG_DIRECT_STAGE) ? mk3(D.x, D.y, D.z) : (dbg == RT_DBG_INDIRECT_STAGE) ? mk3(I.x, I.y, I.z) : mk3(D.x + I.x, D.y + I.y, D.z + I.z);
+    if(tm.autoExposure & 1) {  // :133-153
+      const f3 aD = mk3(mean[0], mean[1], mean[2]), aI = mk3(mean[4], mean[5], mean[6]);
+      const f3 avg = (dbg == RT_DBG_DIRECT_STAGE) ? aD : (dbg == RT_DBG_INDIRECT_STAGE) ? aI : aD + aI;
+      hdr = toneExposure(tm, hdr, postLuminance(avg));
+    }
+    color = toneMapUncharted(hdr * tm.avgLum);  // toneMap(), tonemapping.glsl:89-105 with TONEMAP_UNCHARTED
+    uint32_t rx = uint32_t(x) * 1664525u + 1013904223u, ry = uint32_t(y) * 1664525u + 1013904223u, rz = 1013904223u;  // pcg3d, random.glsl:81-92
+    rx += ry * rz; ry += rz * rx; rz += rx * ry;
+    rx ^= rx >> 16; ry ^= ry >> 16; rz ^= rz >> 16;
+    rx += ry * rz; ry += rz * rx; rz += rx * ry;
+    const f3 noise = mk3(rt_u2f(0x3f800000u | (rx >> 9)) - 1.0f, rt_u2f(0x3f800000u | (ry >> 9)) - 1.0f, rt_u2f(0x3f800000u | (rz >> 9)) - 1.0f);
+    color = ditherColor(sRGBToLinear(color), noise, 1.0f / 255.0f);
+    color = mk3(0.5f) * (1.0f - tm.contrast) + color * tm.contrast;  // mix(vec3(0.5), color, contrast)
+    color = mk3(rt_clamp(color.x, 0.f, 1.f), rt_clamp(color.y, 0.f, 1.f), rt_clamp(color.z, 0.f, 1.f));
+    color = pow3(color, 1.0f / tm.brightness);
+    const float i = (color.x * 0.299f + color.y * 0.587f) + color.z * 0.114f;
+    color = mk3(i) * (1.0f - tm.saturation) + color * tm.saturation;
+    const float ux = ((u * tm.renderingRatio.x) - 0.5f) * 2.0f, uy = ((v * tm.renderingRatio.y) - 0.5f) * 2.0f;
+    color *= 1.0f - (ux * ux + uy * uy) * tm.vignette;
+  }
+  ldr[size_t(y) * W + x] = toUnorm8(color.x) | (toUnorm8(color.y) << 8) | (toUnorm8(color.z) << 16) | 0xff000000u;
+}
+
+hipError_t launchTonemap(hipStream_t stream, const float4* direct, const float4* indirect, double* rowSums, float* mean, const rt_tonemapper& tm, int dbg, int W, int H,
+                         uint32_t* ldr)
+{
+  if(tm.autoExposure & 1) {
+    hipLaunchKernelGGL(k_post_rowsum, dim3(unsigned(2 * H)), dim3(64), 0, stream, direct, indirect, W, H, rowSums);
+    hipLaunchKernelGGL(k_post_mean, dim3(1), dim3(64), 0, stream, (const double*)rowSums, W, H, mean);
+  }
+  hipLaunchKernelGGL(k_tonemap, dim3(unsigned((W + 63) / 64), unsigned((H + 3) / 4)), dim3(256), 0, stream, direct, indirect, (const float*)mean, tm, dbg, W, H, ldr);
+  return hipGetLastError();
+}
+
+}  // namespace rt

@@ -183,7 +183,7 @@ static size_t elemBytes(int id)
     case RT_BUF_MOTION: return 4;
     case RT_BUF_DIRECT_RESV0: case RT_BUF_DIRECT_RESV1: case RT_BUF_DIRECT_RESV_TEMP: return sizeof(rt_direct_reservoir);
     case RT_BUF_INDIRECT_RESV0: case RT_BUF_INDIRECT_RESV1: case RT_BUF_INDIRECT_RESV_TEMP: return sizeof(rt_indirect_reservoir);
-    case RT_BUF_LIGHT_ID0: case RT_BUF_LIGHT_ID1: return 4;
+    case RT_BUF_LIGHT_ID0: case RT_BUF_LIGHT_ID1: case RT_BUF_LDR: return 4;
     default: return 16;
   }
 }
@@ -449,6 +449,7 @@ int rt_resize(rt_ctx* c, int w, int h)
   RT_SCRATCH(rayAO, nh, float4); RT_SCRATCH(rayAD, nh, float4); RT_SCRATCH(occH, nh, uint32_t);
   RT_SCRATCH(qC[0], nh, uint32_t); RT_SCRATCH(qC[1], nh, uint32_t); RT_SCRATCH(qA, nh, uint32_t); RT_SCRATCH(qcount, 256, uint32_t);
   RT_SCRATCH(geomN, n, float4); RT_SCRATCH(geomP, n, float4); RT_SCRATCH(geomNh, nh, float4); RT_SCRATCH(geomPh, nh, float4);
+  RT_SCRATCH(postRowSums, size_t(h) * 6, double); RT_SCRATCH(postMean, 8, float);
   RT_SCRATCH(tileOrder, (size_t(w / 2 + 7) / 8) * (size_t(h / 2 + 7) / 8 + 16 * 2) + 64, uint32_t);
 #undef RT_SCRATCH
   RT_HIP(c, hipDeviceSynchronize());  // memsets above ran on the null stream; the ctx stream does not wait for it implicitly
@@ -485,7 +486,7 @@ static DevFrame makeFrame(rt_ctx* c, int frames)
   F.status = X.status; F.shadowQ = X.shadowQ; F.path = X.path; F.rayCO = X.rayCO; F.rayCD = X.rayCD; F.hitC = X.hitC; F.rayAO = X.rayAO;
   F.rayAD = X.rayAD; F.occH = X.occH; F.qC[0] = X.qC[0]; F.qC[1] = X.qC[1]; F.qA = X.qA; F.qcount = X.qcount;
   F.histRow0 = c->histRow0; F.histRow1 = c->histRow1; F.histMiss = X.qcount + 250;
-  F.geomN = X.geomN; F.geomP = X.geomP; F.geomNh = X.geomNh; F.geomPh = X.geomPh; F.tileOrder = X.tileOrder;
+  F.geomN = X.geomN; F.geomP = X.geomP; F.geomNh = X.geomNh; F.geomPh = X.geomPh; F.tileOrder = X.tileOrder; F.postRowSums = X.postRowSums; F.postMean = X.postMean;
   return F;
 }
 
@@ -704,6 +705,18 @@ int rt_set_pipeline(rt_ctx* c, int pipeline)
 {
   if(!c || pipeline < 0 || pipeline > 1) return RT_ERR_INVALID_ARG;
   c->pipeline = pipeline;
+  return RT_OK;
+}
+
+int rt_tonemap(rt_ctx* c, const rt_tonemapper* tm, int debugging_mode, int frames)
+{
+  if(!c || !tm) return RT_ERR_INVALID_ARG;
+  if(c->W == 0) return fail(c, RT_ERR_NO_TARGET, "rt_tonemap: rt_resize has not been called");
+  RT_HIP(c, hipSetDevice(c->device));
+  RT_HIP(c, joinInFlight(c));  // the result images of `frames` are complete once compose (side stream) is done
+  const int cur = frames & 1;
+  RT_HIP(c, launchTonemap(c->stream, static_cast<const float4*>(c->bufs[RT_BUF_DIRECT_RESULT0 + cur]), static_cast<const float4*>(c->bufs[RT_BUF_INDIRECT_RESULT0 + cur]),
+                          c->scratch.postRowSums, c->scratch.postMean, *tm, debugging_mode, c->W, c->H, static_cast<uint32_t*>(c->bufs[RT_BUF_LDR])));
   return RT_OK;
 }
 

@@ -9,4 +9,7 @@ hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F,
 // the same dispatch entry as a sequence of lean trace kernels + shading kernels with ray compaction (wavefront.hip)
 hipError_t launchStageWavefront(hipStream_t stream, const DevScene& S, const DevFrame& F, const rt_state& st, const rt_scene_camera& cam, int stage, int level,
                                 int rowBegin, int rowEnd);
+// RenderOutput::run + post.frag as compute (post.hip)
+hipError_t launchTonemap(hipStream_t stream, const float4* direct, const float4* indirect, double* rowSums, float* mean, const rt_tonemapper& tm, int dbg, int W, int H,
+                         uint32_t* ldr);
 }

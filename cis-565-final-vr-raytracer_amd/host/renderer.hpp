@@ -65,4 +65,32 @@ class Renderer {
   int m_width = 0, m_height = 0;
 };
 
+// src/render_output.hpp:37-73: the display pass.  run() is the fullscreen post.frag draw (render_output.cpp:224-237) as a
+// compute pass into an RGBA8 image; the two HDR result images themselves live in the context (RT_BUF_*_RESULT*).
+class RenderOutput {
+ public:
+  rt_tonemapper m_tm{1.0f, 1.0f, 1.0f, 0.0f, 1.0f, 1.0f, {1.0f, 1.0f}, 0, 0.5f, 0.5f, 0};      // render_output.hpp:44-55
+  rt_tonemapper m_depthTm{0.0f, 2.2f, 0.0f, 0.0f, 0.0f, 0.0f, {0.0f, 0.0f}, 0, 0.0f, 0.0f, 0};  // render_output.hpp:56-60
+  void setup(rt_ctx* ctx) { m_ctx = ctx; }
+  void create(int width, int height) { update(width, height); }
+  void update(int width, int height) { m_width = width; m_height = height; }
+  void destroy() {}
+  bool run(const rt_state& state, float zoom, rt_vec2 ratio, int frames)
+  {
+    rt_tonemapper tm = (state.debugging_mode == RT_DBG_DEPTH) ? m_depthTm : m_tm;  // render_output.cpp:228-230
+    tm.zoom = zoom; tm.renderingRatio = ratio;
+    if(rt_tonemap(m_ctx, &tm, state.debugging_mode, frames) != RT_OK) { fprintf(stderr, "RenderOutput::run: %s\n", rt_last_error(m_ctx)); return false; }
+    return true;
+  }
+  // the image the reference presents: RGBA8, row-major, top row first
+  bool readImage(std::vector<uint8_t>& rgba)
+  {
+    rgba.resize(size_t(m_width) * m_height * 4);
+    return rt_readback(m_ctx, RT_BUF_LDR, rgba.data(), rgba.size()) == RT_OK;
+  }
+ private:
+  rt_ctx* m_ctx = nullptr;
+  int m_width = 0, m_height = 0;
+};
+
 }  // namespace rth

@@ -2,7 +2,7 @@
 //   loadEnvironmentHdr -> loadScene (Scene::load + AccelStructure::create) -> createRender -> per frame:
 //   updateFrame / Scene::updateCamera -> Renderer::run -> (post.frag's sum of the two HDR images, written to disk)
 // Usage mirrors main.cpp:52-54:  restir_demo [-f scene.gltf | -p cornell|helmet|sponza|bistro|interior] [-e env.hdr]
-//                                            [-w 1920] [-h 1080] [-n frames] [-o out] [-s scale]
+//                                            [-w 1920] [-h 1080] [-n frames] [-o out] [-s scale] [-a autoExposure]
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -71,16 +71,21 @@ int main(int argc, char** argv)
 
   std::vector<float> d, i;
   if(!render.readResult(frames - 1, d, i)) return 6;
-  {  // PFM (bottom-up scanlines, little endian) of direct + indirect, and an Uncharted-free Reinhard PPM preview
-    std::ofstream pfm(out + ".pfm", std::ios::binary), ppm(out + ".ppm", std::ios::binary);
+  {  // PFM (bottom-up scanlines, little endian) of direct + indirect = the HDR frame
+    std::ofstream pfm(out + ".pfm", std::ios::binary);
     pfm << "PF\n" << W << " " << H << "\n-1.0\n";
-    ppm << "P6\n" << W << " " << H << "\n255\n";
     for(int y = H - 1; y >= 0; y--) for(int x = 0; x < W; x++) { float c[3]; for(int k = 0; k < 3; k++) c[k] = d[(size_t(y) * W + x) * 4 + k] + i[(size_t(y) * W + x) * 4 + k]; pfm.write(reinterpret_cast<const char*>(c), 12); }
-    for(int y = 0; y < H; y++) for(int x = 0; x < W; x++) for(int k = 0; k < 3; k++) {
-      float v = d[(size_t(y) * W + x) * 4 + k] + i[(size_t(y) * W + x) * 4 + k];
-      v = std::pow(std::fmax(v / (1.f + v), 0.f), 1.f / 2.2f);
-      ppm.put(char((unsigned char)(std::fmin(v, 1.f) * 255.f + 0.5f)));
-    }
+  }
+  {  // the displayed frame: RenderOutput::run (post.frag: Uncharted 2 tone curve + dither) -> PPM
+    RenderOutput offscreen;
+    offscreen.setup(render.context());
+    offscreen.create(W, H);
+    offscreen.m_tm.autoExposure = atoi(arg(argc, argv, "-a", "0"));
+    std::vector<uint8_t> rgba;
+    if(!offscreen.run(st, 1.0f, rt_vec2{1.0f, 1.0f}, frames - 1) || !offscreen.readImage(rgba)) return 7;
+    std::ofstream ppm(out + ".ppm", std::ios::binary);
+    ppm << "P6\n" << W << " " << H << "\n255\n";
+    for(size_t p = 0; p < size_t(W) * H; p++) ppm.write(reinterpret_cast<const char*>(&rgba[p * 4]), 3);
   }
   render.destroy();
   return 0;

@@ -154,6 +154,13 @@ typedef struct {
   rt_vec3 pad;
 } rt_trig_light;
 
+/* host_device.h:336-351 — 48 B; push constant of post.frag together with debugging_mode (render_output.hpp:40-43) */
+typedef struct {
+  float brightness, contrast, saturation, vignette;
+  float avgLum, zoom; rt_vec2 renderingRatio;
+  int32_t autoExposure; float Ywhite, key; int32_t pad;
+} rt_tonemapper;
+
 /* host_device.h:327-333 — 16 B */
 typedef struct { uint32_t puncLightSize; uint32_t trigLightSize; float trigSampProb; int32_t pad; } rt_light_buf_info;
 
@@ -244,7 +251,8 @@ typedef enum {
                                  0xffffffff none).  Added for the "reservoir sample indices bit-exact" check of
                                  BASELINE.json; the reference stores the sample itself, not an index. */
   RT_BUF_LIGHT_ID1 = 18,
-  RT_BUF_COUNT = 19
+  RT_BUF_LDR = 19,            /* RGBA8 UNORM 4 B/px (R in the low byte): output of rt_tonemap = the swapchain image post.frag draws */
+  RT_BUF_COUNT = 20
 } rt_buffer_id;
 
 /* per-frame stage selector for rt_run_stage — the dispatch list of renderer.cpp:163-205 */
@@ -332,6 +340,14 @@ int rt_history_miss(rt_ctx* ctx, int* missed);
 /* Kernel organisation of the direct / indirect stages: 0 = one fused kernel per reference stage (default, the fastest
  * measured), 1 = wavefront (lean trace kernels + shading kernels with ray compaction).  Outputs are bit-identical; this is
  * an A/B performance switch (also settable with the environment variable RESTIR_PIPELINE=fused|wavefront before rt_create). */
+/* RenderOutput::run (render_output.cpp:224-237) + post.frag:103-175 as a compute pass: reads the two result images of
+ * frame `frames` (RT_BUF_DIRECT_RESULT0/INDIRECT_RESULT0 + (frames & 1)), applies auto-exposure (tonemapping by the image
+ * mean, post.frag:133-153), the Uncharted-2 tone curve (tonemapping.glsl:48-66), dithering (post.frag:50-55), contrast /
+ * brightness / saturation / vignette (post.frag:163-171) or the debug views (post.frag:106-118) and writes RT_BUF_LDR.
+ * Differences from the fragment shader, all documented in DESIGN.md: the image mean replaces the driver-generated mip
+ * pyramid's top level; tm.zoom samples the nearest texel; the "local" auto-exposure bit (autoExposure & 2, which reads an
+ * uninitialised variable in the reference, post.frag:92) uses the global operator. */
+int rt_tonemap(rt_ctx* ctx, const rt_tonemapper* tm, int debugging_mode, int frames);
 int rt_set_pipeline(rt_ctx* ctx, int pipeline);
 /* Stream-level concurrency of rt_render_frame (results are identical in every mode):
  *   0 = every launch of Renderer::run's list (renderer.cpp:163-205) in order on the ctx stream;
@@ -363,6 +379,7 @@ static_assert(sizeof(rt_impt_samp) == 16, "ImptSampData host_device.h:287-293");
 static_assert(sizeof(rt_punc_light) == 80, "PuncLight host_device.h:295-312");
 static_assert(sizeof(rt_trig_light) == 96, "TrigLight host_device.h:314-325");
 static_assert(sizeof(rt_light_buf_info) == 16, "LightBufInfo host_device.h:327-333");
+static_assert(sizeof(rt_tonemapper) == 48, "Tonemapper host_device.h:336-351");
 #endif
 
 #endif /* RT_ABI_H */

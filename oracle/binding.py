@@ -46,6 +46,7 @@ def lib():
         L.orc_upload_history.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         L.orc_get_counters.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_set_history_rows.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_tonemap.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.orc_history_miss.argtypes = [C.c_void_p]
         L.orc_buffer_ptr.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         for n in ["orc_trace_closest", "orc_trace_any", "orc_trace_closest_brute"]:
@@ -76,6 +77,8 @@ class Oracle:
     def render_frame(self, state, frames): self._chk(lib().orc_render_frame(self._h, C.byref(state), frames), "render_frame")
     def run_stage(self, state, frames, stage, level=0, row_begin=0, row_end=0):
         self._chk(lib().orc_run_stage(self._h, C.byref(state), frames, stage, level, row_begin, row_end), "run_stage")
+    def tonemap(self, tm, debugging_mode=0, frames=0):
+        self._chk(lib().orc_tonemap(self._h, C.byref(tm), debugging_mode, frames), "tonemap")
     def buffer_bytes(self, buf): return lib().orc_buffer_bytes(self._h, buf)
     def readback(self, buf):
         out = np.empty(self.buffer_bytes(buf), dtype=np.uint8)

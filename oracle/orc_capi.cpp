@@ -17,7 +17,7 @@ bool isHalfRes(int id) { return id == RT_BUF_INDIRECT_RESV0 || id == RT_BUF_INDI
 size_t elemSize(int id)
 {
   switch(id) {
-    case RT_BUF_MOTION: case RT_BUF_LIGHT_ID0: case RT_BUF_LIGHT_ID1: return 4;
+    case RT_BUF_MOTION: case RT_BUF_LIGHT_ID0: case RT_BUF_LIGHT_ID1: case RT_BUF_LDR: return 4;
     case RT_BUF_DIRECT_RESV0: case RT_BUF_DIRECT_RESV1: case RT_BUF_DIRECT_RESV_TEMP: return sizeof(rt_direct_reservoir);
     case RT_BUF_INDIRECT_RESV0: case RT_BUF_INDIRECT_RESV1: case RT_BUF_INDIRECT_RESV_TEMP: return sizeof(rt_indirect_reservoir);
     default: return 16;
@@ -47,6 +47,7 @@ void* bufPtr(Ctx* c, int id, size_t& bytes)
     case RT_BUF_INDIRECT_RESULT1: bytes = vbytes(f.indirectResult[1]); return f.indirectResult[1].data();
     case RT_BUF_LIGHT_ID0: bytes = vbytes(f.lightId2[0]); return f.lightId2[0].data();
     case RT_BUF_LIGHT_ID1: bytes = vbytes(f.lightId2[1]); return f.lightId2[1].data();
+    case RT_BUF_LDR: bytes = vbytes(f.ldr); return f.ldr.data();
   }
   bytes = 0;
   return nullptr;
@@ -135,6 +136,13 @@ int orc_get_counters(void* p, rt_counters* out)
   out->closestHitRays = c->scene.counters.closestHitRays; out->anyHitRays = c->scene.counters.anyHitRays;
   out->nodesVisited = c->scene.counters.nodesVisited; out->trisTested = c->scene.counters.trisTested;
   out->hitsShaded = c->scene.counters.hitsShaded; out->risCandidates = c->scene.counters.risCandidates;
+  return RT_OK;
+}
+int orc_tonemap(void* p, const rt_tonemapper* tm, int dbg, int frames)
+{
+  Ctx* c = static_cast<Ctx*>(p);
+  if(!tm || c->frame.W == 0) return RT_ERR_INVALID_ARG;
+  c->frame.tonemap(*tm, dbg, frames);
   return RT_OK;
 }
 int orc_set_history_rows(void* p, int r0, int r1) { Ctx* c = static_cast<Ctx*>(p); c->frame.histRow0 = r0; c->frame.histRow1 = r1; return RT_OK; }

@@ -77,20 +77,7 @@ void Frame::resize(int w, int h)
   motion.assign(n * 2, 0);
   for(int i = 0; i < 4; i++) denoiseTemp[i].assign(n * 4, 0.0f);
   for(int i = 0; i < 2; i++) lightId2[i].assign(n, 0xffffffffu);
-}
-
-template <class F>
-void Frame::parallelRows(int rows, int rowBegin, int rowEnd, F&& fn) const
-{
-  if(rowEnd <= 0 || rowEnd > rows) rowEnd = rows;
-  if(rowBegin < 0) rowBegin = 0;
-  int nt = std::max(1, std::min(threads, rowEnd - rowBegin));
-  if(nt == 1) { for(int y = rowBegin; y < rowEnd; y++) fn(y); return; }
-  std::vector<std::thread> pool;
-  std::atomic<int> next{rowBegin};
-  for(int t = 0; t < nt; t++)
-    pool.emplace_back([&] { for(;;) { int y = next.fetch_add(1); if(y >= rowEnd) break; fn(y); } });
-  for(auto& th : pool) th.join();
+  ldr.assign(n, 0u);
 }
 
 // ------------------------------------------------------------------------------------------------------------

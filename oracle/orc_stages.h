@@ -1,6 +1,9 @@
 // orc_stages.h — CPU oracle frame state (screen-space buffers of renderer.cpp:227-302) and stage entry points.
 // TEST INFRASTRUCTURE, not product code.
 #pragma once
+#include <thread>
+#include <atomic>
+#include <algorithm>
 #include <atomic>
 #include <vector>
 #include "orc_shading.h"
@@ -24,6 +27,7 @@ struct Frame {
   std::vector<float> denoiseTemp[4];                // DirA, DirB, IndA, IndB (RGBA32F, full-res allocation)
   std::vector<float> directResult[2], indirectResult[2];
   std::vector<uint32_t> lightId2[2];
+  std::vector<uint32_t> ldr;                        // RGBA8 UNORM: rt_tonemap output
 
   std::vector<uint32_t>& lightId_cur(int cur) { return lightId2[cur]; }
   const std::vector<uint32_t>& lightId_last(int last) const { return lightId2[last]; }
@@ -39,6 +43,7 @@ struct Frame {
   void denoiseDirect(const rt_state& st, int frames, int level, int rowBegin, int rowEnd);
   void denoiseIndirect(const rt_state& st, int frames, int level, int rowBegin, int rowEnd);
   void compose(const rt_state& st, int frames, int rowBegin, int rowEnd);
+  void tonemap(const rt_tonemapper& tm, int debugging_mode, int frames);  // orc_post.cpp
 
   // image access
   uvec4 loadG(int which, ivec2 c) const;
@@ -59,5 +64,20 @@ struct Frame {
   vec3 waveletFilter(const rt_state& st, int cur, const std::vector<float>& inImage, ivec2 coord, vec3 norm, vec3 pos, uint32_t matHash,
                      float sigLumin, float sigNormal, float sigDepth, int level, bool indirect) const;
 };
+
+template <class F>
+void Frame::parallelRows(int rows, int rowBegin, int rowEnd, F&& fn) const
+{
+  if(rowEnd <= 0 || rowEnd > rows) rowEnd = rows;
+  if(rowBegin < 0) rowBegin = 0;
+  int nt = std::max(1, std::min(threads, rowEnd - rowBegin));
+  if(nt == 1) { for(int y = rowBegin; y < rowEnd; y++) fn(y); return; }
+  std::vector<std::thread> pool;
+  std::atomic<int> next{rowBegin};
+  for(int t = 0; t < nt; t++)
+    pool.emplace_back([&] { for(;;) { int y = next.fetch_add(1); if(y >= rowEnd) break; fn(y); } });
+  for(auto& th : pool) th.join();
+}
+
 
 }  // namespace orc
