@@ -196,12 +196,17 @@ __global__ __launch_bounds__(256) void k_ind_tile_order(rt_state st, int rowBegi
 }
 
 __global__ __launch_bounds__(64, 4) void k_indirect_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY, int cap,
-                                                          const uint32_t* lists, const uint32_t* counts)
+                                                          const uint32_t* lists, const uint32_t* counts, int subShift)
 {
+  // subShift > 0 (small launches: row bands of a multi-GPU frame, small images): a tile is split over 2 or 4 waves that own
+  // 32 / 16 of its pixels each; the other lanes of each wave have no path and only serve the wave's ray pool.  With fewer
+  // paths per wave the majority-vote loop runs fewer rounds per ray, and the idle SIMDs of an under-filled chip get work:
+  // the latency of the longest multi-bounce tile — the floor of a small launch — drops.  Results do not change.
   extern __shared__ uint2 s_stack[];
   TileCoord tile;
+  const int part = (int(blockIdx.x) >> 3) & ((1 << subShift) - 1);
   {
-    const int L = int(blockIdx.x), xcd = L & 7, k = L >> 3;
+    const int L = int(blockIdx.x), xcd = L & 7, k = (L >> 3) >> subShift;
     const int nf = int(counts[xcd * 2]), nb = int(counts[xcd * 2 + 1]);
     tile.valid = k < nf + nb;
     const uint32_t t = tile.valid ? lists[size_t(xcd) * cap + (k < nf ? k : cap - 1 - (k - nf))] : 0u;
@@ -210,18 +215,24 @@ __global__ __launch_bounds__(64, 4) void k_indirect_stage(DevScene S, DevFrame F
   if(!tile.valid) return;
   const int lane = int(threadIdx.x);
   const i2 indSize{st.size.x / 2, st.size.y / 2};
-  const i2 px{tile.x * 8 + (lane & 7), rowBegin + tile.y * 8 + (lane >> 3)};
+  const int rowsPerPart = 8 >> subShift;
+  const bool hasPixel = (lane >> 3) < rowsPerPart;
+  const i2 px{tile.x * 8 + (lane & 7), rowBegin + tile.y * 8 + part * rowsPerPart + (lane >> 3)};
   Ctx c(S, st, cam, s_stack + lane);
   c.imageCoords = px;
   c.seed = tea(uint32_t(indSize.x) * uint32_t(px.y) + uint32_t(px.x), st.time);  // :280
-  // TILED_MULTIBOUNCE (:283-288): invocation 0 of the workgroup draws the tile flag from its own stream; the tile is
-  // one wave64, so the flag is wave-uniform and costs one readfirstlane instead of shared memory + barrier.
+  // TILED_MULTIBOUNCE (:283-288): invocation 0 of the workgroup draws the tile flag from its own stream (and so advances
+  // it); the flag is wave-uniform here, so it costs one readfirstlane instead of shared memory + barrier.  Waves that own
+  // another part of the tile recompute the flag from a copy of that pixel's stream.
   int mb = 0;
-  if(lane == 0) mb = rnd(c.seed) < 0.25f ? 1 : 0;
+  if(lane == 0) {
+    if(part == 0) mb = rnd(c.seed) < 0.25f ? 1 : 0;
+    else { uint32_t s0 = tea(uint32_t(indSize.x) * uint32_t(rowBegin + tile.y * 8) + uint32_t(tile.x * 8), st.time); mb = rnd(s0) < 0.25f ? 1 : 0; }
+  }
   const bool multiBounce = __builtin_amdgcn_readfirstlane(mb) != 0;
   // Lanes without a pixel / without a surface stay in the kernel: they trace rays of the other lanes (tracePool).
   float4* pool = reinterpret_cast<float4*>(s_stack + size_t(S.stackEntries) * 64);
-  const bool inImage = !(px.x >= indSize.x || px.y >= indSize.y || px.y >= rowEnd);
+  const bool inImage = hasPixel && !(px.x >= indSize.x || px.y >= indSize.y || px.y >= rowEnd);
   Ray ray = c.raySpawn(px, indSize);
 
   GState g0; float depth;
@@ -511,8 +522,12 @@ hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F,
       // per-XCD tile lists: capacity = the tiles one XCD can own under the striped mapping
       const int cap = int(tileGrid(tilesX, tilesY) / 8);
       hipLaunchKernelGGL(k_ind_tile_order, dim3(8), dim3(256), 0, stream, st, rowBegin, tilesX, tilesY, cap, F.tileOrder, F.qcount + 192);
-      hipLaunchKernelGGL(k_indirect_stage, grid, block, lds + POOL_BYTES, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY, cap, (const uint32_t*)F.tileOrder,
-                         (const uint32_t*)(F.qcount + 192));
+      // under ~2 waves per SIMD (1024 SIMDs) the launch is latency bound: split tiles over more waves
+      static const int subEnv = getenv("RESTIR_IND_SUB") ? atoi(getenv("RESTIR_IND_SUB")) : -1;
+      const int nTiles = tilesX * tilesY;
+      const int subShift = subEnv >= 0 ? subEnv : (nTiles <= 1536 ? 2 : (nTiles <= 3072 ? 1 : 0));
+      hipLaunchKernelGGL(k_indirect_stage, dim3(grid.x << subShift), block, lds + POOL_BYTES, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY, cap,
+                         (const uint32_t*)F.tileOrder, (const uint32_t*)(F.qcount + 192), subShift);
       break;
     }
     case RT_STAGE_DENOISE_DIRECT: {
