@@ -44,6 +44,26 @@ class Tonemapper(C.Structure):  # rt_tonemapper (host_device.h:336-351); default
             setattr(self, k, v)
 
 assert C.sizeof(Tonemapper) == 48
+
+class SunAndSky(C.Structure):  # rt_sun_and_sky (host_device.h:353-377); defaults = SampleExample::m_sunAndSky (sample_example.hpp:186-203)
+    _fields_ = [("rgb_unit_conversion", C.c_float * 3), ("multiplier", C.c_float), ("haze", C.c_float), ("redblueshift", C.c_float), ("saturation", C.c_float),
+                ("horizon_height", C.c_float), ("ground_color", C.c_float * 3), ("horizon_blur", C.c_float), ("night_color", C.c_float * 3),
+                ("sun_disk_intensity", C.c_float), ("sun_direction", C.c_float * 3), ("sun_disk_scale", C.c_float), ("sun_glow_intensity", C.c_float),
+                ("y_is_up", C.c_int32), ("physically_scaled_sun", C.c_int32), ("in_use", C.c_int32)]
+
+    def __init__(self, **kw):
+        super().__init__()
+        self.rgb_unit_conversion[:] = [1, 1, 1]; self.multiplier = 0.0000101320; self.haze = 0.0; self.redblueshift = 0.0; self.saturation = 1.0
+        self.horizon_height = 0.0; self.ground_color[:] = [0.4, 0.4, 0.4]; self.horizon_blur = 0.1; self.night_color[:] = [0.0, 0.0, 0.01]
+        self.sun_disk_intensity = 0.8; self.sun_direction[:] = [0.0, 0.78, 0.62]; self.sun_disk_scale = 5.0; self.sun_glow_intensity = 1.0
+        self.y_is_up = 1; self.physically_scaled_sun = 1; self.in_use = 0
+        for k, v in kw.items():
+            if isinstance(v, (list, tuple)):
+                getattr(self, k)[:] = v
+            else:
+                setattr(self, k, v)
+
+assert C.sizeof(SunAndSky) == 96
 RT_STAGE_COUNT = 7
 class Counters(C.Structure):  # rt_counters
     _fields_ = [("closestHitRays", C.c_uint64), ("anyHitRays", C.c_uint64), ("nodesVisited", C.c_uint64), ("trisTested", C.c_uint64),

@@ -14,7 +14,7 @@ HOST_LIB = os.path.join(_HERE, "host", "librestir_host.so")
 # -ffp-contract=off + correctly rounded divide/sqrt: the bit-reproducibility rules of include/rt_detmath.h
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
              "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-unused-result", "-x", "hip"]
-HIP_SRC = ["rt_api.cpp", "bvh8_builder.cpp", "stages.hip", "wavefront.hip", "post.hip"]
+HIP_SRC = ["rt_api.cpp", "bvh8_builder.cpp", "stages.hip", "wavefront.hip", "stages_sky.hip", "wavefront_sky.hip", "post.hip"]
 HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-pthread"]
 HOST_SRC = ["scene.cpp", "scene_gen.cpp", "hdr_sampling.cpp", "gltf_loader.cpp", "host_capi.cpp"]
 

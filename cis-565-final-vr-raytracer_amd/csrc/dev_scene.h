@@ -38,6 +38,7 @@ struct DevScene {
   rt_light_buf_info lightInfo;
   int32_t envW, envH;
   uint32_t numTris, numNodes;
+  const struct SkyPre* sky;         // != nullptr: procedural sun & sky replaces the HDR map (_sunAndSky.in_use == 1)
   int32_t stackEntries;             // LDS traversal stack entries per lane for this tree (multiple of 4, >= max depth)
   int32_t pad0;
 };

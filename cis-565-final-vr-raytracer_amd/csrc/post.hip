@@ -109,6 +109,14 @@ __global__ __launch_bounds__(256) void k_tonemap(const float4* direct, const flo
   ldr[size_t(y) * W + x] = toUnorm8(color.x) | (toUnorm8(color.y) << 8) | (toUnorm8(color.z) << 16) | 0xff000000u;
 }
 
+__global__ void k_sky_prepare(rt_sun_and_sky ss, SkyPre* out) { if(threadIdx.x == 0 && blockIdx.x == 0) { SkyPre P; skyfn::prepare(ss, P); *out = P; } }
+
+hipError_t launchSkyPrepare(hipStream_t stream, const rt_sun_and_sky& ss, SkyPre* out)
+{
+  hipLaunchKernelGGL(k_sky_prepare, dim3(1), dim3(64), 0, stream, ss, out);
+  return hipGetLastError();
+}
+
 hipError_t launchTonemap(hipStream_t stream, const float4* direct, const float4* indirect, double* rowSums, float* mean, const rt_tonemapper& tm, int dbg, int W, int H,
                          uint32_t* ldr)
 {

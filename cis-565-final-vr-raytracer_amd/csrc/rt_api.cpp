@@ -27,6 +27,8 @@ struct rt_ctx {
   hipEvent_t evD[4] = {}, evI[4] = {}, evDone[4] = {};
   uint64_t seq = 0;          // frames submitted through the pipelined path since the last join
   bool inFlight = false;     // work may be pending on indStream / sideStream
+  void* dSky = nullptr;      // SkyPre (csrc/sky.h), valid while sunAndSky.in_use == 1
+  rt_sun_and_sky sunAndSky{};
   void* spareG = nullptr; void* spareMotion = nullptr;   // third G-buffer / second motion buffer (rotated per pipelined frame)
   int overlap = 2;           // 0 = one stream; 1 = direct A-Trous beside the indirect stage; 2 = 1 + consecutive frames overlap
   std::string err;
@@ -93,6 +95,13 @@ static hipError_t joinInFlight(rt_ctx* c)
   if(e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->evDone[r], 0);
   c->inFlight = false; c->seq = 0;
   return e;
+}
+
+typedef hipError_t (*StageLauncher)(hipStream_t, const DevScene&, const DevFrame&, const rt_state&, const rt_scene_camera&, int, int, int, int);
+static StageLauncher stageLauncher(const rt_ctx* c)
+{
+  if(c->ds.sky) return c->pipeline ? rt::sky::launchStageWavefront : rt::sky::launchStage;
+  return c->pipeline ? rt::base::launchStageWavefront : rt::base::launchStage;
 }
 
 static thread_local std::string g_createErr;
@@ -250,6 +259,7 @@ int rt_destroy(rt_ctx* c)
   if(c->indStream) (void)hipStreamDestroy(c->indStream);
   for(int i = 0; i < 4; i++) { if(c->evD[i]) (void)hipEventDestroy(c->evD[i]); if(c->evI[i]) (void)hipEventDestroy(c->evI[i]); if(c->evDone[i]) (void)hipEventDestroy(c->evDone[i]); }
   if(c->dCounters) (void)hipFree(c->dCounters);
+  if(c->dSky) (void)hipFree(c->dSky);
   for(auto& E : c->evSets) for(int i = 0; i < rt_ctx::MAX_EV; i++) (void)hipEventDestroy(E.ev[i]);
   if(c->ownStream) (void)hipStreamDestroy(c->ownStream);
   if(c->sideStream) (void)hipStreamDestroy(c->sideStream);
@@ -292,6 +302,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
   freePool(c->sceneAllocs); freePool(c->accelAllocs);
   c->haveScene = c->haveAccel = false;
   c->ds = DevScene{};
+  c->ds.sky = (c->sunAndSky.in_use == 1) ? static_cast<const SkyPre*>(c->dSky) : nullptr;
   c->primMeshes.assign(d->primMeshes, d->primMeshes + d->numPrimMeshes);
   c->vertices.assign(d->vertices, d->vertices + d->numVertices);
   c->indices.assign(d->indices, d->indices + d->numIndices);
@@ -508,7 +519,7 @@ int rt_run_stage(rt_ctx* c, const rt_state* st, int frames, int stage, int level
   RT_HIP(c, hipSetDevice(c->device));
   RT_HIP(c, joinInFlight(c));
   const DevFrame F = makeFrame(c, frames);
-  RT_HIP(c, (c->pipeline ? launchStageWavefront : launchStage)(c->stream, c->ds, F, *st, c->cam, stage, level, rowBegin, rowEnd));
+  RT_HIP(c, stageLauncher(c)(c->stream, c->ds, F, *st, c->cam, stage, level, rowBegin, rowEnd));
   return RT_OK;
 }
 
@@ -537,7 +548,7 @@ int rt_render_frame(rt_ctx* c, const rt_state* st, int frames)
   const DevFrame F = makeFrame(c, frames);
   int k = 0, lastMain = 0, lastSide = 0, lastInd = 0;
   auto run = [&](hipStream_t strm, int stage, int level) -> int {
-    hipError_t e = (c->pipeline ? launchStageWavefront : launchStage)(strm, c->ds, F, *st, c->cam, stage, level, 0, 0);
+    hipError_t e = stageLauncher(c)(strm, c->ds, F, *st, c->cam, stage, level, 0, 0);
     if(e != hipSuccess) { c->err = std::string("launchStage: ") + hipGetErrorString(e); return RT_ERR_HIP; }
     e = hipEventRecord(E.ev[k], strm);
     if(e != hipSuccess) { c->err = std::string("hipEventRecord: ") + hipGetErrorString(e); return RT_ERR_HIP; }
@@ -705,6 +716,21 @@ int rt_set_pipeline(rt_ctx* c, int pipeline)
 {
   if(!c || pipeline < 0 || pipeline > 1) return RT_ERR_INVALID_ARG;
   c->pipeline = pipeline;
+  return RT_OK;
+}
+
+int rt_set_sun_and_sky(rt_ctx* c, const rt_sun_and_sky* ss)
+{
+  if(!c || !ss) return RT_ERR_INVALID_ARG;
+  RT_HIP(c, hipSetDevice(c->device));
+  RT_HIP(c, syncAll(c));
+  c->sunAndSky = *ss;
+  if(ss->in_use == 1) {
+    if(!c->dSky) RT_HIP(c, hipMalloc(&c->dSky, 512));
+    RT_HIP(c, launchSkyPrepare(c->stream, *ss, static_cast<SkyPre*>(c->dSky)));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  c->ds.sky = (ss->in_use == 1) ? static_cast<const SkyPre*>(c->dSky) : nullptr;
   return RT_OK;
 }
 

@@ -5,6 +5,10 @@
 // the GLSL it stands for.  Numerics follow include/rt_detmath.h + DESIGN.md §Numerics.
 #pragma once
 #include "traverse.h"
+#include "sky.h"
+#ifndef RT_SKY
+#define RT_SKY 0
+#endif
 
 namespace rt {
 
@@ -351,6 +355,20 @@ struct Ctx {
   // ---------------------------------------------------------------------------- env_sampling.glsl:38-135
   RT_DEV f4 EnvSample(f3& radiance)
   {
+    if(RT_SKY && S.sky) {  // :111-125
+      const SkyPre& P = *S.sky;
+      f3 T, B;
+      CreateCoordinateSystem(P.rawSunDir, T, B);
+      f3 d;
+      d.x = rnd(seed) * P.sampleRadius;
+      d.y = rnd(seed) * P.sampleRadius;
+      d.z = rt_sqrt(rt_max(0.0f, (1.0f - d.x * d.x) - d.y * d.y));
+      const f3 lightDir = normalize((T * d.x + B * d.y) + P.rawSunDir * d.z);
+      radiance = skyfn::evaluate(P, lightDir);
+      lastLightId = 0xBFFFFFFFu;
+      radiance *= rtx.hdrMultiplier;
+      return mk4(lightDir, 0.5f);
+    }
     float r0 = rnd(seed), r1 = rnd(seed), r2 = rnd(seed);
     f3 xi = mk3(r0, r1, r2);
     const uint32_t width = uint32_t(S.envW), height = uint32_t(S.envH);
@@ -391,9 +409,14 @@ struct Ctx {
     pdf = metallicWorkflowSample(mat, N, V, mk3(r0, r1, r2), bsdf, L);
     return bsdf;
   }
-  RT_DEV f3 EnvRadiance(f3 dir) const { return xyz(sampleEnv(S, GetSphericalUv(dir))) * rtx.hdrMultiplier; }  // :40-47
-  RT_DEV f3 EnvEval(f3 dir, float& pdf) const                                                                 // :62-72
+  RT_DEV f3 EnvRadiance(f3 dir) const  // :40-47
   {
+    if(RT_SKY && S.sky) return skyfn::evaluate(*S.sky, dir) * rtx.hdrMultiplier;
+    return xyz(sampleEnv(S, GetSphericalUv(dir))) * rtx.hdrMultiplier;
+  }
+  RT_DEV f3 EnvEval(f3 dir, float& pdf) const  // :62-72
+  {
+    if(RT_SKY && S.sky) { pdf = 0.5f * rtx.environmentProb; return skyfn::evaluate(*S.sky, dir) * rtx.hdrMultiplier; }
     f3 radiance = xyz(sampleEnv(S, GetSphericalUv(dir)));
     pdf = luminance(radiance) * rtx.envMapLuminIntegInv * rtx.environmentProb;
     return radiance;

@@ -13,7 +13,19 @@
 #include "stage_common.h"
 #include <algorithm>
 
+// This file is compiled twice: as is (HDR environment only) and through *_sky.hip with RT_SKY = 1 (procedural sun & sky code
+// paths compiled in).  Keeping sun_and_sky() out of the default kernels saves 13 VGPRs in k_direct_stage (one wave per SIMD of
+// occupancy) — the procedural sky is the rarely used mode (default in_use = 0, sample_example.hpp:202).
+#ifndef RT_SKY
+#define RT_SKY 0
+#endif
+#if RT_SKY
+#define RT_VARIANT sky
+#else
+#define RT_VARIANT base
+#endif
 namespace rt {
+namespace RT_VARIANT {
 
 // ------------------------------------------------------------------------------------------------------------
 // direct_stage.comp
@@ -563,4 +575,5 @@ hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F,
   return hipGetLastError();
 }
 
+}  // namespace RT_VARIANT
 }  // namespace rt

@@ -17,7 +17,19 @@
 #include <cstdio>
 #include <cstdlib>
 
+// This file is compiled twice: as is (HDR environment only) and through *_sky.hip with RT_SKY = 1 (procedural sun & sky code
+// paths compiled in).  Keeping sun_and_sky() out of the default kernels saves 13 VGPRs in k_direct_stage (one wave per SIMD of
+// occupancy) — the procedural sky is the rarely used mode (default in_use = 0, sample_example.hpp:202).
+#ifndef RT_SKY
+#define RT_SKY 0
+#endif
+#if RT_SKY
+#define RT_VARIANT sky
+#else
+#define RT_VARIANT base
+#endif
 namespace rt {
+namespace RT_VARIANT {
 
 // ---- queue append: one atomic per wave ------------------------------------------------------------------------------
 RT_DEV uint32_t queueSlot(uint32_t* counter, bool want)
@@ -607,4 +619,5 @@ hipError_t launchStageWavefront(hipStream_t stream, const DevScene& S, const Dev
   return hipGetLastError();
 }
 
+}  // namespace RT_VARIANT
 }  // namespace rt

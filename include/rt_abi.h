@@ -161,6 +161,16 @@ typedef struct {
   int32_t autoExposure; float Ywhite, key; int32_t pad;
 } rt_tonemapper;
 
+/* host_device.h:353-377 — 96 B; the uniform block `_sunAndSky` (layouts.glsl:53), defaults sample_example.hpp:186-203 */
+typedef struct {
+  rt_vec3 rgb_unit_conversion; float multiplier;
+  float haze, redblueshift, saturation, horizon_height;
+  rt_vec3 ground_color; float horizon_blur;
+  rt_vec3 night_color; float sun_disk_intensity;
+  rt_vec3 sun_direction; float sun_disk_scale;
+  float sun_glow_intensity; int32_t y_is_up; int32_t physically_scaled_sun; int32_t in_use;
+} rt_sun_and_sky;
+
 /* host_device.h:327-333 — 16 B */
 typedef struct { uint32_t puncLightSize; uint32_t trigLightSize; float trigSampProb; int32_t pad; } rt_light_buf_info;
 
@@ -349,6 +359,10 @@ int rt_history_miss(rt_ctx* ctx, int* missed);
  * uninitialised variable in the reference, post.frag:92) uses the global operator. */
 int rt_tonemap(rt_ctx* ctx, const rt_tonemapper* tm, int debugging_mode, int frames);
 int rt_set_pipeline(rt_ctx* ctx, int pipeline);
+/* SampleExample::updateUniformBuffer's vkCmdUpdateBuffer(m_sunAndSkyBuffer, ...) (sample_example.cpp:172): the procedural
+ * sun & sky environment.  With in_use == 1 EnvRadiance / EnvSample / EnvEval (pathtrace.glsl:40-72, env_sampling.glsl:105-135)
+ * evaluate sun_and_sky() (sun_and_sky.glsl:453-601) instead of the HDR map.  Default: in_use = 0. */
+int rt_set_sun_and_sky(rt_ctx* ctx, const rt_sun_and_sky* ss);
 /* Stream-level concurrency of rt_render_frame (results are identical in every mode):
  *   0 = every launch of Renderer::run's list (renderer.cpp:163-205) in order on the ctx stream;
  *   1 = the direct A-Trous chain runs beside the indirect stage on an internal stream and joins before compose;
@@ -380,6 +394,7 @@ static_assert(sizeof(rt_punc_light) == 80, "PuncLight host_device.h:295-312");
 static_assert(sizeof(rt_trig_light) == 96, "TrigLight host_device.h:314-325");
 static_assert(sizeof(rt_light_buf_info) == 16, "LightBufInfo host_device.h:327-333");
 static_assert(sizeof(rt_tonemapper) == 48, "Tonemapper host_device.h:336-351");
+static_assert(sizeof(rt_sun_and_sky) == 96, "SunAndSky host_device.h:353-377");
 #endif
 
 #endif /* RT_ABI_H */

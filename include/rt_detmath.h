@@ -179,6 +179,9 @@ RT_HD float rt_cos(float x)
   return neg ? -y : y;
 }
 
+/* tan as the quotient of the two contract functions (GLSL leaves tan's precision undefined) */
+RT_HD float rt_tan(float x) { return rt_sin(x) / rt_cos(x); }
+
 /* asin on [-1,1]; |x| > 1 or NaN => NaN */
 RT_HD float rt_asin(float x)
 {

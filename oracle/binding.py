@@ -47,6 +47,8 @@ def lib():
         L.orc_get_counters.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_set_history_rows.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orc_tonemap.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.orc_set_sun_and_sky.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_sun_and_sky_eval.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_history_miss.argtypes = [C.c_void_p]
         L.orc_buffer_ptr.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         for n in ["orc_trace_closest", "orc_trace_any", "orc_trace_closest_brute"]:
@@ -77,6 +79,7 @@ class Oracle:
     def render_frame(self, state, frames): self._chk(lib().orc_render_frame(self._h, C.byref(state), frames), "render_frame")
     def run_stage(self, state, frames, stage, level=0, row_begin=0, row_end=0):
         self._chk(lib().orc_run_stage(self._h, C.byref(state), frames, stage, level, row_begin, row_end), "run_stage")
+    def set_sun_and_sky(self, ss): self._chk(lib().orc_set_sun_and_sky(self._h, C.byref(ss)), "set_sun_and_sky")
     def tonemap(self, tm, debugging_mode=0, frames=0):
         self._chk(lib().orc_tonemap(self._h, C.byref(tm), debugging_mode, frames), "tonemap")
     def buffer_bytes(self, buf): return lib().orc_buffer_bytes(self._h, buf)
@@ -114,3 +117,11 @@ class Oracle:
         out = np.empty(rays.shape[0], dtype=np.int32)
         lib().orc_trace_any(self._h, rays.shape[0], rays.ctypes.data, out.ctypes.data)
         return out
+
+
+def sun_and_sky_eval(ss, dirs):
+    """sun_and_sky(ss, dir) (sun_and_sky.glsl:453-601) for an (n,3) float32 array of directions."""
+    d = np.ascontiguousarray(dirs, dtype=np.float32)
+    out = np.empty_like(d)
+    lib().orc_sun_and_sky_eval(C.byref(ss), len(d), d.ctypes.data, out.ctypes.data)
+    return out

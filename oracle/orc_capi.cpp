@@ -138,6 +138,11 @@ int orc_get_counters(void* p, rt_counters* out)
   out->hitsShaded = c->scene.counters.hitsShaded; out->risCandidates = c->scene.counters.risCandidates;
   return RT_OK;
 }
+int orc_set_sun_and_sky(void* p, const rt_sun_and_sky* ss) { if(!ss) return RT_ERR_INVALID_ARG; static_cast<Ctx*>(p)->scene.sunAndSky = *ss; return RT_OK; }
+void orc_sun_and_sky_eval(const rt_sun_and_sky* ss, int n, const float* dirs, float* out)
+{
+  for(int i = 0; i < n; i++) { vec3 r = sky::sun_and_sky(*ss, V3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2])); out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z; }
+}
 int orc_tonemap(void* p, const rt_tonemapper* tm, int dbg, int frames)
 {
   Ctx* c = static_cast<Ctx*>(p);

@@ -61,6 +61,7 @@ struct Scene {
   std::vector<rt_punc_light> puncLights;
   std::vector<rt_trig_light> trigLights;
   rt_light_buf_info lightInfo{};
+  rt_sun_and_sky sunAndSky{};  // in_use = 0 by default (uniform block _sunAndSky, layouts.glsl:53)
   int envW = 1, envH = 1;
   std::vector<float> env;  // rgba32f
   std::vector<rt_impt_samp> envAccel;

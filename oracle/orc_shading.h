@@ -8,6 +8,7 @@
 #pragma once
 #include <cmath>
 #include "orc_scene.h"
+#include "orc_sky.h"
 
 namespace orc {
 
@@ -434,8 +435,23 @@ struct Shader {
     to_light = V3(cos_phi * sin_theta, cos_theta, sin_phi * sin_theta);
     return xyz(S.sampleEnv(V2(u, v)));
   }
-  vec4 EnvSample(vec3& radiance)  // :105-135 (HDR branch; sun&sky is out of scope)
+  vec4 EnvSample(vec3& radiance)  // :105-135
   {
+    if(S.sunAndSky.in_use == 1) {  // :111-125 ("#TODO: find proper light direction + PDF" in the reference: kept as is)
+      const rt_sun_and_sky& ss = S.sunAndSky;
+      const float sun_radius = (0.00465f * 10.0f) * ss.sun_disk_scale;
+      vec3 T, B;
+      CreateCoordinateSystem(toV(ss.sun_direction), T, B);
+      vec3 d;
+      d.x = rnd(seed) * sun_radius;
+      d.y = rnd(seed) * sun_radius;
+      d.z = rt_sqrt(rt_max(0.0f, (1.0f - d.x * d.x) - d.y * d.y));
+      const vec3 lightDir = normalize((T * d.x + B * d.y) + toV(ss.sun_direction) * d.z);
+      radiance = sky::sun_and_sky(ss, lightDir);
+      lastLightId = 0xBFFFFFFFu;  // "sun & sky sample" (no texel)
+      radiance *= rtx.hdrMultiplier;
+      return V4(lightDir, 0.5f);
+    }
     vec3 lightDir; float pdf; uint32_t texel;
     float r0 = rnd(seed), r1 = rnd(seed), r2 = rnd(seed);
     radiance = Environment_sample(V3(r0, r1, r2), lightDir, pdf, texel);
@@ -460,9 +476,14 @@ struct Shader {
     pdf = metallicWorkflowSample(s, N, V, V3(r0, r1, r2), bsdf, L);
     return bsdf;
   }
-  vec3 EnvRadiance(vec3 dir) const { return xyz(S.sampleEnv(GetSphericalUv(dir))) * rtx.hdrMultiplier; }  // :40-47
-  vec3 EnvEval(vec3 dir, float& pdf) const                                                                  // :62-72
+  vec3 EnvRadiance(vec3 dir) const  // :40-47
   {
+    if(S.sunAndSky.in_use == 1) return sky::sun_and_sky(S.sunAndSky, dir) * rtx.hdrMultiplier;
+    return xyz(S.sampleEnv(GetSphericalUv(dir))) * rtx.hdrMultiplier;
+  }
+  vec3 EnvEval(vec3 dir, float& pdf) const  // :62-72
+  {
+    if(S.sunAndSky.in_use == 1) { pdf = 0.5f * rtx.environmentProb; return sky::sun_and_sky(S.sunAndSky, dir) * rtx.hdrMultiplier; }
     vec3 radiance = xyz(S.sampleEnv(GetSphericalUv(dir)));
     pdf = luminance(radiance) * rtx.envMapLuminIntegInv * rtx.environmentProb;
     return radiance;
