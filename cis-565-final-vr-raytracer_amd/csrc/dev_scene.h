@@ -76,6 +76,7 @@ struct DevFrame {
   uint32_t* qC[2]; uint32_t* qA; uint32_t* qcount;
   // A-Trous geometry decoded once per frame: (normal.xyz, matHash bits) and (world position.xyz, 0); full-res and half-res grids
   float4* geomN; float4* geomP; float4* geomNh; float4* geomPh;
+  rt_direct_reservoir* tempDirectResv;  // RT_BUF_DIRECT_RESV_TEMP: cacheTempReservoir target of the spatial reuse (direct_stage.comp:127-129)
   double* postRowSums; float* postMean;  // rt_tonemap: per-row colour sums [2][H][3], image means [2][4]
   uint32_t* tileOrder;              // 8 per-XCD lists of half-res tile ids, longest (multi-bounce) first
   int32_t W, H;

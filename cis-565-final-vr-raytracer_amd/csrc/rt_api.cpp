@@ -485,6 +485,7 @@ static DevFrame makeFrame(rt_ctx* c, int frames)
   F.lastDirectResv = static_cast<const rt_direct_reservoir*>(c->bufs[RT_BUF_DIRECT_RESV0 + last]);
   F.thisIndirectResv = static_cast<rt_indirect_reservoir*>(c->bufs[RT_BUF_INDIRECT_RESV0 + cur]);
   F.lastIndirectResv = static_cast<const rt_indirect_reservoir*>(c->bufs[RT_BUF_INDIRECT_RESV0 + last]);
+  F.tempDirectResv = static_cast<rt_direct_reservoir*>(c->bufs[RT_BUF_DIRECT_RESV_TEMP]);
   F.thisLightId = static_cast<uint32_t*>(c->bufs[RT_BUF_LIGHT_ID0 + cur]); F.lastLightId = static_cast<const uint32_t*>(c->bufs[RT_BUF_LIGHT_ID0 + last]);
   F.thisDirectResult = static_cast<float4*>(c->bufs[RT_BUF_DIRECT_RESULT0 + cur]);
   F.thisIndirectResult = static_cast<float4*>(c->bufs[RT_BUF_INDIRECT_RESULT0 + cur]);

@@ -46,6 +46,8 @@ __global__ __launch_bounds__(64) void k_direct_stage(DevScene S, DevFrame F, rt_
   const Ray r = c.raySpawn(px, i2{st.size.x, st.size.y});
 
   f3 radiance;
+  const bool spatial = st.ReSTIRState == RT_RESTIR_SPATIAL || st.ReSTIRState == RT_RESTIR_SPATIOTEMPORAL;
+  bool deferred = false;
   c.ClosestHit(r);
   if(c.hit.t >= RT_INFINITY) {  // :155-159
     F.thisG[index] = make_uint4(rt_f2u(RT_INFINITY), 0u, 0u, RT_INVALID_MAT_ID);
@@ -82,20 +84,87 @@ __global__ __launch_bounds__(64) void k_direct_stage(DevScene S, DevFrame F, rt_
         resvClamp(tempResv, st.RISSampleNum * st.reservoirClamp);
         F.thisDirectResv[index] = tempResv;  // saveNewReservoir
         F.thisLightId[index] = lid;
-        // in-workgroup spatial reuse (direct_stage.comp:224-255) is SURVEY §8(f) rank 4: not implemented
-        const rt_light_sample ls = resv.lightSample;
-        if(!resvInvalidW(resv.weight)) {
-          f3 LiBsdf = mk3(ls.Li) * metallicWorkflowBSDF(state.mat, state.ffnormal, wo, mk3(ls.wi));
-          direct = LiBsdf / resvToScalar(LiBsdf) * resv.weight / float(resv.num);
+        if(spatial) {
+          // Spatial / spatiotemporal reuse (:224-255) reads the reservoirs its neighbours cache here.  The reference orders
+          // that with workgroup barriers only (neighbours in other workgroups race); this build finishes the pixel in a
+          // second kernel (k_direct_spatial) once every pixel of the launch has cached its reservoir.
+          if(resvInvalidW(resv.weight)) { resv.num = 0; resv.weight = 0.f; }  // resvCheckValidity(resv) :231
+          F.tempDirectResv[index] = resv;                                      // cacheTempReservoir :234
+          SurfRec sr;
+          sr.position = toR(state.position); sr.normal = toR(state.normal); sr.ffnormal = toR(state.ffnormal); sr.emission = toR(state.mat.emission);
+          sr.roughness = state.mat.roughness; sr.metallic = state.mat.metallic; sr.matID = state.matID; sr.seed = c.seed;
+          F.surf[index] = sr;
+          deferred = true;
+        } else {
+          const rt_light_sample ls = resv.lightSample;
+          if(!resvInvalidW(resv.weight)) {
+            f3 LiBsdf = mk3(ls.Li) * metallicWorkflowBSDF(state.mat, state.ffnormal, wo, mk3(ls.wi));
+            direct = LiBsdf / resvToScalar(LiBsdf) * resv.weight / float(resv.num);
+          }
         }
       }
       if(rt_isnan(direct.x) || rt_isnan(direct.y) || rt_isnan(direct.z)) direct = mk3(0.0f);
       radiance = HDRToLDR(c.clampRadiance(state.mat.emission + direct));
     }
   }
-  const f3 pixelColor = c.clampRadiance(radiance);
-  storeImg(F.thisDirectResult, F, px, mk4(pixelColor, 1.0f));  // :286
+  if(spatial) F.status[index] = deferred ? 1u : 0u;
+  if(!deferred) {
+    const f3 pixelColor = c.clampRadiance(radiance);
+    storeImg(F.thisDirectResult, F, px, mk4(pixelColor, 1.0f));  // :286
+  }
   flushCounters(F, c);
+}
+
+// Second half of direct_stage.comp's ReSTIRDirect for the spatial modes (:86-121, 236-262): two rounds of five neighbour
+// merges from the cached reservoirs, the final merge and the shading.  No rays.
+__global__ __launch_bounds__(64) void k_direct_spatial(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY)
+{
+  const TileCoord tile = tileOf(tilesX, tilesY);
+  if(!tile.valid) return;
+  const int lane = int(threadIdx.x);
+  const i2 px{tile.x * 8 + (lane & 7), rowBegin + tile.y * 8 + (lane >> 3)};
+  if(px.x >= st.size.x || px.y >= rowEnd) return;
+  const size_t index = size_t(px.y) * st.size.x + px.x;
+  if(F.status[index] != 1u) return;
+  Ctx c(S, st, cam, nullptr);
+  c.imageCoords = px;
+  const SurfRec sr = F.surf[index];
+  c.seed = sr.seed;
+  rt_direct_reservoir resv = F.tempDirectResv[index];
+  const uint4 g = F.thisG[index];
+  const f3 pnorm = decompress_unit_vec(g.y);          // loadThisGeometryInfo(imageCoords, ...): the pixel's own G-buffer entry
+  const float pdepth = rt_u2f(g.x), depth = pdepth;   // prd.hitT is what encodeGeometryInfo stored in .x
+  const f3 normal = mk3(sr.normal), ffnormal = mk3(sr.ffnormal);
+  const i2 size{st.size.x, st.size.y};
+  rt_direct_reservoir spatial = zeroDirectResv();
+  for(int round = 0; round < 2; round++) {
+    rt_direct_reservoir agg = zeroDirectResv();
+    bool valid = false;
+    for(int i = 0; i < 5; i++) {
+      const float r0 = rnd(c.seed), r1 = rnd(c.seed);
+      const f2 p = toConcentricDisk(mk2(r0, r1));
+      const i2 q{rt_ftoi((float(px.x) + p.x) + 0.5f), rt_ftoi((float(px.y) + p.y) + 0.5f)};
+      if(!inBound(q, size)) continue;
+      if(dot(normal, pnorm) < 0.5f || rt_abs(depth - pdepth) > depth * 0.1f) continue;
+      const rt_direct_reservoir nb = F.tempDirectResv[size_t(q.y) * st.size.x + q.x];
+      if(!resvInvalidW(nb.weight)) { resvMerge(agg, nb, rnd(c.seed)); valid = true; }
+    }
+    if(valid && !resvInvalidW(agg.weight)) resvMerge(spatial, agg, rnd(c.seed));
+  }
+  if(!resvInvalidW(spatial.weight)) resvMerge(resv, spatial, rnd(c.seed));
+  const Ray r = c.raySpawn(px, size);
+  const f3 wo = -r.direction;
+  Material mat;
+  mat.albedo = mk3(1.0f); mat.emission = mk3(sr.emission); mat.metallic = sr.metallic; mat.roughness = sr.roughness; mat.ior = 0.f; mat.transmission = 0.f;
+  f3 direct = mk3(0.0f);
+  const rt_light_sample ls = resv.lightSample;
+  if(!resvInvalidW(resv.weight)) {
+    const f3 LiBsdf = mk3(ls.Li) * metallicWorkflowBSDF(mat, ffnormal, wo, mk3(ls.wi));
+    direct = LiBsdf / resvToScalar(LiBsdf) * resv.weight / float(resv.num);
+  }
+  if(rt_isnan(direct.x) || rt_isnan(direct.y) || rt_isnan(direct.z)) direct = mk3(0.0f);
+  const f3 radiance = HDRToLDR(c.clampRadiance(mat.emission + direct));
+  storeImg(F.thisDirectResult, F, px, mk4(c.clampRadiance(radiance), 1.0f));
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -527,7 +596,11 @@ hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F,
   const dim3 grid(tileGrid(tilesX, tilesY)), block(64);
   const size_t lds = size_t(S.stackEntries) * 64 * sizeof(uint2);
   switch(stage) {
-    case RT_STAGE_DIRECT: hipLaunchKernelGGL(k_direct_stage, grid, block, lds, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY); break;
+    case RT_STAGE_DIRECT:
+      hipLaunchKernelGGL(k_direct_stage, grid, block, lds, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY);
+      if(st.ReSTIRState == RT_RESTIR_SPATIAL || st.ReSTIRState == RT_RESTIR_SPATIOTEMPORAL)
+        hipLaunchKernelGGL(k_direct_spatial, grid, block, 0, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY);
+      break;
     case RT_STAGE_DIRECT_GEN: hipLaunchKernelGGL(k_direct_gen, grid, block, lds, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY); break;
     case RT_STAGE_DIRECT_REUSE: hipLaunchKernelGGL(k_direct_reuse, grid, block, 0, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY); break;
     case RT_STAGE_INDIRECT: {

@@ -564,6 +564,9 @@ hipError_t launchStageWavefront(hipStream_t stream, const DevScene& S, const Dev
 {
   const bool isDirect = stage == RT_STAGE_DIRECT || stage == RT_STAGE_DIRECT_GEN;
   if(!isDirect && stage != RT_STAGE_INDIRECT) return launchStage(stream, S, F, st, cam, stage, level, rowBegin, rowEnd);
+  // the spatial reuse modes exist in the fused organisation only (k_direct_stage + k_direct_spatial)
+  if(stage == RT_STAGE_DIRECT && (st.ReSTIRState == RT_RESTIR_SPATIAL || st.ReSTIRState == RT_RESTIR_SPATIOTEMPORAL))
+    return launchStage(stream, S, F, st, cam, stage, level, rowBegin, rowEnd);
   const bool half = !isDirect;
   const int gw = half ? st.size.x / 2 : st.size.x, gh = half ? st.size.y / 2 : st.size.y;
   if(rowEnd <= 0 || rowEnd > gh) rowEnd = gh;

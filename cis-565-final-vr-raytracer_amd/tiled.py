@@ -178,6 +178,10 @@ class TiledFrame:
         c, b = self.comm, self.b
         cur, last = frames & 1, (frames + 1) & 1
         single = c.world == 1
+        if not single and state.ReSTIRState in (abi.RESTIR_SPATIAL, abi.RESTIR_SPATIOTEMPORAL):
+            # the spatial reuse step reads the cached reservoirs of the rows above / below the band (direct_stage.comp:86-107);
+            # that buffer is not part of the halo exchange
+            raise NotImplementedError("ReSTIRState eSpatial / eSpatiotemporal is single-GPU only in this build")
         c.wait(self._pending)
         self._pending = []
 

@@ -140,20 +140,89 @@ bool Frame::findTemporalNeighborDirect(const rt_state& st, int last, vec3 norm, 
 void Frame::directStage(const rt_state& st, int frames, int rowBegin, int rowEnd)
 {
   const int cur = frames & 1, last = (frames + 1) & 1;
+  // The reference does the spatial reuse inside the same dispatch, between barrier()s that only order one workgroup, reading
+  // neighbours' tempDirectResv entries that other workgroups may or may not have written yet (a data race).  The race-free
+  // reading restated here: every pixel caches its reservoir first (pass 1), then every pixel merges (pass 2).
+  const bool spatial = st.ReSTIRState == RT_RESTIR_SPATIAL || st.ReSTIRState == RT_RESTIR_SPATIOTEMPORAL;
+  std::vector<SpatialPending> pend(spatial ? size_t(st.size.x) * st.size.y : 0);
   parallelRows(st.size.y, rowBegin, rowEnd, [&](int y) {
     for(int x = 0; x < st.size.x; x++) {
       Shader sh(*scene, st, cam);
       sh.imageCoords = ivec2{x, y};
       sh.seed = tea(uint32_t(st.size.x) * uint32_t(y) + uint32_t(x), st.time);  // :279
       Ray ray = sh.raySpawn(sh.imageCoords, ivec2{st.size.x, st.size.y});
-      vec3 radiance = ReSTIRDirect(sh, ray, cur, last);
+      SpatialPending* P = spatial ? &pend[size_t(y) * st.size.x + x] : nullptr;
+      vec3 radiance = ReSTIRDirect(sh, ray, cur, last, P);
+      if(P && P->active) continue;
       vec3 pixelColor = sh.clampRadiance(radiance);
       storeImg(directResult[cur], sh.imageCoords, V4(pixelColor, 1.0f));  // :286
     }
   });
+  if(!spatial) return;
+  parallelRows(st.size.y, rowBegin, rowEnd, [&](int y) {
+    for(int x = 0; x < st.size.x; x++) {
+      const SpatialPending& P = pend[size_t(y) * st.size.x + x];
+      if(!P.active) continue;
+      Shader sh(*scene, st, cam);
+      sh.imageCoords = ivec2{x, y};
+      sh.seed = P.seed;
+      vec3 radiance = finishSpatial(sh, P, cur);
+      storeImg(directResult[cur], sh.imageCoords, V4(sh.clampRadiance(radiance), 1.0f));
+    }
+  });
 }
 
-vec3 Frame::ReSTIRDirect(Shader& sh, const Ray& r, int cur, int last)  // direct_stage.comp:150-270
+// direct_stage.comp:86-121 + 229-262 for one pixel, after all pixels have run cacheTempReservoir
+vec3 Frame::finishSpatial(Shader& sh, const SpatialPending& P, int cur)
+{
+  const rt_state& st = sh.rtx;
+  const ivec2 size{st.size.x, st.size.y};
+  rt_direct_reservoir resv = P.resv;
+  float dummyPdf = 0;
+  auto findSpatialNeighbor = [&](rt_direct_reservoir& out) -> bool {  // :86-107 (Radius is unused there; the geometry test looks at the pixel itself)
+    float r0 = rnd(sh.seed), r1 = rnd(sh.seed);
+    vec2 p = toConcentricDisk(V2(r0, r1));
+    int px = rt_ftoi((float(sh.imageCoords.x) + p.x) + 0.5f);
+    int py = rt_ftoi((float(sh.imageCoords.y) + p.y) + 0.5f);
+    uvec4 g = loadG(cur, sh.imageCoords);  // loadThisGeometryInfo(imageCoords, ...)
+    vec3 pnorm = decompress_unit_vec(g.y);
+    float pdepth = rt_u2f(g.x);
+    if(!inBound(ivec2{px, py}, size)) return false;
+    if(dot(P.state.normal, pnorm) < 0.5f || rt_abs(P.hitT - pdepth) > P.hitT * 0.1f) return false;
+    out = directResvTemp[size_t(py) * st.size.x + px];
+    return true;
+  };
+  auto mergeSpatialNeighbors = [&](rt_direct_reservoir& out) -> bool {  // :109-121
+    bool valid = false;
+    memset(&out, 0, sizeof(out));  // `out` parameter + resvReset: sample undefined in GLSL, zero here (DESIGN.md deviation 3)
+    for(int i = 0; i < 5; i++) {
+      rt_direct_reservoir sp; memset(&sp, 0, sizeof(sp));
+      if(findSpatialNeighbor(sp)) {
+        if(!resvInvalid(sp)) { resvMerge(out, sp, rnd(sh.seed)); valid = true; }
+      }
+    }
+    return valid;
+  };
+  rt_direct_reservoir spatial; memset(&spatial, 0, sizeof(spatial));
+  for(int round = 0; round < 2; round++) {  // :236-252 (the reservoir cached between the rounds is the same one)
+    rt_direct_reservoir agg;
+    if(mergeSpatialNeighbors(agg)) {
+      if(!resvInvalid(agg)) resvMerge(spatial, agg, rnd(sh.seed));
+    }
+  }
+  if(!resvInvalid(spatial)) resvMerge(resv, spatial, rnd(sh.seed));
+  vec3 direct = V3(0.0f);
+  const rt_light_sample ls = resv.lightSample;
+  if(!resvInvalid(resv)) {
+    vec3 LiBsdf = toV(ls.Li) * sh.Eval(P.state, P.wo, P.state.ffnormal, toV(ls.wi), dummyPdf);
+    direct = LiBsdf / resvToScalar(LiBsdf) * resv.weight / float(resv.num);
+  }
+  if(rt_isnan(direct.x) || rt_isnan(direct.y) || rt_isnan(direct.z)) direct = V3(0.0f);
+  vec3 res = sh.clampRadiance(P.state.mat.emission + direct);
+  return HDRToLDR(res);
+}
+
+vec3 Frame::ReSTIRDirect(Shader& sh, const Ray& r, int cur, int last, SpatialPending* pending)  // direct_stage.comp:150-270
 {
   const rt_state& st = sh.rtx;
   const size_t index = size_t(sh.imageCoords.y) * st.size.x + sh.imageCoords.x;
@@ -209,7 +278,12 @@ vec3 Frame::ReSTIRDirect(Shader& sh, const Ray& r, int cur, int last)  // direct
     resvClamp(tempResv, st.RISSampleNum * st.reservoirClamp);
     directResv[cur][index] = tempResv;  // saveNewReservoir
     lightId_cur(cur)[index] = lid;
-    // spatial / spatiotemporal in-workgroup reuse (direct_stage.comp:224-255) is SURVEY §8(f) rank 4: not restated
+    if(pending) {  // :229-234: resvCheckValidity(resv); cacheTempReservoir(resv); the rest happens in finishSpatial
+      resvCheckValidity(resv);
+      directResvTemp[index] = resv;
+      pending->active = true; pending->state = state; pending->wo = wo; pending->hitT = sh.hitT; pending->seed = sh.seed; pending->resv = resv;
+      return V3(0.0f);
+    }
     ls = resv.lightSample;
     if(!resvInvalid(resv)) {
       vec3 LiBsdf = toV(ls.Li) * sh.Eval(state, wo, state.ffnormal, toV(ls.wi), dummyPdf);

@@ -58,7 +58,11 @@ struct Frame {
   void loadLastGeometryInfo(int last, ivec2 c, vec3& normal, float& depth, uint32_t& matHash) const;
   bool findTemporalNeighborDirect(const rt_state& st, int last, vec3 norm, float reprojDepth, uint32_t matId, ivec2 lastCoord,
                                   rt_direct_reservoir& resv, uint32_t& lid) const;
-  vec3 ReSTIRDirect(Shader& sh, const Ray& r, int cur, int last);
+  // spatial / spatiotemporal reuse (direct_stage.comp:224-255): a pixel that reaches the reuse step parks what the rest of
+  // ReSTIRDirect needs and finishes after every pixel of the frame has cached its reservoir (SpatialPending / finishSpatial)
+  struct SpatialPending { bool active = false; State state; vec3 wo; float hitT = 0; uint32_t seed = 0; rt_direct_reservoir resv; };
+  vec3 ReSTIRDirect(Shader& sh, const Ray& r, int cur, int last, SpatialPending* pending);
+  vec3 finishSpatial(Shader& sh, const SpatialPending& P, int cur);
   vec3 ReSTIRIndirect(Shader& sh, float dist, float primSamplePdf, vec3 primWo, State primState, rt_gi_sample gi, int cur, int last);
   void loadThisGeometry(int cur, ivec2 coord, vec3& normal, vec3& pos, uint32_t& matHash, ivec2 imageSize) const;
   vec3 waveletFilter(const rt_state& st, int cur, const std::vector<float>& inImage, ivec2 coord, vec3 norm, vec3 pos, uint32_t matHash,

@@ -115,7 +115,7 @@ def test_cornell_config2_di_only_512():
 
 
 @pytest.mark.parametrize("wavefront", [True, False], ids=["wavefront", "fused"])
-@pytest.mark.parametrize("variant", ["restir_none", "ris_only", "no_denoise", "no_modulate", "no_mis_depth2", "debug_normal", "gen_reuse_split", "m16_clamp4"])
+@pytest.mark.parametrize("variant", ["restir_none", "ris_only", "no_denoise", "no_modulate", "no_mis_depth2", "debug_normal", "gen_reuse_split", "m16_clamp4", "spatial", "spatiotemporal"])
 def test_state_variants(variant, wavefront):
     W, H = 160, 96
     sc, env = make_scene(abi.PROC_SPONZA, 0.01, 1, (128, 64))
@@ -123,6 +123,8 @@ def test_state_variants(variant, wavefront):
     stages = None
     if variant == "restir_none": st.ReSTIRState = abi.RESTIR_NONE
     if variant == "ris_only": st.ReSTIRState = abi.RESTIR_RIS
+    if variant == "spatial": st.ReSTIRState = abi.RESTIR_SPATIAL
+    if variant == "spatiotemporal": st.ReSTIRState = abi.RESTIR_SPATIOTEMPORAL
     if variant == "no_denoise": st.denoise = 0
     if variant == "no_modulate": st.modulate = 0
     if variant == "no_mis_depth2": st.MIS = 0; st.maxDepth = 2
@@ -132,7 +134,8 @@ def test_state_variants(variant, wavefront):
         stages = [(abi.STAGE_DIRECT_GEN, 0), (abi.STAGE_DIRECT_REUSE, 0), (abi.STAGE_INDIRECT, 0)] + \
                  [(abi.STAGE_DENOISE_DIRECT, l) for l in range(4)] + [(abi.STAGE_DENOISE_INDIRECT, l) for l in range(5)] + [(abi.STAGE_COMPOSE, 0)]
     o, r = _pair(sc, env, W, H, wavefront)
-    _run(sc, st, o, r, W, H, 3, moving=True, stages=stages)
+    bufs = (lambda f: frame_buffers(f) + [abi.BUF_DIRECT_RESV_TEMP]) if variant.startswith("spatial") or variant == "spatiotemporal" else None
+    _run(sc, st, o, r, W, H, 3, moving=True, stages=stages, buffers=bufs)
 
 
 def test_history_upload_roundtrip_and_determinism():

@@ -122,3 +122,30 @@ def test_bsdf_reciprocity_pdf_and_energy():
             assert np.allclose(back[0:3], e[0:3], rtol=2e-3, atol=1e-6)             # reciprocity
             acc += e[0:3] * wi[2] / pdf; cnt += 1
         assert (acc / cnt < 1.6).all()   # the reference BSDF (alpha = roughness, Schlick-G) is not exactly energy conserving; it stays bounded
+
+
+def test_spatial_reuse_modes():
+    """ReSTIRState eSpatial / eSpatiotemporal (direct_stage.comp:224-255): the reuse step runs after every pixel cached its
+    reservoir; it changes the shaded image but not the saved reservoirs, and the cached reservoirs are the pre-clamp ones."""
+    from oracle.binding import Oracle
+    W, H = 64, 48
+    sc, env = make_scene(abi.PROC_SPONZA, 0.01, 1, (64, 32))
+    desc = sc.desc(env)
+    out = {}
+    for mode in (abi.RESTIR_TEMPORAL, abi.RESTIR_SPATIOTEMPORAL, abi.RESTIR_RIS, abi.RESTIR_SPATIAL):
+        st = host.default_state(W, H, sc, env); st.ReSTIRState = mode
+        o = Oracle(0); o.upload_scene(desc); o.resize(W, H)
+        sc.setCamera(*sc.cameraPose()); sc.updateCamera(W, H)
+        for f in range(2):
+            st.time = 500 + f; sc.updateCamera(W, H); o.set_camera(sc.getCamera())
+            o.run_stage(st, f, abi.STAGE_DIRECT)
+        out[mode] = (o.readback(abi.BUF_DIRECT_RESULT0 + 1).view(np.float32).reshape(H, W, 4)[..., :3].copy(),
+                     o.readback(abi.BUF_DIRECT_RESV0 + 1).copy(), o.readback(abi.BUF_DIRECT_RESV_TEMP).copy())
+    for a, b in ((abi.RESTIR_TEMPORAL, abi.RESTIR_SPATIOTEMPORAL), (abi.RESTIR_RIS, abi.RESTIR_SPATIAL)):
+        img_a, resv_a, _ = out[a]; img_b, resv_b, temp_b = out[b]
+        assert np.isfinite(img_b).all()
+        assert np.array_equal(resv_a, resv_b)                      # saveNewReservoir happens before the spatial step
+        assert not np.array_equal(img_a, img_b)                    # the shaded sample went through ten neighbour merges
+        t = temp_b.view(np.uint8).reshape(-1, 36); s = resv_b.view(np.uint8).reshape(-1, 36)
+        num_t = t[:, 28:32].copy().view(np.uint32).ravel(); num_s = s[:, 28:32].copy().view(np.uint32).ravel()
+        assert (num_t >= num_s).all() and (num_t > 0).any()        # cached = un-clamped M
