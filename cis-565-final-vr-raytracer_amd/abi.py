@@ -64,6 +64,10 @@ class SunAndSky(C.Structure):  # rt_sun_and_sky (host_device.h:353-377); default
                 setattr(self, k, v)
 
 assert C.sizeof(SunAndSky) == 96
+
+class PickResult(C.Structure):  # rt_pick_result == nvvk::RayPickerKHR::PickResult
+    _fields_ = [("worldRayOrigin", C.c_float * 4), ("worldRayDirection", C.c_float * 4), ("hitT", C.c_float), ("primitiveID", C.c_int32), ("instanceID", C.c_int32),
+                ("instanceCustomIndex", C.c_int32), ("baryCoord", C.c_float * 3)]
 RT_STAGE_COUNT = 7
 class Counters(C.Structure):  # rt_counters
     _fields_ = [("closestHitRays", C.c_uint64), ("anyHitRays", C.c_uint64), ("nodesVisited", C.c_uint64), ("trisTested", C.c_uint64),

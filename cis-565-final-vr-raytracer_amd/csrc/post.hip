@@ -117,6 +117,34 @@ hipError_t launchSkyPrepare(hipStream_t stream, const rt_sun_and_sky& ss, SkyPre
   return hipGetLastError();
 }
 
+// nvvk::RayPickerKHR stand-in: one ray, lane 0 of one wave (the other lanes stay out of the traversal ballots)
+__global__ __launch_bounds__(64) void k_pick(DevScene S, rt_mat4 viewInv, rt_mat4 projInv, float pickX, float pickY, rt_pick_result* out)
+{
+  extern __shared__ uint2 s_stack[];
+  if(threadIdx.x != 0) return;
+  const f2 d = mk2(pickX, pickY) * 2.0f - 1.0f;
+  const f4 origin = mul(viewInv, mk4(0, 0, 0, 1));
+  const f4 target = mul(projInv, mk4(d.x, d.y, 1, 1));
+  const f4 direction = mul(viewInv, mk4(normalize(xyz(target)), 0));
+  const f3 o = xyz(origin), dir = normalize(xyz(direction));
+  RayHit hit; TravCounters tc{0, 0};
+  traceRay<false>(S, o, dir, RT_INFINITY, 0u, s_stack, hit, tc);
+  rt_pick_result r;
+  r.worldRayOrigin = rt_vec4{o.x, o.y, o.z, 1.0f}; r.worldRayDirection = rt_vec4{dir.x, dir.y, dir.z, 0.0f};
+  r.hitT = hit.t; r.primitiveID = 0; r.instanceID = -1; r.instanceCustomIndex = 0; r.baryCoord = rt_vec3{0, 0, 0};
+  if(hit.gid != 0xffffffffu) {
+    const TriRef tr = S.triRef[hit.gid];
+    r.primitiveID = int32_t(tr.prim); r.instanceID = int32_t(tr.inst); r.instanceCustomIndex = int32_t(S.instances[tr.inst].primMesh);
+    r.baryCoord = rt_vec3{(1.0f - hit.u) - hit.v, hit.u, hit.v};
+  }
+  *out = r;
+}
+hipError_t launchPick(hipStream_t stream, const DevScene& S, const rt_mat4& viewInv, const rt_mat4& projInv, float pickX, float pickY, rt_pick_result* out)
+{
+  hipLaunchKernelGGL(k_pick, dim3(1), dim3(64), size_t(S.stackEntries) * 64 * sizeof(uint2), stream, S, viewInv, projInv, pickX, pickY, out);
+  return hipGetLastError();
+}
+
 hipError_t launchTonemap(hipStream_t stream, const float4* direct, const float4* indirect, double* rowSums, float* mean, const rt_tonemapper& tm, int dbg, int W, int H,
                          uint32_t* ldr)
 {

@@ -720,6 +720,20 @@ int rt_set_pipeline(rt_ctx* c, int pipeline)
   return RT_OK;
 }
 
+int rt_pick(rt_ctx* c, const rt_mat4* modelViewInv, const rt_mat4* perspectiveInv, float pickX, float pickY, rt_pick_result* out)
+{
+  if(!c || !modelViewInv || !perspectiveInv || !out) return RT_ERR_INVALID_ARG;
+  if(!c->haveScene) return fail(c, RT_ERR_NO_SCENE, "no scene uploaded");
+  if(!c->haveAccel) return fail(c, RT_ERR_NO_ACCEL, "rt_build_accel has not been called");
+  RT_HIP(c, hipSetDevice(c->device));
+  if(!c->dSky) RT_HIP(c, hipMalloc(&c->dSky, 512));  // 512 B block: SkyPre in the first 256, the pick result behind it
+  rt_pick_result* d = reinterpret_cast<rt_pick_result*>(static_cast<char*>(c->dSky) + 256);
+  RT_HIP(c, launchPick(c->stream, c->ds, *modelViewInv, *perspectiveInv, pickX, pickY, d));
+  RT_HIP(c, hipMemcpyAsync(out, d, sizeof(*out), hipMemcpyDeviceToHost, c->stream));
+  RT_HIP(c, hipStreamSynchronize(c->stream));
+  return RT_OK;
+}
+
 int rt_set_sun_and_sky(rt_ctx* c, const rt_sun_and_sky* ss)
 {
   if(!c || !ss) return RT_ERR_INVALID_ARG;

@@ -19,6 +19,7 @@ RT_DECL_LAUNCH(sky)
 // uniform-only terms of sun_and_sky() (sky.h), one thread
 struct SkyPre;
 hipError_t launchSkyPrepare(hipStream_t stream, const rt_sun_and_sky& ss, SkyPre* out);
+hipError_t launchPick(hipStream_t stream, const DevScene& S, const rt_mat4& viewInv, const rt_mat4& projInv, float pickX, float pickY, rt_pick_result* out);
 // RenderOutput::run + post.frag as compute (post.hip)
 hipError_t launchTonemap(hipStream_t stream, const float4* direct, const float4* indirect, double* rowSums, float* mean, const rt_tonemapper& tm, int dbg, int W, int H,
                          uint32_t* ldr);

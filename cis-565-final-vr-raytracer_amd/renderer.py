@@ -15,7 +15,7 @@ _lib = None
 # every symbol include/rt_abi.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_build_accel", "rt_resize", "rt_set_camera",
                "rt_render_frame", "rt_run_stage", "rt_readback", "rt_upload_history", "rt_buffer_bytes", "rt_device_ptr",
-               "rt_set_counting", "rt_get_counters", "rt_sync", "rt_last_error", "rt_abi_version", "rt_set_pipeline", "rt_set_history_rows", "rt_history_miss", "rt_set_overlap", "rt_tonemap", "rt_set_sun_and_sky"]
+               "rt_set_counting", "rt_get_counters", "rt_sync", "rt_last_error", "rt_abi_version", "rt_set_pipeline", "rt_set_history_rows", "rt_history_miss", "rt_set_overlap", "rt_tonemap", "rt_set_sun_and_sky", "rt_pick"]
 
 
 def hip_lib():
@@ -54,6 +54,7 @@ def hip_lib():
         L.rt_set_overlap.argtypes = [C.c_void_p, C.c_int]
         L.rt_tonemap.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.rt_set_sun_and_sky.argtypes = [C.c_void_p, C.c_void_p]
+        L.rt_pick.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
         L.rt_set_history_rows.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.rt_history_miss.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.rt_get_counters.argtypes = [C.c_void_p, C.c_void_p]
@@ -159,6 +160,12 @@ class Renderer:
         """RenderOutput::run (render_output.cpp:224-237): post.frag over the result images of `frames` -> BUF_LDR (RGBA8)."""
         tm = tm if tm is not None else abi.Tonemapper()
         self._chk(hip_lib().rt_tonemap(self._h, C.byref(tm), debugging_mode, frames), "rt_tonemap")
+
+    def pick(self, view_inv, proj_inv, x, y):
+        """SampleExample::screenPicking (sample_example.cpp:456-497): x, y = normalised window position; returns abi.PickResult."""
+        out = abi.PickResult()
+        self._chk(hip_lib().rt_pick(self._h, C.byref(view_inv), C.byref(proj_inv), x, y, C.byref(out)), "rt_pick")
+        return out
 
     def set_sun_and_sky(self, ss):
         """updateUniformBuffer's SunAndSky upload (sample_example.cpp:172); ss.in_use = 1 switches the environment to the procedural sky."""

@@ -359,6 +359,16 @@ int rt_history_miss(rt_ctx* ctx, int* missed);
  * uninitialised variable in the reference, post.frag:92) uses the global operator. */
 int rt_tonemap(rt_ctx* ctx, const rt_tonemapper* tm, int debugging_mode, int frames);
 int rt_set_pipeline(rt_ctx* ctx, int pipeline);
+/* SampleExample::screenPicking (sample_example.cpp:456-497): nvvk::RayPickerKHR — one camera ray through the normalised
+ * window position (pickX, pickY in [0,1]) built like raySpawn (origin = modelViewInv * (0,0,0,1), direction = modelViewInv *
+ * normalize(perspectiveInv * (2*pick-1, 1, 1))), traced with the path's ClosestHit rules.  The result mirrors
+ * nvvk::RayPickerKHR::PickResult; instanceID == -1 => nothing hit. */
+typedef struct {
+  rt_vec4 worldRayOrigin, worldRayDirection;
+  float hitT; int32_t primitiveID; int32_t instanceID; int32_t instanceCustomIndex;
+  rt_vec3 baryCoord;
+} rt_pick_result;
+int rt_pick(rt_ctx* ctx, const rt_mat4* modelViewInv, const rt_mat4* perspectiveInv, float pickX, float pickY, rt_pick_result* out);
 /* SampleExample::updateUniformBuffer's vkCmdUpdateBuffer(m_sunAndSkyBuffer, ...) (sample_example.cpp:172): the procedural
  * sun & sky environment.  With in_use == 1 EnvRadiance / EnvSample / EnvEval (pathtrace.glsl:40-72, env_sampling.glsl:105-135)
  * evaluate sun_and_sky() (sun_and_sky.glsl:453-601) instead of the HDR map.  Default: in_use = 0. */

@@ -48,6 +48,7 @@ def lib():
         L.orc_set_history_rows.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orc_tonemap.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.orc_set_sun_and_sky.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_pick.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
         L.orc_sun_and_sky_eval.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_history_miss.argtypes = [C.c_void_p]
         L.orc_buffer_ptr.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
@@ -80,6 +81,11 @@ class Oracle:
     def run_stage(self, state, frames, stage, level=0, row_begin=0, row_end=0):
         self._chk(lib().orc_run_stage(self._h, C.byref(state), frames, stage, level, row_begin, row_end), "run_stage")
     def set_sun_and_sky(self, ss): self._chk(lib().orc_set_sun_and_sky(self._h, C.byref(ss)), "set_sun_and_sky")
+    def pick(self, view_inv, proj_inv, x, y):
+        from restir_amd import abi
+        out = abi.PickResult()
+        self._chk(lib().orc_pick(self._h, C.byref(view_inv), C.byref(proj_inv), x, y, C.byref(out)), "pick")
+        return out
     def tonemap(self, tm, debugging_mode=0, frames=0):
         self._chk(lib().orc_tonemap(self._h, C.byref(tm), debugging_mode, frames), "tonemap")
     def buffer_bytes(self, buf): return lib().orc_buffer_bytes(self._h, buf)

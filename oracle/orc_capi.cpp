@@ -143,6 +143,25 @@ void orc_sun_and_sky_eval(const rt_sun_and_sky* ss, int n, const float* dirs, fl
 {
   for(int i = 0; i < n; i++) { vec3 r = sky::sun_and_sky(*ss, V3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2])); out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z; }
 }
+int orc_pick(void* p, const rt_mat4* viewInv, const rt_mat4* projInv, float pickX, float pickY, rt_pick_result* out)
+{
+  Ctx* c = static_cast<Ctx*>(p);
+  if(!c->haveScene) return RT_ERR_NO_SCENE;
+  const vec2 d = V2(pickX, pickY) * 2.0f - 1.0f;
+  const vec4 origin = mul(*reinterpret_cast<const mat4*>(viewInv), V4(0, 0, 0, 1));
+  const vec4 target = mul(*reinterpret_cast<const mat4*>(projInv), V4(d.x, d.y, 1, 1));
+  const vec4 direction = mul(*reinterpret_cast<const mat4*>(viewInv), V4(normalize(xyz(target)), 0));
+  const vec3 o = xyz(origin), dir = normalize(xyz(direction));
+  const Hit h = c->scene.closestHit(o, dir, 0u);
+  out->worldRayOrigin = rt_vec4{o.x, o.y, o.z, 1.0f}; out->worldRayDirection = rt_vec4{dir.x, dir.y, dir.z, 0.0f};
+  out->hitT = h.t; out->primitiveID = 0; out->instanceID = -1; out->instanceCustomIndex = 0; out->baryCoord = rt_vec3{0, 0, 0};
+  if(h.tri != 0xffffffffu) {
+    const Tri& t = c->scene.tris[h.tri];
+    out->primitiveID = int32_t(t.prim); out->instanceID = int32_t(t.inst); out->instanceCustomIndex = int32_t(c->scene.instances[t.inst].primMesh);
+    out->baryCoord = rt_vec3{(1.0f - h.u) - h.v, h.u, h.v};
+  }
+  return RT_OK;
+}
 int orc_tonemap(void* p, const rt_tonemapper* tm, int dbg, int frames)
 {
   Ctx* c = static_cast<Ctx*>(p);

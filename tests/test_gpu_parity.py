@@ -181,3 +181,21 @@ def test_error_paths():
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
+
+
+def test_pick_matches_oracle():
+    """rt_pick (SampleExample::screenPicking / nvvk::RayPickerKHR stand-in): same hit record as the oracle for a grid of window positions."""
+    W, H = 64, 64
+    sc, env = make_scene(abi.PROC_SPONZA, 0.02, 1)
+    o, r = _pair(sc, None, W, H, wavefront=False)
+    sc.updateCamera(W, H)
+    cam = sc.getCamera()
+    hits = 0
+    for y in np.linspace(0.05, 0.95, 7):
+        for x in np.linspace(0.05, 0.95, 7):
+            a = r.pick(cam.viewInverse, cam.projInverse, float(x), float(y)); b = o.pick(cam.viewInverse, cam.projInverse, float(x), float(y))
+            assert bytes(a) == bytes(b), (x, y)
+            hits += a.instanceID >= 0
+            if a.instanceID >= 0:
+                assert abs(sum(a.baryCoord) - 1.0) < 1e-5 and a.hitT > 0
+    assert hits > 20
