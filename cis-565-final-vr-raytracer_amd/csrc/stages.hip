@@ -4,7 +4,7 @@
 //   k_direct_gen       direct_gen.comp:77-149     (compiled by the reference, dispatch disabled: renderer.cpp:166-168)
 //   k_direct_reuse     direct_reuse.comp:102-153  (idem, renderer.cpp:170-171)
 //   k_indirect_stage   indirect_stage.comp:129-309, half resolution, tile-level multi-bounce
-//   k_denoise<IND>     denoise_direct.comp / denoise_indirect.comp: one edge-avoiding A-Trous level
+//   k_denoise<IND,FAST> denoise_direct.comp / denoise_indirect.comp: one edge-avoiding A-Trous level
 //   k_compose          compose.comp:23-43
 //
 // Launch shape: one wave64 per 8x8 pixel tile (= the reference's 8x8 workgroups, host_device.h:31-38), 1-D grid with
@@ -463,11 +463,6 @@ __global__ __launch_bounds__(64, 4) void k_indirect_stage(DevScene S, DevFrame F
 // ------------------------------------------------------------------------------------------------------------
 // denoise_common.glsl + denoise_direct.comp + denoise_indirect.comp
 // ------------------------------------------------------------------------------------------------------------
-__constant__ float c_gauss[5][5] = {{.0030f, .0133f, .0219f, .0133f, .0030f},
-                                    {.0133f, .0596f, .0983f, .0596f, .0133f},
-                                    {.0219f, .0983f, .1621f, .0983f, .0219f},
-                                    {.0133f, .0596f, .0983f, .0596f, .0133f},
-                                    {.0030f, .0133f, .0219f, .0133f, .0030f}};  // denoise_common.glsl:15-21
 
 // denoise_common.glsl:27-40: the direction is not re-normalised after the view transform
 RT_DEV f3 cameraPosDenoise(const rt_scene_camera& cam, i2 coord, float dist, i2 imageSize)
@@ -502,8 +497,77 @@ __global__ __launch_bounds__(64) void k_denoise_geom(DevFrame F, rt_state st, rt
   (IND ? F.geomPh : F.geomP)[idx] = make_float4(pos.x, pos.y, pos.z, 0.f);
 }
 
-template <bool IND>
-__global__ __launch_bounds__(64) void k_denoise(DevFrame F, rt_state st, const float4* src, float4* dst, int level, int rowBegin, int rowEnd, int tilesX, int tilesY)
+// exp(x) for x <= 0 or NaN, bit-identical to rt_exp() on that domain (same range reduction, polynomial and scaling; the
+// x > 88.7 early-out of rt_exp cannot trigger) but with selects instead of branches.
+RT_DEV float expNonPositive(float x)
+{
+  const float z = rt_floor(x * 1.44269504088896341f + 0.5f);
+  const int n = max(rt_ftoi(z), -300);
+  float r = x - z * 0.693359375f;
+  r = r - z * -2.12194440e-4f;
+  const float rr = r * r;
+  float p = 1.9875691500E-4f;
+  p = p * r + 1.3981999507E-3f;
+  p = p * r + 8.3334519073E-3f;
+  p = p * r + 4.1665795894E-2f;
+  p = p * r + 1.6666665459E-1f;
+  p = p * r + 5.0000001201E-1f;
+  p = p * rr + r;
+  p = p + 1.0f;
+  const int a = n >> 1, b = n - a;
+  float e = (p * rt_u2f(uint32_t(a + 127) << 23)) * rt_u2f(uint32_t(b + 127) << 23);
+  e = (x < -87.33654475055310f) ? 0.0f : e;
+  return rt_isnan(x) ? x : e;
+}
+
+// a / b for a uniform divisor b with y = RN(1 / b) precomputed by an IEEE division: q = RN(a*y), r = a - b*q (exact, fma),
+// q' = RN(q + r*y) is the correctly rounded quotient (Markstein 1990, Theorem 7.1: holds when y is the correctly rounded
+// reciprocal and no intermediate leaves the normal range).  launchStage enables this path only for 1e-6 <= b <= 1e6; then the
+// residual r is a normal number whenever |a/b| >= 2^-25, and below that exp(-a/b) is exactly 1 whatever the last bit of the
+// quotient.  Non-finite a takes the plain division.
+template <bool FAST>
+RT_DEV float divUniform(float a, float b, float y)
+{
+  if(!FAST) return a / b;
+  const float q = a * y;
+  const float r = __builtin_fmaf(-b, q, a);
+  const float q2 = __builtin_fmaf(r, y, q);
+  return (a <= 3.0e38f) ? q2 : a / b;
+}
+
+__device__ constexpr float kGauss[5][5] = {{.0030f, .0133f, .0219f, .0133f, .0030f},
+                                {.0133f, .0596f, .0983f, .0596f, .0133f},
+                                {.0219f, .0983f, .1621f, .0983f, .0219f},
+                                {.0133f, .0596f, .0983f, .0596f, .0133f},
+                                {.0030f, .0133f, .0219f, .0133f, .0030f}};  // denoise_common.glsl:15-21
+
+// One tap of waveletFilter.  CHECK: the tap may fall outside the image (border tiles); interior tiles skip the tests.
+template <bool IND, bool FAST, bool CHECK>
+RT_DEV void denoiseTap(const float4* __restrict__ src, const float4* __restrict__ gN, const float4* __restrict__ gP, int pitch, i2 bound, i2 q, float gauss, f3 color, f3 norm,
+                       f3 pos, uint32_t matHash, float sigL, float sigN, float sigD, float yL, float yN, float yD, f3& sum, float& sumWeight)
+{
+  if(CHECK) { if(q.x >= bound.x || q.y >= bound.y || q.x < 0 || q.y < 0) return; }
+  const size_t qi = size_t(q.y) * bound.x + q.x;
+  const float4 qN = gN[qi];
+  const uint32_t matHashQ = rt_f2u(qN.w);
+  if(matHash != matHashQ || matHashQ == RT_INVALID_MAT_ID) return;
+  const float4 qP = gP[qi];
+  const float4 cq = src[size_t(q.y) * pitch + q.x];
+  const f3 normQ = mk3(qN.x, qN.y, qN.z), posQ = mk3(qP.x, qP.y, qP.z), colorQ = mk3(cq.x, cq.y, cq.z);
+  const float distColor = IND ? dot(color - colorQ, color - colorQ) : rt_abs(luminance(color) - luminance(colorQ));
+  const float wColor = expNonPositive(-divUniform<FAST>(distColor, sigL, yL)) + 1e-2f;
+  const float distNorm2 = dot(norm - normQ, norm - normQ);
+  const float wNorm = rt_min(1.0f, expNonPositive(-divUniform<FAST>(distNorm2, sigN, yN)));
+  const float distPos2 = dot(pos - posQ, pos - posQ);
+  const float wDepth = expNonPositive(-divUniform<FAST>(distPos2, sigD, yD)) + 1e-2f;
+  const float weight = wColor * wNorm * wDepth * gauss;
+  sum += colorQ * weight;
+  sumWeight += weight;
+}
+
+template <bool IND, bool FAST>
+__global__ __launch_bounds__(64) void k_denoise(DevFrame F, rt_state st, const float4* src, float4* dst, int level, int rowBegin, int rowEnd, int tilesX, int tilesY, float yL,
+                                                float yN, float yD)
 {
   const TileCoord tile = tileOf(tilesX, tilesY);
   if(!tile.valid) return;
@@ -529,27 +593,22 @@ __global__ __launch_bounds__(64) void k_denoise(DevFrame F, rt_state st, const f
     f3 sum = mk3(0.0f);
     float sumWeight = 0.0f;
     const f3 color = xyz(loadImg(src, F, coord));
-    for(int j = -2; j <= 2; j++) {
-      for(int i = -2; i <= 2; i++) {
-        const i2 q{coord.x + i * step, coord.y + j * step};
-        if(q.x >= bound.x || q.y >= bound.y || q.x < 0 || q.y < 0) continue;
-        const size_t qi = size_t(q.y) * bound.x + q.x;
-        const float4 qN = gN[qi];
-        const uint32_t matHashQ = rt_f2u(qN.w);
-        if(matHash != matHashQ || matHashQ == RT_INVALID_MAT_ID) continue;
-        const float4 qP = gP[qi];
-        const f3 normQ = mk3(qN.x, qN.y, qN.z), posQ = mk3(qP.x, qP.y, qP.z);
-        const f3 colorQ = xyz(loadImg(src, F, q));
-        const float distColor = IND ? dot(color - colorQ, color - colorQ) : rt_abs(luminance(color) - luminance(colorQ));
-        const float wColor = rt_exp(-distColor / sigLumin) + 1e-2f;
-        const float distNorm2 = dot(norm - normQ, norm - normQ);
-        const float wNorm = rt_min(1.0f, rt_exp(-distNorm2 / sigNormal));
-        const float distPos2 = dot(pos - posQ, pos - posQ);
-        const float wDepth = rt_exp(-distPos2 / sigDepth) + 1e-2f;
-        const float weight = wColor * wNorm * wDepth * c_gauss[i + 2][j + 2];
-        sum += colorQ * weight;
-        sumWeight += weight;
-      }
+    // wave-uniform: every tap of every pixel of this 8x8 tile lies inside the image
+    const int tx0 = tile.x * 8, ty0 = rowBegin + tile.y * 8;
+    const bool interior = tx0 - 2 * step >= 0 && ty0 - 2 * step >= 0 && tx0 + 7 + 2 * step < bound.x && ty0 + 7 + 2 * step < bound.y;
+    // the accumulation order of the reference's loops (j outer, i inner) is kept: float sums are order dependent
+    if(interior) {
+#pragma unroll
+      for(int j = -2; j <= 2; j++)
+#pragma unroll
+        for(int i = -2; i <= 2; i++)
+          denoiseTap<IND, FAST, false>(src, gN, gP, F.W, bound, i2{coord.x + i * step, coord.y + j * step}, kGauss[i + 2][j + 2], color, norm, pos, matHash, sigLumin,
+                                       sigNormal, sigDepth, yL, yN, yD, sum, sumWeight);
+    } else {
+      for(int j = -2; j <= 2; j++)
+        for(int i = -2; i <= 2; i++)
+          denoiseTap<IND, FAST, true>(src, gN, gP, F.W, bound, i2{coord.x + i * step, coord.y + j * step}, kGauss[i + 2][j + 2], color, norm, pos, matHash, sigLumin,
+                                      sigNormal, sigDepth, yL, yN, yD, sum, sumWeight);
     }
     res = (sumWeight < 1e-5f) ? mk3(0.0f) : sum / sumWeight;
     if(hasNan(res) || res.x < 0 || res.y < 0 || res.z < 0 || res.x > 1e8f || res.y > 1e8f || res.z > 1e8f) res = mk3(0.0f);
@@ -584,6 +643,9 @@ __global__ __launch_bounds__(64) void k_compose(DevFrame F, rt_state st, int row
 // ------------------------------------------------------------------------------------------------------------
 // host-side launch (one entry of Renderer::run's dispatch list, renderer.cpp:163-205)
 // ------------------------------------------------------------------------------------------------------------
+// divUniform's fast path: the divisor must keep every intermediate in the normal range (see there)
+static bool uniformDivOk(float s) { return s >= 1e-6f && s <= 1e6f; }
+
 hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F, const rt_state& st, const rt_scene_camera& cam, int stage, int level,
                        int rowBegin, int rowEnd)
 {
@@ -625,7 +687,11 @@ hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F,
         const int gty = (g1 - g0 + 7) / 8;
         hipLaunchKernelGGL(k_denoise_geom<false>, dim3(tileGrid(tilesX, gty)), block, 0, stream, F, st, cam, g0, g1, tilesX, gty);
       }
-      hipLaunchKernelGGL(k_denoise<false>, grid, block, 0, stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, tilesX, tilesY);
+      if(uniformDivOk(st.sigLuminDirect) && uniformDivOk(st.sigNormalDirect) && uniformDivOk(st.sigDepthDirect))
+        hipLaunchKernelGGL((k_denoise<false, true>), grid, block, 0, stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, tilesX, tilesY,
+                           1.0f / st.sigLuminDirect, 1.0f / st.sigNormalDirect, 1.0f / st.sigDepthDirect);
+      else
+        hipLaunchKernelGGL((k_denoise<false, false>), grid, block, 0, stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, tilesX, tilesY, 0.f, 0.f, 0.f);
       break;
     }
     case RT_STAGE_DENOISE_INDIRECT: {
@@ -639,7 +705,11 @@ hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F,
         const int gty = (g1 - g0 + 7) / 8;
         hipLaunchKernelGGL(k_denoise_geom<true>, dim3(tileGrid(tilesX, gty)), block, 0, stream, F, st, cam, g0, g1, tilesX, gty);
       }
-      hipLaunchKernelGGL(k_denoise<true>, grid, block, 0, stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, tilesX, tilesY);
+      if(uniformDivOk(st.sigLuminIndirect) && uniformDivOk(st.sigNormalIndirect) && uniformDivOk(st.sigDepthIndirect))
+        hipLaunchKernelGGL((k_denoise<true, true>), grid, block, 0, stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, tilesX, tilesY,
+                           1.0f / st.sigLuminIndirect, 1.0f / st.sigNormalIndirect, 1.0f / st.sigDepthIndirect);
+      else
+        hipLaunchKernelGGL((k_denoise<true, false>), grid, block, 0, stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, tilesX, tilesY, 0.f, 0.f, 0.f);
       break;
     }
     case RT_STAGE_COMPOSE: hipLaunchKernelGGL(k_compose, grid, block, 0, stream, F, st, rowBegin, rowEnd, tilesX, tilesY); break;

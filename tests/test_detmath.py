@@ -3,7 +3,7 @@ import ctypes as C
 import numpy as np
 from oracle.binding import lib
 
-OPS = {"exp": 0, "log": 1, "pow": 2, "sin": 3, "cos": 4, "asin": 5, "acos": 6, "atan2": 7}
+OPS = {"exp": 0, "log": 1, "pow": 2, "sin": 3, "cos": 4, "asin": 5, "acos": 6, "atan2": 7, "tan": 8, "div_uniform": 9, "exp_nonpos": 10}
 
 
 def det(op, a, b=None):
@@ -50,3 +50,31 @@ def test_pow_srgb():
     ref = np.power(x.astype(np.float64), np.float64(np.float32(2.2)))
     rel = np.abs(got[1:] - ref[1:]) / ref[1:]
     assert rel.max() < 4e-6 and got[0] == 0.0
+
+
+def test_uniform_divisor_shortcut_is_ieee_division():
+    """csrc/stages.hip divUniform (A-Trous weights: distance / sigma): q' = fma(a - b*q, 1/b, q) equals RN(a/b) for every tested
+    numerator, for divisors in the range launchStage accepts (1e-6 .. 1e6)."""
+    rng = np.random.default_rng(5)
+    sig = np.concatenate([[0.4, 0.1, 0.02, 4.0, 1.0, 1e-6, 1e6, 0.3333333, 0.99999994, 1.9999999], np.exp(rng.uniform(np.log(1e-6), np.log(1e6), 90))]).astype(np.float32)
+    for b in sig:
+        a = np.concatenate([np.exp(rng.uniform(np.log(2.0 ** -25) + np.log(b), 40.0, 60000)), rng.random(20000), [0.0, b, 3 * b, b / 3]]).astype(np.float32)
+        got = det("div_uniform", a, np.full_like(a, b))
+        want = a / b                                    # numpy float32 division = IEEE
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (b, int((got != want).sum()))
+    # below 2^-25 * sigma the quotient may differ in the last bit (subnormal residual) but exp(-q) is exactly 1 for both
+    a = (np.float32(0.4) * np.exp(rng.uniform(-80, np.log(2.0 ** -25), 20000))).astype(np.float32)
+    q1 = det("div_uniform", a, np.full_like(a, 0.4)); q2 = a / np.float32(0.4)
+    assert (det("exp", -q1) == 1.0).all() and (det("exp", -q2) == 1.0).all()
+
+
+def test_branch_free_exp_equals_rt_exp_on_nonpositive_arguments():
+    x = -np.concatenate([np.geomspace(1e-30, 200.0, 300001), np.linspace(0, 90, 200001), [0.0, np.inf]]).astype(np.float32)
+    a, b = det("exp_nonpos", x), det("exp", x)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.isnan(det("exp_nonpos", [np.nan])[0])
+
+
+def test_tan_is_sin_over_cos():
+    x = np.linspace(-1.5, 1.5, 100001, dtype=np.float32)
+    assert ulp_err(det("tan", x), np.tan(x.astype(np.float64))).max() <= 8.0
