@@ -71,7 +71,8 @@ class PickResult(C.Structure):  # rt_pick_result == nvvk::RayPickerKHR::PickResu
 RT_STAGE_COUNT = 7
 class Counters(C.Structure):  # rt_counters
     _fields_ = [("closestHitRays", C.c_uint64), ("anyHitRays", C.c_uint64), ("nodesVisited", C.c_uint64), ("trisTested", C.c_uint64),
-                ("hitsShaded", C.c_uint64), ("risCandidates", C.c_uint64), ("stageMs", C.c_float * RT_STAGE_COUNT), ("frameMs", C.c_float), ("framesTimed", C.c_uint32)]
+                ("hitsShaded", C.c_uint64), ("risCandidates", C.c_uint64), ("stageMs", C.c_float * RT_STAGE_COUNT), ("frameMs", C.c_float), ("framesTimed", C.c_uint32),
+                ("laneRounds", C.c_uint64), ("laneLiveRounds", C.c_uint64)]
 
 assert C.sizeof(SceneCamera) == 336 and C.sizeof(RtxState) == 100
 

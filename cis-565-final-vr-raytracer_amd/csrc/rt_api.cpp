@@ -685,7 +685,7 @@ int rt_get_counters(rt_ctx* c, rt_counters* out)
   RT_HIP(c, syncAll(c));
   unsigned long long h[8];
   RT_HIP(c, hipMemcpy(h, c->dCounters, sizeof(h), hipMemcpyDeviceToHost));
-  out->closestHitRays = h[0]; out->anyHitRays = h[1]; out->nodesVisited = h[2]; out->trisTested = h[3]; out->hitsShaded = h[4]; out->risCandidates = h[5];
+  out->closestHitRays = h[0]; out->anyHitRays = h[1]; out->nodesVisited = h[2]; out->trisTested = h[3]; out->hitsShaded = h[4]; out->risCandidates = h[5]; out->laneRounds = h[6]; out->laneLiveRounds = h[7];
   harvestTimings(c);
   for(int i = 0; i < RT_STAGE_COUNT; i++) out->stageMs[i] = float(c->accStage[i]);
   out->frameMs = float(c->accFrame);

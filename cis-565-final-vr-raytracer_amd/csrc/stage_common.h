@@ -40,6 +40,8 @@ RT_DEV void flushCounters(const DevFrame& F, const Ctx& c)
   atomicAdd(&F.counters[3], (unsigned long long)c.tc.tris);
   atomicAdd(&F.counters[4], (unsigned long long)c.nShaded);
   atomicAdd(&F.counters[5], (unsigned long long)c.nRis);
+  atomicAdd(&F.counters[6], (unsigned long long)c.tc.rounds);
+  atomicAdd(&F.counters[7], (unsigned long long)c.tc.live);
 }
 
 // ---- image helpers: Vulkan storage-image semantics (out-of-bounds loads return 0) ------------------------------

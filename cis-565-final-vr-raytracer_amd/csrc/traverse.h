@@ -21,7 +21,7 @@ struct RayHit {
   float u, v;
 };
 
-struct TravCounters { uint32_t nodes, tris; };
+struct TravCounters { uint32_t nodes, tris, rounds, live; };
 
 // ---- texture fetch: Vulkan sampler restatement, LOD 0 (scene.cpp:513-548) -----------------
 RT_DEV int wrapCoord(int i, int n, int mode)
@@ -292,6 +292,7 @@ RT_DEV void travTri(const DevScene& S, Trav& T, TravCounters& tc)
 template <int ANY>
 RT_DEV bool travRound(const DevScene& S, Trav& T, bool live, uint2* stack, TravCounters& tc)
 {
+  tc.rounds++; tc.live += live ? 1u : 0u;
   const bool wantTri = live && travHasTris(T);
   const bool wantNode = live && !wantTri;
   const int nT = __popcll(__ballot(wantTri ? 1 : 0)), nN = __popcll(__ballot(wantNode ? 1 : 0));

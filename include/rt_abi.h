@@ -289,6 +289,11 @@ typedef struct {
   float stageMs[RT_STAGE_COUNT];
   float frameMs;
   uint32_t framesTimed;
+  /* SIMD efficiency of the traversal loops (counting mode): summed over lanes, the scheduling rounds a lane sat through while
+   * its wave was traversing (laneRounds) and the rounds in which it still had a ray to advance (laneLiveRounds).
+   * (nodesVisited + trisTested) / laneLiveRounds = share of live lanes the majority vote lets step;
+   * laneLiveRounds / laneRounds = share of lanes that are not just waiting for the slowest ray of their wave. */
+  uint64_t laneRounds, laneLiveRounds;
 } rt_counters;
 
 typedef enum {

@@ -28,7 +28,7 @@ with open(out + "/summary.txt", "w") as fo:
         for c, v in sorted(d.items()):
             fo.write("   %-28s %16.1f per launch (%d launches)\n" % (c, v / calls[(k, c)], calls[(k, c)]))
 import json
-traffic = {k.replace("void ", "").split("<")[0].replace("rt::", ""): {"FETCH_SIZE_KB": d.get("FETCH_SIZE", 0) / max(1, calls[(k, "FETCH_SIZE")]),
+traffic = {k.replace("void ", "").split("<")[0].split("::")[-1]: {"FETCH_SIZE_KB": d.get("FETCH_SIZE", 0) / max(1, calls[(k, "FETCH_SIZE")]),
                                                               "WRITE_SIZE_KB": d.get("WRITE_SIZE", 0) / max(1, calls[(k, "WRITE_SIZE")])}
            for k, d in agg.items() if k.startswith(("rt::", "void rt::"))}
 json.dump(traffic, open(out + "/pmc_traffic.json", "w"), indent=1)
