@@ -73,6 +73,8 @@ __global__ __launch_bounds__(64) void k_trace(DevScene S, DevFrame F, const uint
     atomicAdd(&F.counters[ANY ? 1 : 0], 1ull);
     atomicAdd(&F.counters[2], (unsigned long long)tc.nodes);
     atomicAdd(&F.counters[3], (unsigned long long)tc.tris);
+    atomicAdd(&F.counters[6], (unsigned long long)tc.rounds);
+    atomicAdd(&F.counters[7], (unsigned long long)tc.live);
   }
 }
 
@@ -145,6 +147,8 @@ __global__ __launch_bounds__(64) void k_trace_p(DevScene S, DevFrame F, rt_state
     atomicAdd(&F.counters[ANY ? 1 : 0], (unsigned long long)nRays);
     atomicAdd(&F.counters[2], (unsigned long long)tc.nodes);
     atomicAdd(&F.counters[3], (unsigned long long)tc.tris);
+    atomicAdd(&F.counters[6], (unsigned long long)tc.rounds);
+    atomicAdd(&F.counters[7], (unsigned long long)tc.live);
   }
 }
 
@@ -174,6 +178,8 @@ __global__ __launch_bounds__(64) void k_primary(DevScene S, DevFrame F, rt_state
     atomicAdd(&F.counters[0], 1ull);
     atomicAdd(&F.counters[2], (unsigned long long)tc.nodes);
     atomicAdd(&F.counters[3], (unsigned long long)tc.tris);
+    atomicAdd(&F.counters[6], (unsigned long long)tc.rounds);
+    atomicAdd(&F.counters[7], (unsigned long long)tc.live);
   }
 }
 
