@@ -83,7 +83,8 @@ def main():
         torch.cuda.set_stream(stream)
         r.set_stream(stream.cuda_stream)
     comm = tiled.TorchComm() if world > 1 else tiled.LocalComm()
-    frame = tiled.TiledFrame(tiled.RendererTensors(r), comm, W, H) if world > 1 else None
+    Frame = tiled.TiledFrame if os.environ.get("RESTIR_TILED") == "serial" else tiled.PipelinedTiledFrame
+    frame = Frame(tiled.RendererTensors(r), comm, W, H) if world > 1 else None
     if world == 1 and args.emulate_world > 1:
         class StubComm(tiled.LocalComm):   # per-rank compute + host overhead of the tiled schedule, no real peers
             world = args.emulate_world
@@ -92,7 +93,7 @@ def main():
             def halo_exchange(self, items, async_op=False): return []
             def gather_rows_to(self, *a, **k): return None
             def any_flag(self, flag): return False
-        frame = tiled.TiledFrame(tiled.RendererTensors(r), StubComm(), W, H)
+        frame = Frame(tiled.RendererTensors(r), StubComm(), W, H)
 
     scene.updateCamera(W, H)  # prime the camera history (static camera: SURVEY.md §8d)
 
@@ -158,7 +159,7 @@ def main():
             "config": {"workload": f"bistro-exterior-class procedural scene, {scene.getStat()['instancedTriangles']} triangles, {W}x{H}, "
                                    "ReSTIR DI (temporal, M=4) + GI (maxDepth 4, MIS) + A-Trous 4+5 levels + compose, static camera, "
                                    "2048x1024 synthetic HDR sky", "width": W, "height": H, "scene_scale": args.scale,
-                       "parallelism": ("single GPU" if frame is None else f"ONE rank of an emulated {args.emulate_world}-way row tiling, communication stubbed (not a benchmark result)") if world == 1 else f"row-tiled x{world}, in-place all-gather + neighbour halos over RCCL",
+                       "parallelism": ("single GPU" if frame is None else f"ONE rank of an emulated {args.emulate_world}-way row tiling, communication stubbed (not a benchmark result)") if world == 1 else f"row-tiled x{world}: frames in flight on 3 streams per rank, neighbour halo exchanges over RCCL (restir_amd/tiled.py PipelinedTiledFrame)",
                        "rays_per_frame": round(rays_per_frame), "fps": round(1e3 / ms_per_step, 2), "bvh8_build_s": round(build_s, 2),
                        "accel": r.accel_stats()},
         }

@@ -519,7 +519,8 @@ int rt_run_stage(rt_ctx* c, const rt_state* st, int frames, int stage, int level
   if(rowBegin < 0 || (rowBegin & 7)) return fail(c, RT_ERR_INVALID_ARG, "rt_run_stage: rowBegin must be a non-negative multiple of 8");
   RT_HIP(c, hipSetDevice(c->device));
   RT_HIP(c, joinInFlight(c));
-  const DevFrame F = makeFrame(c, frames);
+  DevFrame F = makeFrame(c, frames);
+  if(stage == RT_STAGE_INDIRECT) F.histMiss = c->scratch.qcount + 251;  // per-stage-kind flag (rt_history_miss_stage)
   RT_HIP(c, stageLauncher(c)(c->stream, c->ds, F, *st, c->cam, stage, level, rowBegin, rowEnd));
   return RT_OK;
 }
@@ -705,11 +706,35 @@ int rt_history_miss(rt_ctx* c, int* missed)
   if(!c || !missed) return RT_ERR_INVALID_ARG;
   if(c->W == 0) return fail(c, RT_ERR_NO_TARGET, "rt_history_miss: rt_resize has not been called");
   RT_HIP(c, hipSetDevice(c->device));
-  uint32_t v = 0;
-  RT_HIP(c, hipMemcpyAsync(&v, c->scratch.qcount + 250, sizeof(v), hipMemcpyDeviceToHost, c->stream));
-  RT_HIP(c, hipMemsetAsync(c->scratch.qcount + 250, 0, sizeof(v), c->stream));
+  uint32_t v[2] = {0, 0};
   RT_HIP(c, syncAll(c));
+  RT_HIP(c, hipMemcpyAsync(v, c->scratch.qcount + 250, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+  RT_HIP(c, hipMemsetAsync(c->scratch.qcount + 250, 0, sizeof(v), c->stream));
+  RT_HIP(c, hipStreamSynchronize(c->stream));
+  *missed = (v[0] | v[1]) ? 1 : 0;
+  return RT_OK;
+}
+
+int rt_history_miss_stage(rt_ctx* c, int stage, int* missed)
+{
+  if(!c || !missed || stage < 0 || stage >= RT_STAGE_COUNT) return RT_ERR_INVALID_ARG;
+  if(c->W == 0) return fail(c, RT_ERR_NO_TARGET, "rt_history_miss_stage: rt_resize has not been called");
+  RT_HIP(c, hipSetDevice(c->device));
+  uint32_t* flag = c->scratch.qcount + 250 + (stage == RT_STAGE_INDIRECT ? 1 : 0);
+  uint32_t v = 0;
+  RT_HIP(c, hipMemcpyAsync(&v, flag, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+  RT_HIP(c, hipMemsetAsync(flag, 0, sizeof(v), c->stream));
+  RT_HIP(c, hipStreamSynchronize(c->stream));  // the ctx stream only: other streams of the host keep running
   *missed = v ? 1 : 0;
+  return RT_OK;
+}
+
+int rt_rotate_buffers(rt_ctx* c, int frames)
+{
+  if(!c) return RT_ERR_INVALID_ARG;
+  if(c->W == 0 || !c->spareG || !c->spareMotion) return fail(c, RT_ERR_NO_TARGET, "rt_rotate_buffers: rt_resize has not been called");
+  std::swap(c->bufs[RT_BUF_GBUFFER0 + (frames & 1)], c->spareG);
+  std::swap(c->bufs[RT_BUF_MOTION], c->spareMotion);
   return RT_OK;
 }
 

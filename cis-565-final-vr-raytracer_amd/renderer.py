@@ -15,7 +15,7 @@ _lib = None
 # every symbol include/rt_abi.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_build_accel", "rt_resize", "rt_set_camera",
                "rt_render_frame", "rt_run_stage", "rt_readback", "rt_upload_history", "rt_buffer_bytes", "rt_device_ptr",
-               "rt_set_counting", "rt_get_counters", "rt_sync", "rt_last_error", "rt_abi_version", "rt_set_pipeline", "rt_set_history_rows", "rt_history_miss", "rt_set_overlap", "rt_tonemap", "rt_set_sun_and_sky", "rt_pick"]
+               "rt_set_counting", "rt_get_counters", "rt_sync", "rt_last_error", "rt_abi_version", "rt_set_pipeline", "rt_set_history_rows", "rt_history_miss", "rt_set_overlap", "rt_tonemap", "rt_set_sun_and_sky", "rt_pick", "rt_history_miss_stage", "rt_rotate_buffers"]
 
 
 def hip_lib():
@@ -54,6 +54,8 @@ def hip_lib():
         L.rt_set_overlap.argtypes = [C.c_void_p, C.c_int]
         L.rt_tonemap.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.rt_set_sun_and_sky.argtypes = [C.c_void_p, C.c_void_p]
+        L.rt_history_miss_stage.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.rt_rotate_buffers.argtypes = [C.c_void_p, C.c_int]
         L.rt_pick.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
         L.rt_set_history_rows.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.rt_history_miss.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
@@ -122,6 +124,7 @@ class Renderer:
 
     def set_camera(self, cam):
         self._chk(hip_lib().rt_set_camera(self._h, C.byref(cam)), "rt_set_camera")
+        self.camera = type(cam).from_buffer_copy(cam)   # the camera the next launches will use (hosts that defer work re-set it)
 
     def set_stream(self, stream_ptr):
         self._chk(hip_lib().rt_set_stream(self._h, stream_ptr), "rt_set_stream")
@@ -174,6 +177,14 @@ class Renderer:
     def set_overlap(self, mode):
         """0 = serial launches, 1 = direct A-Trous beside the indirect stage, 2 = 1 + frames in flight (default)."""
         self._chk(hip_lib().rt_set_overlap(self._h, int(mode)), "rt_set_overlap")
+
+    def history_miss_stage(self, stage):
+        m = C.c_int()
+        self._chk(hip_lib().rt_history_miss_stage(self._h, stage, C.byref(m)), "rt_history_miss_stage")
+        return bool(m.value)
+
+    def rotate_buffers(self, frames):
+        self._chk(hip_lib().rt_rotate_buffers(self._h, frames), "rt_rotate_buffers")
 
     def set_history_rows(self, row0, row1):
         self._chk(hip_lib().rt_set_history_rows(self._h, row0, row1), "rt_set_history_rows")

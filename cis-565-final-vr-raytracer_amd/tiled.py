@@ -71,6 +71,7 @@ class TorchComm:
         self.world = dist.get_world_size(group)
         self.nccl = dist.get_backend(group) == "nccl"
         self._flag = torch.zeros(1, dtype=torch.int32, device="cuda" if self.nccl else "cpu")
+        self._done = {}
 
     def all_gather_rows(self, tensor, chunk_bytes, async_op=False):
         out = tensor[: self.world * chunk_bytes]
@@ -134,11 +135,20 @@ class TorchComm:
         return bool(int(self._flag.item()))
 
     def wait(self, work):
+        """NCCL: makes the CURRENT stream wait for the operation (may be called once per consuming stream).  gloo: blocks the
+        host; a second wait on a finished point-to-point work can hang there, so finished works are remembered."""
         if work is None:
             return
         for w in (work if isinstance(work, (list, tuple)) else [work]):
-            if w is not None:
+            if w is None:
+                continue
+            if self.nccl:
                 w.wait()
+            elif id(w) not in self._done:
+                w.wait()
+                self._done[id(w)] = w          # keeps the object alive so that the id stays unique
+                if len(self._done) > 4096:
+                    self._done.clear()
 
     def barrier(self):
         self.dist.barrier(group=self.group)
@@ -241,18 +251,252 @@ class TiledFrame:
         self._pending, self._result_pending = [], []
 
 
+class _NullCtx:
+    def __enter__(self): return self
+    def __exit__(self, *a): return False
+
+
+class PipelinedTiledFrame(TiledFrame):
+    """TiledFrame with frames in flight on three streams per rank, the row-band version of rt_render_frame's overlap mode 2:
+
+        main : direct(f)   | exchange X_D(f): G-buffer (144 rows), direct reservoirs + light ids (32), noisy direct colour (40)
+        ind  : indirect(f) | exchange X_I(f): indirect reservoirs (16 half rows), noisy indirect colour (72 half rows)
+        side : direct A-Trous x4 (f) ... indirect A-Trous x5 (f), compose(f), result bands -> rank 0
+
+    direct(f+1) needs only X_D(f) — the neighbours' G-buffer / direct-reservoir history rows — so it starts while indirect(f) and
+    the filters of frame f are still running.  A small band is latency bound (one multi-bounce tile is the critical path of the
+    indirect stage however few rows the band has), so overlapping the stages is what makes more ranks pay off.  The second half
+    of frame f (X_I, indirect A-Trous, compose, gather) is issued at the start of render_frame(f+1) after the host has seen the
+    indirect stage's history-miss flag; finish() issues it for the last frame.
+
+    Exactness: the G-buffer is triple buffered and the motion vectors double buffered (backend.rotate) because indirect(f)
+    reads G(f) and G(f-1) while direct(f+1) writes; the history-miss flags are per stage kind (history_miss_stage); a miss
+    drains everything and re-runs that stage with the all-gathered history, exactly like TiledFrame."""
+
+    def __init__(self, backend, comm, width, height):
+        super().__init__(backend, comm, width, height)
+        self._wD = []            # X_D of the latest direct stage
+        self._wD_prev = []       # ... and of the one before (history rows the indirect stage reads)
+        self._rotated = None
+        self._validated = True
+        self._wI = []            # X_I of the latest finished frame
+        self._wR = {}            # result gathers in flight, by frame parity
+        self._prev = None        # (state copy, frames) whose second half is still to be issued
+        self._ev = {}            # events: ("D"|"I"|"done", frames) -> event
+        self._f0 = None
+
+    # -- backend shims: the CPU test backends have no streams / events / rotation ------------------------------------------------
+    def _stream(self, name):
+        fn = getattr(self.b, "stream", None)
+        return fn(name) if fn else _NullCtx()
+
+    def _record(self, key):
+        fn = getattr(self.b, "record", None)
+        self._ev[key] = fn() if fn else None
+        for k in [k for k in self._ev if k[1] < key[1] - 4]:
+            del self._ev[k]
+
+    def _wait_ev(self, key):
+        ev = self._ev.get(key)
+        if ev is not None:
+            self.b.wait_event(ev)
+
+    def _miss(self, stage):
+        fn = getattr(self.b, "history_miss_stage", None)
+        return fn(stage) if fn else self.b.history_miss()
+
+    def _camera(self):
+        r = getattr(self.b, "r", None) or getattr(self.b, "o", None)   # RendererTensors.r / the CPU test backend's oracle
+        return getattr(r, "camera", None)
+
+    def _set_camera(self, cam):
+        r = getattr(self.b, "r", None) or getattr(self.b, "o", None)
+        if cam is not None and r is not None:
+            r.set_camera(cam)
+
+    def _copy_state(self, state):
+        return type(state).from_buffer_copy(state)
+
+    def _drain(self):
+        fn = getattr(self.b, "sync_all", None)
+        if fn:
+            fn()
+
+    # -- frame -----------------------------------------------------------------------------------------------------------------
+    def render_frame(self, state, frames):
+        c, b = self.comm, self.b
+        if c.world == 1:
+            return super().render_frame(state, frames)
+        if state.ReSTIRState in (abi.RESTIR_SPATIAL, abi.RESTIR_SPATIOTEMPORAL):
+            raise NotImplementedError("ReSTIRState eSpatial / eSpatiotemporal is single-GPU only in this build")
+        f, cur, last = frames, frames & 1, (frames + 1) & 1
+        self._rotate(f)
+        # ---- 1. direct(f) on the main stream ---------------------------------------------------------------------------------
+        with self._stream("main"):
+            self._wait_ev(("done", f - 2)); self._wait_ev(("I", f - 2))     # storage of dcol(f) / G(f) is free again
+            c.wait(self._wR.pop(cur, None))                                   # ... and the result band of f-2 has left
+            c.wait(self._wD)                                                  # neighbours' history rows of f-1
+            b.set_history_rows(max(0, self.y0 - HIST_HALO), min(self.H, self.y1 + HIST_HALO))
+            self._run(state, f, abi.STAGE_DIRECT, 0, self.y0, self.y1, self.H)
+            if c.any_flag(self._miss(abi.STAGE_DIRECT)):
+                self.history_fallbacks += 1
+                self._drain()
+                for buf in (abi.BUF_GBUFFER0 + last, abi.BUF_DIRECT_RESV0 + last, abi.BUF_LIGHT_ID0 + last):
+                    t, p = self._t(buf)
+                    c.all_gather_rows(t, self.B * p)
+                b.set_history_rows(0, self.H)
+                self._run(state, f, abi.STAGE_DIRECT, 0, self.y0, self.y1, self.H)
+                self._miss(abi.STAGE_DIRECT)  # clear
+            items = []
+            g, gp = self._t(abi.BUF_GBUFFER0 + cur)
+            items.append((g, gp, self.y0, self.y1, HALO_GBUFFER if state.denoise > 0 else HIST_HALO, self.H, self.B))
+            for buf in (abi.BUF_DIRECT_RESV0 + cur, abi.BUF_LIGHT_ID0 + cur):
+                t, p = self._t(buf)
+                items.append((t, p, self.y0, self.y1, HIST_HALO, self.H, self.B))
+            if state.denoise > 0:
+                dcol, _ = self._t(abi.BUF_DIRECT_RESULT0 + cur)
+                items.append((dcol, self.W * _COLOR_BYTES, self.y0, self.y1, HALO_DIRECT_COLOR, self.H, self.B))
+            self._wD_prev = self._wD
+            self._wD = c.halo_exchange(items, async_op=True)
+            self._record(("D", f))
+        # ---- 2. second half of frame f-1 (its indirect stage ran beside direct(f)) ---------------------------------------------
+        self._finish_prev()
+        # ---- 3. indirect(f) on the ind stream -----------------------------------------------------------------------------------
+        with self._stream("ind"):
+            self._wait_ev(("D", f)); self._wait_ev(("done", f - 1))            # this G-buffer band; the noisy-indirect scratch is free
+            c.wait(self._wD_prev); c.wait(self._wI)                           # G(f-1) / indirect-reservoir history rows
+            b.set_history_rows(max(0, self.y0 - HIST_HALO), min(self.H, self.y1 + HIST_HALO))
+            self._run(state, f, abi.STAGE_INDIRECT, 0, self.h0, self.h1, self.Hh)
+            self._validated = False
+            if getattr(b, "rotate", None) is None:
+                # a backend without buffer rotation (the sequential CPU test backends) cannot re-run indirect(f) once
+                # direct(f+1) has overwritten the G-buffer it reprojects into: validate right away
+                self._validate_indirect(state, f)
+            self._record(("I", f))
+        # ---- 4. direct A-Trous(f) on the side stream ------------------------------------------------------------------------------
+        with self._stream("side"):
+            self._wait_ev(("D", f))
+            c.wait(self._wD)
+            if state.denoise > 0:
+                for l in range(4):
+                    self._run(state, f, abi.STAGE_DENOISE_DIRECT, l, self.y0 - DIRECT_GROW[l], self.y1 + DIRECT_GROW[l], self.H)
+        self._prev = (self._copy_state(state), f, self._camera())
+
+    def _finish_prev(self):
+        if self._prev is None:
+            return
+        c, b = self.comm, self.b
+        state, f, cam = self._prev
+        self._prev = None
+        cur, last = f & 1, (f + 1) & 1
+        now = self._camera()
+        self._set_camera(cam)           # the deferred launches belong to frame f: its camera, not the one set for f+1
+        with self._stream("ind"):
+            if not self._validated:
+                self._validate_indirect(state, f)
+            items = []
+            t, p = self._t(abi.BUF_INDIRECT_RESV0 + cur)
+            items.append((t, p, self.h0, self.h1, HIST_HALO // 2, self.Hh, self.Bh))
+            if state.denoise > 0:
+                icol, _ = self._t(abi.BUF_DENOISE_IND_A)
+                items.append((icol, self.W * _COLOR_BYTES, self.h0, self.h1, HALO_INDIRECT_COLOR, self.Hh, self.Bh))
+            self._wI = c.halo_exchange(items, async_op=True)
+            self._record(("Ix", f))
+        with self._stream("side"):
+            self._wait_ev(("Ix", f)); self._wait_ev(("I", f))
+            c.wait(self._wI)
+            if state.denoise > 0:
+                for l in range(5):
+                    self._run(state, f, abi.STAGE_DENOISE_INDIRECT, l, self.h0 - INDIRECT_GROW[l], self.h1 + INDIRECT_GROW[l], self.Hh)
+            self._run(state, f, abi.STAGE_COMPOSE, 0, self.y0, self.y1, self.H)
+            self._record(("done", f))
+            works = []
+            for buf in (abi.BUF_DIRECT_RESULT0 + cur, abi.BUF_INDIRECT_RESULT0 + cur):
+                t, p = self._t(buf)
+                w = c.gather_rows_to(t, self.B * p, dst=0, async_op=True)
+                if w:
+                    works += list(w)
+            self._wR[cur] = works
+        self._set_camera(now)
+
+    def _validate_indirect(self, state, f):
+        """History-miss check of indirect(f) (waits for it), with the exact fallback: all-gather G(f-1) and the indirect
+        reservoirs of f-1, re-run the stage.  Must be called with the ind stream current."""
+        c, b = self.comm, self.b
+        last = (f + 1) & 1
+        self._validated = True
+        if not c.any_flag(self._miss(abi.STAGE_INDIRECT)):
+            return
+        self.history_fallbacks += 1
+        self._drain()
+        newer = self._rotated
+        if newer is not None and newer > f:
+            self._rotate(newer)            # undo: the boundary ids point at frame f's G-buffers / motion vectors again
+        for buf, chunk in ((abi.BUF_GBUFFER0 + last, self.B), (abi.BUF_INDIRECT_RESV0 + last, self.Bh)):
+            t, p = self._t(buf)
+            c.all_gather_rows(t, chunk * p)
+        b.set_history_rows(0, self.H)
+        self._run(state, f, abi.STAGE_INDIRECT, 0, self.h0, self.h1, self.Hh)
+        self._miss(abi.STAGE_INDIRECT)     # clear
+        self._drain()
+        if newer is not None and newer > f:
+            self._rotate(newer)            # redo
+
+    def _rotate(self, frames):  # remembers which frame the boundary ids of the rotated buffers currently belong to
+        fn = getattr(self.b, "rotate", None)
+        if fn:
+            fn(frames)
+        self._rotated = frames
+
+    def finish(self):
+        self._finish_prev()
+        with self._stream("main"):
+            self.comm.wait(self._wD); self.comm.wait(self._wI)
+            for w in self._wR.values():
+                self.comm.wait(w)
+        self._wR = {}
+        self._drain()
+
+
 class RendererTensors:
     """Backend adapter: HIP Renderer + torch views of its HBM buffers (zero copy through __cuda_array_interface__)."""
     def __init__(self, renderer):
         import torch
         self.r, self.torch = renderer, torch
         self._cache = {}
+        self._streams = None
     def run_stage(self, state, frames, stage, level, r0, r1):
         self.r.run_stage(state, frames, stage, level, r0, r1)
     def set_history_rows(self, r0, r1):
         self.r.set_history_rows(r0, r1)
     def history_miss(self):
         return self.r.history_miss()
+    # ---- frames in flight (PipelinedTiledFrame) ----
+    def history_miss_stage(self, stage):
+        return self.r.history_miss_stage(stage)
+    def rotate(self, frames):
+        self.r.rotate_buffers(frames)
+        for buf in (abi.BUF_GBUFFER0, abi.BUF_GBUFFER1, abi.BUF_MOTION):
+            self._cache.pop(buf, None)
+    def stream(self, name):
+        """Context: kernels (rt_set_stream) and collectives (torch current stream) issued inside go to the named stream."""
+        if self._streams is None:
+            self._streams = {n: self.torch.cuda.Stream() for n in ("main", "ind", "side")}
+        backend, s = self, self._streams[name]
+        class _Ctx:
+            def __enter__(self_):
+                self_.prev = backend.torch.cuda.current_stream()
+                backend.torch.cuda.set_stream(s); backend.r.set_stream(s.cuda_stream)
+            def __exit__(self_, *a):
+                backend.torch.cuda.set_stream(self_.prev); backend.r.set_stream(self_.prev.cuda_stream)
+                return False
+        return _Ctx()
+    def record(self):
+        ev = self.torch.cuda.Event(); ev.record(self.torch.cuda.current_stream()); return ev
+    def wait_event(self, ev):
+        self.torch.cuda.current_stream().wait_event(ev)
+    def sync_all(self):
+        self.torch.cuda.synchronize()
     def tensor(self, buf):
         if buf not in self._cache:
             arr, pitch = self.r.device_array(buf)

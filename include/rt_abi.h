@@ -352,6 +352,16 @@ int rt_get_counters(rt_ctx* ctx, rt_counters* out);
  * gather the full history and redo the frame.  Default: every row is valid. */
 int rt_set_history_rows(rt_ctx* ctx, int row0, int row1);
 int rt_history_miss(rt_ctx* ctx, int* missed);
+/* The same flag per stage kind, for hosts that keep the direct stage of frame f+1 in flight beside the indirect stage of
+ * frame f on different streams: RT_STAGE_DIRECT* launches raise flag 0, RT_STAGE_INDIRECT launches raise flag 1;
+ * this call waits for the ctx stream only, then reads and clears the flag of `stage`.  (rt_history_miss = both flags.) */
+int rt_history_miss_stage(rt_ctx* ctx, int stage, int* missed);
+/* Stage-wise submission with frames in flight (what rt_render_frame does internally in overlap mode 2): before submitting the
+ * stages of frame `frames`, swap RT_BUF_GBUFFER0 + (frames & 1) and RT_BUF_MOTION with their spare buffers so that this
+ * frame's direct stage does not overwrite the G-buffer / motion vectors that the previous frame's indirect stage, possibly
+ * still running on another stream, reads.  Calling it a second time with the same `frames` undoes the swap.
+ * Invalidates rt_device_ptr results for those three buffers. */
+int rt_rotate_buffers(rt_ctx* ctx, int frames);
 /* Kernel organisation of the direct / indirect stages: 0 = one fused kernel per reference stage (default, the fastest
  * measured), 1 = wavefront (lean trace kernels + shading kernels with ray compaction).  Outputs are bit-identical; this is
  * an A/B performance switch (also settable with the environment variable RESTIR_PIPELINE=fused|wavefront before rt_create). */

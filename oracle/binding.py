@@ -51,6 +51,7 @@ def lib():
         L.orc_pick.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
         L.orc_sun_and_sky_eval.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_history_miss.argtypes = [C.c_void_p]
+        L.orc_history_miss_stage.argtypes = [C.c_void_p, C.c_int]
         L.orc_buffer_ptr.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         for n in ["orc_trace_closest", "orc_trace_any", "orc_trace_closest_brute"]:
             getattr(L, n).argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -76,7 +77,9 @@ class Oracle:
         if rc != 0: raise RuntimeError(f"oracle {what} failed: {rc}")
     def upload_scene(self, desc): self._chk(lib().orc_upload_scene(self._h, C.byref(desc)), "upload_scene")
     def resize(self, w, h): self._chk(lib().orc_resize(self._h, w, h), "resize")
-    def set_camera(self, cam): self._chk(lib().orc_set_camera(self._h, C.byref(cam)), "set_camera")
+    def set_camera(self, cam):
+        self._chk(lib().orc_set_camera(self._h, C.byref(cam)), "set_camera")
+        self.camera = type(cam).from_buffer_copy(cam)
     def render_frame(self, state, frames): self._chk(lib().orc_render_frame(self._h, C.byref(state), frames), "render_frame")
     def run_stage(self, state, frames, stage, level=0, row_begin=0, row_end=0):
         self._chk(lib().orc_run_stage(self._h, C.byref(state), frames, stage, level, row_begin, row_end), "run_stage")
@@ -98,6 +101,7 @@ class Oracle:
         self._chk(lib().orc_upload_history(self._h, buf, a.ctypes.data, a.nbytes), "upload_history")
     def set_history_rows(self, r0, r1): lib().orc_set_history_rows(self._h, r0, r1)
     def history_miss(self): return bool(lib().orc_history_miss(self._h))
+    def history_miss_stage(self, stage): return bool(lib().orc_history_miss_stage(self._h, stage))
     def buffer_array(self, buf):
         """(flat uint8 numpy view of the whole allocation incl. slack rows, row pitch in bytes) — zero copy"""
         p, n, pitch = C.c_void_p(), C.c_size_t(), C.c_size_t()

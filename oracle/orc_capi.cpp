@@ -170,7 +170,8 @@ int orc_tonemap(void* p, const rt_tonemapper* tm, int dbg, int frames)
   return RT_OK;
 }
 int orc_set_history_rows(void* p, int r0, int r1) { Ctx* c = static_cast<Ctx*>(p); c->frame.histRow0 = r0; c->frame.histRow1 = r1; return RT_OK; }
-int orc_history_miss(void* p) { Ctx* c = static_cast<Ctx*>(p); return int(c->frame.histMiss.exchange(0u)); }
+int orc_history_miss(void* p) { Ctx* c = static_cast<Ctx*>(p); return int(c->frame.histMiss.exchange(0u) | c->frame.histMissInd.exchange(0u)); }
+int orc_history_miss_stage(void* p, int stage) { Ctx* c = static_cast<Ctx*>(p); return int(stage == RT_STAGE_INDIRECT ? c->frame.histMissInd.exchange(0u) : c->frame.histMiss.exchange(0u)); }
 void orc_reset_counters(void* p) { static_cast<Ctx*>(p)->scene.counters.reset(); }
 uint64_t orc_num_triangles(void* p) { return static_cast<Ctx*>(p)->scene.tris.size(); }
 

@@ -554,7 +554,7 @@ vec3 Frame::ReSTIRIndirect(Shader& sh, float dist, float primSamplePdf, vec3 pri
     float reprojDepth = length(toV(sh.cam.lastPosition) - primState.position);
     ivec2 motionIdx = loadMotion(ivec2{sh.imageCoords.x * 2, sh.imageCoords.y * 2});
     vec3 pnorm; float pdepth; uint32_t matHash;
-    if(motionIdx.x >= 0 && motionIdx.x < W && motionIdx.y >= 0 && motionIdx.y < H && (motionIdx.y < histRow0 || motionIdx.y >= histRow1)) histMiss = 1u;
+    if(motionIdx.x >= 0 && motionIdx.x < W && motionIdx.y >= 0 && motionIdx.y < H && (motionIdx.y < histRow0 || motionIdx.y >= histRow1)) histMissInd = 1u;
     loadLastGeometryInfo(last, motionIdx, pnorm, pdepth, matHash);
     ivec2 coord{motionIdx.x / 2, motionIdx.y / 2};
     if(inBound(coord, indSize)) {

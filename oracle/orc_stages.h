@@ -17,7 +17,7 @@ struct Frame {
   int threads = 1;
   // row-tiled runs: rows of the last-frame buffers valid on this rank; lookups outside raise histMiss (rt_abi.h rt_set_history_rows)
   int histRow0 = 0, histRow1 = 1 << 30;
-  mutable std::atomic<uint32_t> histMiss{0};
+  mutable std::atomic<uint32_t> histMiss{0}, histMissInd{0};  // raised by the direct stages / by the indirect stage (rt_history_miss_stage)
 
   // boundary layouts == reference layouts (rt_abi.h rt_buffer_id)
   std::vector<uint32_t> gbuffer[2];                 // RGBA32UI

@@ -122,11 +122,15 @@ class ThreadComm:
     def barrier(self): self.s["barrier"].wait()
 
 
-def test_tiled_three_ranks_equals_untiled(bistro):
+@pytest.mark.parametrize("mode", ["serial", "serial-fallbacks", "frames-in-flight", "frames-in-flight-fallbacks"])
+def test_tiled_three_ranks_equals_untiled(bistro, mode, monkeypatch):
     import torch
     from restir_amd import tiled
     sc, env, st, cam = bistro
-    world, frames = 3, 2
+    world, frames = 3, (2 if mode == "serial" else 4)
+    Frame = tiled.TiledFrame if mode.startswith("serial") else tiled.PipelinedTiledFrame
+    if mode.endswith("fallbacks"):
+        monkeypatch.setattr(tiled, "HIST_HALO", 0)   # every cross-band reprojection misses: both exact fallbacks (incl. the un-rotate / re-rotate of the G-buffers) run
     ref = _renderer(sc, env)
     rs = [_renderer(sc, env) for _ in range(world)]
     shared = {"renderers": rs, "barrier": threading.Barrier(world), "slot": [None] * world, "flags": [False] * world}
@@ -137,27 +141,32 @@ def test_tiled_three_ranks_equals_untiled(bistro):
     for f in range(frames):
         s2.setCamera(eye + np.array([0.3 * f, 0.05 * f, 0], dtype=np.float32), center, up, fov); s2.updateCamera(W, H); cams.append(s2.getCamera())
     errors = []
+    fallbacks = [0] * world
 
     def rank_main(rank):
         try:
             torch.cuda.set_device(0)
-            fr = tiled.TiledFrame(tiled.RendererTensors(rs[rank]), ThreadComm(rank, world, shared), W, H)
+            fr = Frame(tiled.RendererTensors(rs[rank]), ThreadComm(rank, world, shared), W, H)
             import copy
             st_r = copy.copy(st)
             for f in range(frames):
                 st_r.time = 500 + f; rs[rank].set_camera(cams[f]); fr.render_frame(st_r, f)
             fr.finish(); rs[rank].sync()
+            fallbacks[rank] = fr.history_fallbacks
         except Exception as e:  # pragma: no cover
             errors.append(e); shared["barrier"].abort()
 
     th = [threading.Thread(target=rank_main, args=(i,)) for i in range(world)]
     [t.start() for t in th]; [t.join() for t in th]
     assert not errors, errors
+    assert (fallbacks[0] > 0) == mode.endswith("fallbacks")
     for f in range(frames):
         st.time = 500 + f; ref.set_camera(cams[f]); ref.run(st, f)
     cur = (frames - 1) & 1
-    for b in [abi.BUF_DIRECT_RESULT0 + cur, abi.BUF_INDIRECT_RESULT0 + cur]:   # gathered on rank 0
-        assert np.array_equal(rs[0].readback(b), ref.readback(b)), abi.BUFFER_NAMES[b]
+    for b in [abi.BUF_DIRECT_RESULT0 + cur, abi.BUF_INDIRECT_RESULT0 + cur, abi.BUF_DIRECT_RESULT0 + (cur ^ 1), abi.BUF_INDIRECT_RESULT0 + (cur ^ 1)]:   # gathered on rank 0: last frame and the one before
+        got, want = rs[0].readback(b).reshape(H, -1), ref.readback(b).reshape(H, -1)
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert bad.size == 0, (abi.BUFFER_NAMES[b], "rows", int(bad.min()), int(bad.max()), int(bad.size))
     B = tiled.band_height(H, world)
     for b, elem, half in [(abi.BUF_GBUFFER0 + cur, 16, False), (abi.BUF_DIRECT_RESV0 + cur, 36, False), (abi.BUF_LIGHT_ID0 + cur, 4, False),
                           (abi.BUF_INDIRECT_RESV0 + cur, 76, True)]:

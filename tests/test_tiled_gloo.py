@@ -23,6 +23,7 @@ class OracleTensors:
     def run_stage(self, state, frames, stage, level, r0, r1): self.o.run_stage(state, frames, stage, level, r0, r1)
     def set_history_rows(self, r0, r1): self.o.set_history_rows(r0, r1)
     def history_miss(self): return self.o.history_miss()
+    def history_miss_stage(self, stage): return self.o.history_miss_stage(stage)
     def tensor(self, buf):
         if buf not in self._c:
             arr, pitch = self.o.buffer_array(buf)
@@ -46,7 +47,7 @@ def _setup():
     return sc, env, st, o
 
 
-def _worker(rank, world, port, outdir, fast):
+def _worker(rank, world, port, outdir, fast, pipelined=False):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -54,16 +55,16 @@ def _worker(rank, world, port, outdir, fast):
     if fast:
         tiled.HIST_HALO = 0   # no history halo: the first cross-band reprojection must trigger the exact fallback
     sc, env, st, o = _setup()
-    frame = tiled.TiledFrame(OracleTensors(o), tiled.TorchComm(), W, H)
+    frame = (tiled.PipelinedTiledFrame if pipelined else tiled.TiledFrame)(OracleTensors(o), tiled.TorchComm(), W, H)
     sc.updateCamera(W, H)
     for f in range(FRAMES):
         st.time = 900 + f; _camera(sc, f, fast); sc.updateCamera(W, H); o.set_camera(sc.getCamera())
         frame.render_frame(st, f)
     frame.finish()
     cur = (FRAMES - 1) & 1
-    if rank == 0:
+    if rank == 0:   # both parities: the last frame and the one before it (whose second half was issued one call later)
         np.savez(os.path.join(outdir, f"tiled_{world}.npz"), fallbacks=np.array([frame.history_fallbacks]),
-                 **{abi.BUFFER_NAMES[b]: o.readback(b) for b in _result_buffers(cur)})
+                 **{abi.BUFFER_NAMES[b]: o.readback(b) for b in _result_buffers(cur) + _result_buffers(cur ^ 1)})
     # every rank owns the authoritative copy of its band of the history buffers
     np.savez(os.path.join(outdir, f"band_{world}_{rank}.npz"), rows=np.array([frame.y0, frame.y1, frame.h0, frame.h1]),
              **{abi.BUFFER_NAMES[b]: o.readback(b) for b in _history_buffers(cur)})
@@ -81,10 +82,11 @@ def _history_buffers(cur):
 _ELEM = {"gbuffer": 16, "direct_resv": 36, "light_id": 4, "indirect_resv": 76}
 
 
+@pytest.mark.parametrize("pipelined", [False, True], ids=["serial", "frames-in-flight"])
 @pytest.mark.parametrize("fast", [False, True], ids=["slow-camera", "fast-camera-fallback"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_tiled_equals_untiled(world, fast, tmp_path):
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), fast), nprocs=world, join=True)
+def test_tiled_equals_untiled(world, fast, pipelined, tmp_path):
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), fast, pipelined), nprocs=world, join=True)
     got = np.load(os.path.join(tmp_path, f"tiled_{world}.npz"))
     sc, env, st, o = _setup()
     sc.updateCamera(W, H)
@@ -92,7 +94,7 @@ def test_tiled_equals_untiled(world, fast, tmp_path):
         st.time = 900 + f; _camera(sc, f, fast); sc.updateCamera(W, H); o.set_camera(sc.getCamera()); o.render_frame(st, f)
     cur = (FRAMES - 1) & 1
     # rank 0 ends the frame with both full result images (gathered)
-    for b in _result_buffers(cur):
+    for b in _result_buffers(cur) + _result_buffers(cur ^ 1):
         assert np.array_equal(got[abi.BUFFER_NAMES[b]], o.readback(b)), abi.BUFFER_NAMES[b]
     # the frame's history (G-buffer, reservoirs, light ids) is distributed: each rank's band must match the untiled frame
     for rank in range(world):
