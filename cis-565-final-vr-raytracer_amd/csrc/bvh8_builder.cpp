@@ -43,12 +43,15 @@ struct Builder2 {
       auto makeLeaf = [&] { N.leaf = true; N.a = b; N.n = cnt; };
       if(cnt <= 1) { makeLeaf(); return; }
       // binned SAH over the three axes
-      constexpr int NB = 16;
+      constexpr int NBMAX = 64;
+      static const int envNB = getenv("RESTIR_BVH_BINS") ? std::min(NBMAX, std::max(4, atoi(getenv("RESTIR_BVH_BINS")))) : 16;
+      static const float leafSlotCost = getenv("RESTIR_BVH_SLOTCOST") ? float(atof(getenv("RESTIR_BVH_SLOTCOST"))) : 0.25f;  // measured: 0.25 beats 0.5 by 2 % on the Bistro-class scene, bins 16 vs 32 vs 64 make no difference
+      const int NB = (cnt <= 64 && getenv("RESTIR_BVH_FINE")) ? NBMAX : envNB;
       float best = 3e38f; int bestAxis = -1, bestBin = 0;
       for(int ax = 0; ax < 3; ax++) {
         float ext = cb.hi[ax] - cb.lo[ax];
         if(!(ext > 0)) continue;
-        Box bb[NB]; uint32_t bc[NB];
+        Box bb[NBMAX]; uint32_t bc[NBMAX];
         for(int i = 0; i < NB; i++) { bb[i].reset(); bc[i] = 0; }
         const float k1 = NB * (1.f - 1e-6f) / ext;
         for(uint32_t k = b; k < e; k++) {
@@ -56,7 +59,7 @@ struct Builder2 {
           int bi = std::min(NB - 1, std::max(0, int((p.c[ax] - cb.lo[ax]) * k1)));
           bb[bi].grow(p.b); bc[bi]++;
         }
-        float ra[NB]; uint32_t rc[NB];
+        float ra[NBMAX]; uint32_t rc[NBMAX];
         Box acc; acc.reset(); uint32_t c = 0;
         for(int i = NB - 1; i > 0; i--) { acc.grow(bb[i]); c += bc[i]; ra[i] = acc.area(); rc[i] = c; }
         acc.reset(); c = 0;
@@ -69,8 +72,8 @@ struct Builder2 {
       }
       const float pa = std::max(N.b.area(), 1e-30f);
       if(cnt <= 3) {
-        // leaf of <= 3 triangles unless splitting is clearly cheaper (one wide-node slot costs ~0.5 triangle tests)
-        if(bestAxis < 0 || 0.5f * pa + best >= float(cnt) * pa) { makeLeaf(); return; }
+        // leaf of <= 3 triangles unless splitting is clearly cheaper (one wide-node slot costs a fraction of a triangle test)
+        if(bestAxis < 0 || leafSlotCost * pa + best >= float(cnt) * pa) { makeLeaf(); return; }
       }
       uint32_t mid;
       if(bestAxis >= 0) {
