@@ -16,7 +16,7 @@ HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "
              "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-unused-result", "-x", "hip"]
 HIP_SRC = ["rt_api.cpp", "bvh8_builder.cpp", "stages.hip", "wavefront.hip", "stages_sky.hip", "wavefront_sky.hip", "post.hip"]
 HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-pthread"]
-HOST_SRC = ["scene.cpp", "scene_gen.cpp", "hdr_sampling.cpp", "gltf_loader.cpp", "host_capi.cpp"]
+HOST_SRC = ["scene.cpp", "scene_gen.cpp", "hdr_sampling.cpp", "gltf_loader.cpp", "jpeg_decoder.cpp", "host_capi.cpp"]
 
 
 def _stale(target, sources):

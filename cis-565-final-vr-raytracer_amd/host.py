@@ -24,7 +24,7 @@ def host_lib():
         L.rth_env_average.restype = C.c_float
         for name, args in {
             "rth_scene_destroy": [C.c_void_p], "rth_scene_load": [C.c_void_p, C.c_char_p],
-            "rth_scene_make_procedural": [C.c_void_p, C.c_int, C.c_float, C.c_uint32], "rth_scene_save_gltf": [C.c_void_p, C.c_char_p],
+            "rth_scene_make_procedural": [C.c_void_p, C.c_int, C.c_float, C.c_uint32], "rth_scene_save_gltf": [C.c_void_p, C.c_char_p], "rth_decode_jpeg": [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
             "rth_scene_set_camera": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float],
             "rth_scene_get_camera_pose": [C.c_void_p, C.c_void_p], "rth_scene_update_camera": [C.c_void_p, C.c_int, C.c_int],
             "rth_scene_get_camera": [C.c_void_p, C.c_void_p], "rth_scene_light_weights": [C.c_void_p, C.c_void_p, C.c_void_p],
@@ -123,3 +123,14 @@ def default_state(width, height, scene=None, env=None, time=1000):
         st.fireflyClampThreshold = env.getIntegral() * 4.0
         st.envMapLuminIntegInv = 1.0 / env.getIntegral()
     return st
+
+
+def decode_jpeg(data):
+    """host/jpeg_decoder.cpp on a bytes object -> (H, W, 4) uint8 BGRA array, or None when the stream is not supported."""
+    buf = np.frombuffer(data, dtype=np.uint8)
+    w, h = C.c_int(), C.c_int()
+    out = np.empty(64 << 20, dtype=np.uint8)
+    rc = host_lib().rth_decode_jpeg(buf.ctypes.data, buf.size, C.byref(w), C.byref(h), out.ctypes.data, out.size)
+    if rc != 0:
+        return None
+    return out[: w.value * h.value * 4].reshape(h.value, w.value, 4).copy()

@@ -6,7 +6,7 @@
 // one GltfPrimMesh per (mesh, primitive) and one GltfNode per drawable instance like nvh::GltfScene; triangle primitives
 // with POSITION / NORMAL / TANGENT / TEXCOORD_0 / COLOR_0 and any index type; pbrMetallicRoughness materials with
 // KHR_materials_transmission, KHR_materials_ior, KHR_materials_emissive_strength; KHR_lights_punctual; perspective cameras;
-// samplers; PNG images (8-bit, non-interlaced, via zlib).  JPEG images decode to a white texel with a warning.
+// samplers; PNG images (8-bit, non-interlaced, via zlib) and JPEG images (baseline / progressive, jpeg_decoder.cpp).
 #include "scene.hpp"
 #include <zlib.h>
 #include <cstdio>
@@ -17,6 +17,7 @@
 #include <sstream>
 
 namespace rth {
+bool decodeJpeg(const uint8_t* d, size_t n, TextureImage& img);  // jpeg_decoder.cpp
 namespace {
 
 // ---------------------------------------------------------------------------------------------------------- JSON
@@ -300,8 +301,8 @@ bool loadGltfFile(const std::string& filename, GltfScene& out, std::string& erro
       }
     }
     TextureImage t;
-    if(!have || !decodePng(bytes.data(), bytes.size(), t)) {
-      if(have) fprintf(stderr, "gltf: image %zu is not an 8-bit PNG (JPEG decoding is not built in): using a white texel\n", i);
+    if(!have || !(decodePng(bytes.data(), bytes.size(), t) || decodeJpeg(bytes.data(), bytes.size(), t))) {
+      if(have) fprintf(stderr, "gltf: image %zu is neither an 8-bit PNG nor a Huffman-coded 8-bit JPEG: using a white texel\n", i);
       t.width = t.height = 1; t.bgra = {255, 255, 255, 255};  // addDefaultImage, scene.cpp:566-572
     }
     images[i] = std::move(t);

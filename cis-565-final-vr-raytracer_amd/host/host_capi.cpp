@@ -5,11 +5,22 @@
 
 using namespace rth;
 
+namespace rth { bool decodeJpeg(const uint8_t* d, size_t n, TextureImage& img); }  // jpeg_decoder.cpp
 extern "C" {
 
 void* rth_scene_create() { return new(std::nothrow) Scene(); }
 void rth_scene_destroy(void* s) { delete static_cast<Scene*>(s); }
 int rth_scene_load(void* s, const char* path) { return static_cast<Scene*>(s)->load(path) ? 0 : -1; }
+// image decoders on a memory block (tests): returns 0 and fills w/h + BGRA8 pixels (caller passes a buffer of cap bytes)
+int rth_decode_jpeg(const uint8_t* data, size_t n, int* w, int* h, uint8_t* out, size_t cap)
+{
+  TextureImage t;
+  if(!rth::decodeJpeg(data, n, t)) return -1;
+  *w = t.width; *h = t.height;
+  if(t.bgra.size() > cap) return -2;
+  memcpy(out, t.bgra.data(), t.bgra.size());
+  return 0;
+}
 int rth_scene_save_gltf(void* s, const char* path)
 {
   std::string err;

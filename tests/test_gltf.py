@@ -156,3 +156,66 @@ def test_load_errors(tmp_path):
     sc2 = host.Scene()
     ok = sc2.load(str(tmp_path / "oob.gltf"))
     assert (not ok) or sc2.getStat()["triangles"] <= 5                      # rejected outright or the primitive is dropped; never read out of bounds
+
+
+# ---- JPEG textures (host/jpeg_decoder.cpp) ------------------------------------------------------------------------------
+def _smooth(w, h):
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.stack([128 + 100 * np.sin(x / 17.0) * np.cos(y / 23.0), 128 + 90 * np.cos(x / 29.0 + 1), 128 + 80 * np.sin((x + y) / 31.0)], -1)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+JPEG_VARIANTS = {
+    "baseline-444": dict(quality=95, subsampling=0),
+    "baseline-422": dict(quality=85, subsampling=1),
+    "baseline-420-optimized": dict(quality=90, subsampling=2, optimize=True),
+    "progressive-420": dict(quality=92, subsampling=2, progressive=True),
+    "progressive-444": dict(quality=95, subsampling=0, progressive=True),
+    "restart-markers": dict(quality=90, subsampling=2, restart_marker_blocks=3),
+}
+
+
+@pytest.mark.parametrize("variant", list(JPEG_VARIANTS))
+@pytest.mark.parametrize("size", [(64, 48), (77, 53), (200, 9), (1, 1)])
+def test_jpeg_decoder_matches_libjpeg(variant, size):
+    """Against libjpeg (through PIL) on smooth images: <= 1 code value where no chroma upsampling is involved (inverse DCT
+    rounding), <= 8 where libjpeg's triangle-filter upsampling meets this decoder's pixel replication."""
+    import io
+    Image = pytest.importorskip("PIL.Image")
+    w, h = size
+    src = _smooth(w, h)
+    for mode in ("RGB", "L"):
+        im = Image.fromarray(src if mode == "RGB" else src[..., 0], mode)
+        bio = io.BytesIO()
+        try:
+            im.save(bio, "JPEG", **JPEG_VARIANTS[variant])
+        except TypeError:
+            pytest.skip("this Pillow cannot write restart markers")
+        data = bio.getvalue()
+        got = host.decode_jpeg(data)
+        assert got is not None, (variant, mode)
+        ref = np.asarray(Image.open(io.BytesIO(data)).convert("RGB")).astype(int)
+        assert got.shape == (h, w, 4) and (got[..., 3] == 255).all()
+        d = np.abs(got[..., [2, 1, 0]].astype(int) - ref)
+        exact = mode == "L" or JPEG_VARIANTS[variant]["subsampling"] == 0
+        assert d.max() <= (3 if exact else 8) and d.mean() < (0.1 if exact else 2.0), (variant, mode, int(d.max()), float(d.mean()))
+
+
+def test_jpeg_decoder_rejects_what_it_cannot_decode():
+    assert host.decode_jpeg(b"\xff\xd8\xff\xe0 not really a jpeg") is None
+    assert host.decode_jpeg(b"") is None
+    assert host.decode_jpeg(b"\x89PNG\r\n\x1a\n") is None
+
+
+def test_gltf_with_jpeg_texture(tmp_path):
+    import io
+    Image = pytest.importorskip("PIL.Image")
+    g = json.load(open(os.path.join(GOLD, "mini_scene.gltf")))
+    bio = io.BytesIO(); Image.fromarray(_smooth(32, 16), "RGB").save(bio, "JPEG", quality=95, subsampling=0)
+    g["images"][3] = {"uri": "data:image/jpeg;base64," + base64.b64encode(bio.getvalue()).decode()}
+    (tmp_path / "jpeg.gltf").write_text(json.dumps(g))
+    d = dump(_load(tmp_path / "jpeg.gltf"))
+    T = d["textures"][3]
+    assert (T["width"], T["height"]) == (32, 16)
+    ref = np.asarray(Image.open(io.BytesIO(bio.getvalue())).convert("RGB")).astype(int).reshape(-1, 3)
+    assert np.abs(d["texels"][3][:, [2, 1, 0]].astype(int) - ref).max() <= 3
