@@ -135,7 +135,7 @@ bool loadUri(const std::string& uri, const std::string& dir, std::vector<uint8_t
   return readFile(dir + path, out);
 }
 
-// PNG: 8-bit gray / gray+alpha / RGB / RGBA / palette, non-interlaced.  Output BGRA8 (scene.cpp:559: VK_FORMAT_B8G8R8A8_UNORM,
+// PNG: 8- or 16-bit gray / gray+alpha / RGB / RGBA, 8-bit palette, non-interlaced.  Output BGRA8 (scene.cpp:559: VK_FORMAT_B8G8R8A8_UNORM,
 // FreeImage's native channel order).
 bool decodePng(const uint8_t* d, size_t n, TextureImage& img)
 {
@@ -156,9 +156,11 @@ bool decodePng(const uint8_t* d, size_t n, TextureImage& img)
     else if(!memcmp(tag, "IEND", 4)) break;
     pos += 12 + len;
   }
-  if(!w || !h || depth != 8 || interlace != 0) return false;
-  const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
-  if(!ch) return false;
+  if(!w || !h || (depth != 8 && depth != 16) || interlace != 0 || (depth == 16 && ctype == 3)) return false;
+  const int chn = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+  if(!chn) return false;
+  const int bps = depth / 8;               // bytes per sample; 16-bit samples keep their high byte
+  const int ch = chn * bps;                // bytes per pixel = the filter distance
   const size_t stride = size_t(w) * ch;
   std::vector<uint8_t> raw((stride + 1) * h);
   uLongf rawLen = uLongf(raw.size());
@@ -178,16 +180,23 @@ bool decodePng(const uint8_t* d, size_t n, TextureImage& img)
       cur[x] = uint8_t(v);
     }
   }
+  if(bps == 2) {  // big-endian 16-bit samples -> their high bytes
+    for(size_t i = 0; i < size_t(w) * h * chn; i++) px[i] = px[2 * i];
+  }
+  {
+    const int ch = chn;  // from here on: one byte per sample
+    (void)ch;
   img.width = int(w); img.height = int(h); img.bgra.resize(size_t(w) * h * 4);
   for(size_t i = 0; i < size_t(w) * h; i++) {
     uint8_t r, g, b, a = 255;
-    const uint8_t* s = &px[i * ch];
+    const uint8_t* s = &px[i * chn];
     if(ctype == 0) { r = g = b = s[0]; }
     else if(ctype == 4) { r = g = b = s[0]; a = s[1]; }
     else if(ctype == 3) { size_t k = s[0]; if(k * 3 + 2 >= plte.size()) { r = g = b = 0; } else { r = plte[k * 3]; g = plte[k * 3 + 1]; b = plte[k * 3 + 2]; } if(k < trns.size()) a = trns[k]; }
-    else { r = s[0]; g = s[1]; b = s[2]; if(ch == 4) a = s[3]; }
+    else { r = s[0]; g = s[1]; b = s[2]; if(chn == 4) a = s[3]; }
     uint8_t* o = &img.bgra[i * 4];
     o[0] = b; o[1] = g; o[2] = r; o[3] = a;
+  }
   }
   return true;
 }

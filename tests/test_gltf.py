@@ -219,3 +219,20 @@ def test_gltf_with_jpeg_texture(tmp_path):
     assert (T["width"], T["height"]) == (32, 16)
     ref = np.asarray(Image.open(io.BytesIO(bio.getvalue())).convert("RGB")).astype(int).reshape(-1, 3)
     assert np.abs(d["texels"][3][:, [2, 1, 0]].astype(int) - ref).max() <= 3
+
+
+def test_gltf_with_16bit_png_texture(tmp_path):
+    """16-bit PNG samples keep their high byte."""
+    import struct, zlib
+    w, h = 5, 3
+    rng = np.random.default_rng(2)
+    v = rng.integers(0, 65536, (h, w, 3), dtype=np.uint16)
+    raw = b"".join(b"\x00" + v[y].astype(">u2").tobytes() for y in range(h))
+    def chunk(tag, body): return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xffffffff)
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 16, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b"")
+    g = json.load(open(os.path.join(GOLD, "mini_scene.gltf")))
+    g["images"][3] = {"uri": "data:image/png;base64," + base64.b64encode(png).decode()}
+    (tmp_path / "p16.gltf").write_text(json.dumps(g))
+    d = dump(_load(tmp_path / "p16.gltf"))
+    assert (d["textures"][3]["width"], d["textures"][3]["height"]) == (w, h)
+    assert np.array_equal(d["texels"][3][:, [2, 1, 0]], (v >> 8).astype(np.uint8).reshape(-1, 3)) and (d["texels"][3][:, 3] == 255).all()
