@@ -25,8 +25,11 @@
 
 #if defined(__HIPCC__)
 #define RT_HD __host__ __device__ inline
-#else
+#elif defined(__cplusplus)
 #define RT_HD inline
+#else
+#include <stdbool.h>
+#define RT_HD static inline
 #endif
 
 RT_HD uint32_t rt_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }

@@ -42,3 +42,15 @@ def test_error_convention_without_gpu():
         h = C.c_void_p()
         assert lib.rt_create(C.byref(h), 0) == -2            # RT_ERR_NO_DEVICE: the product has no CPU path
         assert not h.value and b"no CPU path" in lib.rt_last_error(None)
+
+
+def test_header_is_valid_c_and_cpp(tmp_path):
+    """include/rt_abi.h and include/rt_detmath.h are the boundary: they must compile as plain C11 and as C++17 on their own."""
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    (tmp_path / "t.c").write_text('#include "rt_abi.h"\n#include "rt_detmath.h"\nint main(void) { rt_state s; (void)s; return (int)(rt_exp(0.0f) != 1.0f) + (int)(sizeof(rt_tonemapper) != 48); }\n')
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", inc, str(tmp_path / "t.c"), "-o", str(tmp_path / "tc"), "-lm"])
+    assert subprocess.call([str(tmp_path / "tc")]) == 0
+    (tmp_path / "t.cpp").write_text('#include "rt_abi.h"\n#include "rt_detmath.h"\nint main() { rt_scene_desc d{}; (void)d; return rt_sin(0.0f) != 0.0f; }\n')
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", inc, str(tmp_path / "t.cpp"), "-o", str(tmp_path / "tcpp")])
+    assert subprocess.call([str(tmp_path / "tcpp")]) == 0
