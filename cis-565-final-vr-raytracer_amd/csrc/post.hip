@@ -109,6 +109,7 @@ __global__ __launch_bounds__(256) void k_tonemap(const float4* direct, const flo
   ldr[size_t(y) * W + x] = toUnorm8(color.x) | (toUnorm8(color.y) << 8) | (toUnorm8(color.z) << 16) | 0xff000000u;
 }
 
+static_assert(sizeof(SkyPre) <= 512, "rt_set_sun_and_sky allocates 512 B for the precomputed sky terms");
 __global__ void k_sky_prepare(rt_sun_and_sky ss, SkyPre* out) { if(threadIdx.x == 0 && blockIdx.x == 0) { SkyPre P; skyfn::prepare(ss, P); *out = P; } }
 
 hipError_t launchSkyPrepare(hipStream_t stream, const rt_sun_and_sky& ss, SkyPre* out)

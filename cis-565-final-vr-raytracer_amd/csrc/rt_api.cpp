@@ -28,6 +28,7 @@ struct rt_ctx {
   uint64_t seq = 0;          // frames submitted through the pipelined path since the last join
   bool inFlight = false;     // work may be pending on indStream / sideStream
   void* dSky = nullptr;      // SkyPre (csrc/sky.h), valid while sunAndSky.in_use == 1
+  void* dPick = nullptr;     // rt_pick_result written by k_pick
   rt_sun_and_sky sunAndSky{};
   void* spareG = nullptr; void* spareMotion = nullptr;   // third G-buffer / second motion buffer (rotated per pipelined frame)
   int overlap = 2;           // 0 = one stream; 1 = direct A-Trous beside the indirect stage; 2 = 1 + consecutive frames overlap
@@ -260,6 +261,7 @@ int rt_destroy(rt_ctx* c)
   for(int i = 0; i < 4; i++) { if(c->evD[i]) (void)hipEventDestroy(c->evD[i]); if(c->evI[i]) (void)hipEventDestroy(c->evI[i]); if(c->evDone[i]) (void)hipEventDestroy(c->evDone[i]); }
   if(c->dCounters) (void)hipFree(c->dCounters);
   if(c->dSky) (void)hipFree(c->dSky);
+  if(c->dPick) (void)hipFree(c->dPick);
   for(auto& E : c->evSets) for(int i = 0; i < rt_ctx::MAX_EV; i++) (void)hipEventDestroy(E.ev[i]);
   if(c->ownStream) (void)hipStreamDestroy(c->ownStream);
   if(c->sideStream) (void)hipStreamDestroy(c->sideStream);
@@ -751,8 +753,8 @@ int rt_pick(rt_ctx* c, const rt_mat4* modelViewInv, const rt_mat4* perspectiveIn
   if(!c->haveScene) return fail(c, RT_ERR_NO_SCENE, "no scene uploaded");
   if(!c->haveAccel) return fail(c, RT_ERR_NO_ACCEL, "rt_build_accel has not been called");
   RT_HIP(c, hipSetDevice(c->device));
-  if(!c->dSky) RT_HIP(c, hipMalloc(&c->dSky, 512));  // 512 B block: SkyPre in the first 256, the pick result behind it
-  rt_pick_result* d = reinterpret_cast<rt_pick_result*>(static_cast<char*>(c->dSky) + 256);
+  if(!c->dPick) RT_HIP(c, hipMalloc(&c->dPick, sizeof(rt_pick_result)));
+  rt_pick_result* d = static_cast<rt_pick_result*>(c->dPick);
   RT_HIP(c, launchPick(c->stream, c->ds, *modelViewInv, *perspectiveInv, pickX, pickY, d));
   RT_HIP(c, hipMemcpyAsync(out, d, sizeof(*out), hipMemcpyDeviceToHost, c->stream));
   RT_HIP(c, hipStreamSynchronize(c->stream));
