@@ -30,7 +30,7 @@ namespace RT_VARIANT {
 // ------------------------------------------------------------------------------------------------------------
 // direct_stage.comp
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_direct_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY)
+__global__ __launch_bounds__(64, 5) void k_direct_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY)
 {
   extern __shared__ uint2 s_stack[];
   const TileCoord tile = tileOf(tilesX, tilesY);
@@ -276,8 +276,173 @@ __global__ __launch_bounds__(256) void k_ind_tile_order(rt_state st, int rowBegi
   if(threadIdx.x < 2) counts[xcd * 2 + threadIdx.x] = s_cnt[threadIdx.x];
 }
 
+// ReSTIRIndirect, indirect_stage.comp:228-268 (+ findTemporalNeighbor :74-108): temporal lookup, reservoir update, shading
+// of the half-resolution pixel.  Shared by the generic indirect kernel body and the multi-tile single-bounce body.
+RT_DEV void restirIndirectFinish(Ctx& c, const DevFrame& F, const rt_state& st, const rt_scene_camera& cam, i2 px, i2 indSize, const GState& primState, f3 primWo,
+                                 rt_gi_sample gi, float primSamplePdf)
+{
+  f3 indirect = mk3(0.0f);
+  rt_indirect_reservoir resv;
+  resv.giSample.L = rt_vec3{0, 0, 0}; resv.giSample.xv = rt_vec3{0, 0, 0}; resv.giSample.nv = rt_vec3{0, 0, 0};
+  resv.giSample.xs = rt_vec3{0, 0, 0}; resv.giSample.ns = rt_vec3{0, 0, 0}; resv.giSample.pHat = 0.f;
+  resv.num = 0; resv.weight = 0.f; resv.bigW = 0.f;
+  if(st.ReSTIRState == RT_RESTIR_TEMPORAL || st.ReSTIRState == RT_RESTIR_SPATIOTEMPORAL) {
+    const float reprojDepth = length(mk3(cam.lastPosition) - primState.position);
+    const i2 motionIdx = loadMotion(F, i2{px.x * 2, px.y * 2});
+    if(motionIdx.x >= 0 && motionIdx.x < F.W && motionIdx.y >= 0 && motionIdx.y < F.H && (motionIdx.y < F.histRow0 || motionIdx.y >= F.histRow1)) *F.histMiss = 1u;
+    const uint4 lg = loadG(F.lastG, F, motionIdx);
+    const f3 pnorm = decompress_unit_vec(lg.y);
+    const float pdepth = rt_u2f(lg.x);
+    const uint32_t matHash = lg.w & 0xFF000000u;
+    const i2 coord{motionIdx.x / 2, motionIdx.y / 2};
+    if(inBound(coord, indSize)) {
+      if(hash8bit(primState.matID) == matHash) {
+        if(dot(primState.ffnormal, pnorm) > 0.5f && reprojDepth < pdepth * 1.1f) resv = F.lastIndirectResv[size_t(coord.y) * indSize.x + coord.x];
+      }
+    }
+  }
+  float sampleWeight = 0.0f;
+  if(GISampleValid(gi)) {
+    gi.pHat = resvToScalar(mk3(gi.L));  // pHatIndirect :61-66
+    sampleWeight = gi.pHat / primSamplePdf;
+    if(rt_isnan(sampleWeight) || sampleWeight < 0.0f) sampleWeight = 0.0f;
+  }
+  {  // resvUpdate :54-60
+    const float rr = rnd(c.seed);
+    resv.weight += sampleWeight; resv.num += 1;
+    if(rr * resv.weight < sampleWeight) resv.giSample = gi;
+  }
+  if(resvInvalidW(resv.weight)) { resv.num = 0; resv.weight = 0.f; resv.bigW = 0.f; }
+  resvClamp(resv, st.reservoirClamp * 2);
+  F.thisIndirectResv[size_t(px.y) * indSize.x + px.x] = resv;  // saveNewReservoir
+
+  gi = resv.giSample;
+  if(!resvInvalidW(resv.weight) && GISampleValid(gi)) {
+    const f3 primWi = normalize(mk3(gi.xs) - mk3(gi.xv));
+    Material pm = primState.mat;
+    pm.albedo = mk3(1.0f);
+    const float bigW = resv.weight / (resvToScalar(mk3(resv.giSample.L)) * float(resv.num));  // bigWIndirect :68-70
+    indirect = mk3(gi.L) * metallicWorkflowBSDF(pm, mk3(gi.nv), primWo, primWi) * satDot(mk3(gi.nv), primWi) * bigW;
+  }
+  f3 pixelColor = HDRToLDR(c.clampRadiance(indirect));
+  pixelColor = c.clampRadiance(pixelColor);
+  storeImg(F.denoiseIndA, F, px, mk4(pixelColor, 1.0f));
+}
+
+// ---- single-bounce tiles, K tiles per wave ----------------------------------------------------------------------------------
+// 75 % of the tiles stop after one bounce + one NEE shadow ray (TILED_MULTIBOUNCE, :283-288): per path one closest-hit ray,
+// then at most one any-hit ray.  With one tile per wave the ray pool holds fewer rays than the wave has lanes (sky pixels,
+// paths that left the scene), and every lane then waits for the slowest ray: 77 % of the lane-rounds of these tiles were
+// idle.  Here a wave owns K such tiles; what a path carries between its three phases is small (seed, pdf, direction /
+// hit point, normal, pending NEE term), so K paths per lane stay in registers, both traces run over a pool of up to 64 K
+// rays, and lanes pull rays until the pool is dry.  Same arithmetic, same RNG draw order per path as the generic body.
+template <int K>
+RT_DEV void indirectSingleBounceTiles(const DevScene& S, const DevFrame& F, const rt_state& st, const rt_scene_camera& cam, int rowBegin, int rowEnd, int tilesX,
+                                      const uint32_t* tiles /* K entries */, int nTilesHere, uint2* s_stack)
+{
+  const int lane = int(threadIdx.x);
+  const i2 indSize{st.size.x / 2, st.size.y / 2};
+  float4* pool = reinterpret_cast<float4*>(s_stack + size_t(S.stackEntries) * 64);
+  Ctx c(S, st, cam, s_stack + lane);
+  struct Path { i2 px; uint32_t seed; float primSamplePdf; f3 a, b, pend; bool hasSurface, nvSet, shadow; };
+  // a: sampleWi between phase 0 and 1, gi.xs afterwards; b: gi.ns; pend: the NEE term waiting for its visibility
+  Path P[K];
+  uint32_t have = 0;
+  // ---- phase 0: G-buffer decode, BSDF sample, park the bounce ray (depth 1 of pathTraceIndirect, :129-226) ---------------------
+#pragma unroll
+  for(int k = 0; k < K; k++) {
+    Path& p = P[k];
+    p.hasSurface = false; p.nvSet = false; p.shadow = false; p.primSamplePdf = 0.0f; p.a = mk3(0.0f); p.b = mk3(0.0f); p.pend = mk3(0.0f);
+    const int t = int(tiles[k < nTilesHere ? k : 0]);
+    const int ty = t / tilesX, tx = t - ty * tilesX;
+    p.px = i2{tx * 8 + (lane & 7), rowBegin + ty * 8 + (lane >> 3)};
+    p.seed = tea(uint32_t(indSize.x) * uint32_t(p.px.y) + uint32_t(p.px.x), st.time);  // :280
+    if(lane == 0) (void)rnd(p.seed);  // invocation 0 drew the tile flag from its own stream (:283-288); the flag is known here
+    const bool inImage = k < nTilesHere && !(p.px.x >= indSize.x || p.px.y >= indSize.y || p.px.y >= rowEnd);
+    if(!inImage) continue;
+    const Ray ray = c.raySpawn(p.px, indSize);
+    GState g0; float depth;
+    if(!stateFromGBuffer(loadG(F.thisG, F, i2{p.px.x * 2, p.px.y * 2}), ray, g0, depth)) { storeImg(F.denoiseIndA, F, p.px, mk4(0, 0, 0, 0)); continue; }
+    p.hasSurface = true;
+    g0.position += g0.ffnormal * 2e-2f;  // :299
+    Material m = g0.mat; m.albedo = mk3(1.0f);
+    if(st.maxDepth < 1) continue;
+    c.seed = p.seed;
+    f3 wi = mk3(0.0f); float pdf = 0.0f;
+    (void)c.Sample(m, -ray.direction, g0.ffnormal, wi, pdf);
+    p.seed = c.seed;
+    if(Ctx::IsPdfInvalid(pdf)) continue;
+    p.primSamplePdf = pdf; p.nvSet = true; p.a = wi;
+    c.nClosest++;
+    poolPut(pool, k * 64 + lane, OffsetRay(g0.position, g0.ffnormal), wi, RT_INFINITY, p.seed);
+    have |= 1u << k;
+  }
+  tracePoolTiles<K, false>(S, pool, have, c.stack, c.tc);
+  // ---- phase 1: the hit; NEE sample of depth 2 -> shadow ray; the BSDF sample depth 2 draws before it stops (:169-176) ------
+  uint32_t haveS = 0;
+#pragma unroll
+  for(int k = 0; k < K; k++) {
+    Path& p = P[k];
+    if(!((have >> k) & 1u)) continue;
+    const f3 wi = p.a;
+    c.hit = poolGet(pool, k * 64 + lane);
+    const Ray ray0 = c.raySpawn(p.px, indSize);
+    GState g0; float depth;
+    stateFromGBuffer(loadG(F.thisG, F, i2{p.px.x * 2, p.px.y * 2}), ray0, g0, depth);
+    g0.position += g0.ffnormal * 2e-2f;
+    if(c.hit.t >= RT_INFINITY - 1e-4f) {  // :183-195, depth 1
+      p.a = g0.position + wi * RT_INFINITY * 0.8f; p.b = -wi;
+      continue;
+    }
+    const Ray ray{OffsetRay(g0.position, g0.ffnormal), wi};
+    State state = c.GetState(ray.direction);
+    c.GetMaterials(state, ray);
+    p.a = state.position; p.b = state.ffnormal;  // gi.xs / gi.ns, emitter or not (:197-215)
+    if(state.isEmitter || st.maxDepth < 2) continue;
+    c.seed = p.seed;
+    const f3 wo = -ray.direction;
+    if(st.MIS > 0) {  // SampleDirectLight (pathtrace.glsl:185-203) minus its visibility test; throughput is 1 in these tiles
+      rt_light_sample ls;
+      const float lightPdf = c.SampleDirectLightNoVisibility(state.position, ls);
+      if(!Ctx::IsPdfInvalid(lightPdf)) {
+        const f3 lwi = mk3(ls.wi);
+        const f3 so = OffsetRay(state.position, state.ffnormal);
+        const float maxDist = ((ls.dist - rt_abs(so.x - state.position.x)) - rt_abs(so.y - state.position.y)) - rt_abs(so.z - state.position.z);  // Occlusion :18-22
+        c.nAny++;
+        poolPut(pool, k * 64 + lane, so, lwi, maxDist, c.seed);
+        haveS |= 1u << k; p.shadow = true;
+        const float BSDFPdf = metallicWorkflowPdf(state.mat, state.ffnormal, wo, lwi);
+        const float weight = MISw(st, lightPdf, BSDFPdf);
+        p.pend = mk3(ls.Li) * metallicWorkflowBSDF(state.mat, state.ffnormal, wo, lwi) * absDot(state.ffnormal, lwi) * mk3(1.0f) / lightPdf * weight;
+      }
+    }
+    f3 w2 = mk3(0.0f); float pdf2 = 0.0f;
+    (void)c.Sample(state.mat, wo, state.ffnormal, w2, pdf2);  // depth 2 samples the BSDF, then `if(!multiBounce) break`
+    p.seed = c.seed;
+  }
+  // (slots of the bounce rays were read above; the shadow rays reuse them)
+  tracePoolTiles<K, true>(S, pool, haveS, c.stack, c.tc);
+  // ---- phase 2: visibility of the NEE term, then ReSTIRIndirect ------------------------------------------------------------------
+#pragma unroll
+  for(int k = 0; k < K; k++) {
+    Path& p = P[k];
+    if(!p.hasSurface) continue;
+    rt_gi_sample gi = newGISample();
+    const Ray ray0 = c.raySpawn(p.px, indSize);
+    GState primState; float depth;
+    stateFromGBuffer(loadG(F.thisG, F, i2{p.px.x * 2, p.px.y * 2}), ray0, primState, depth);
+    primState.position += primState.ffnormal * 2e-2f;
+    if(p.nvSet) { gi.xv = toR(primState.position); gi.nv = toR(primState.ffnormal); gi.xs = toR(p.a); gi.ns = toR(p.b); }
+    if(p.shadow && poolGet(pool, k * 64 + lane).gid == 0xffffffffu) gi.L = toR(mk3(gi.L) + p.pend);  // not occluded
+    c.seed = p.seed;
+    c.imageCoords = p.px;
+    restirIndirectFinish(c, F, st, cam, p.px, indSize, primState, -ray0.direction, gi, p.primSamplePdf);
+  }
+  flushCounters(F, c);
+}
+
 __global__ __launch_bounds__(64, 4) void k_indirect_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY, int cap,
-                                                          const uint32_t* lists, const uint32_t* counts, int subShift)
+                                                          const uint32_t* lists, const uint32_t* counts, int subShift, int sbK, int genericBlocks)
 {
   // subShift > 0 (small launches: row bands of a multi-GPU frame, small images): a tile is split over 2 or 4 waves that own
   // 32 / 16 of its pixels each; the other lanes of each wave have no path and only serve the wave's ray pool.  With fewer
@@ -287,9 +452,20 @@ __global__ __launch_bounds__(64, 4) void k_indirect_stage(DevScene S, DevFrame F
   TileCoord tile;
   const int part = (int(blockIdx.x) >> 3) & ((1 << subShift) - 1);
   {
-    const int L = int(blockIdx.x), xcd = L & 7, k = (L >> 3) >> subShift;
+    const int L = int(blockIdx.x), xcd = L & 7;
     const int nf = int(counts[xcd * 2]), nb = int(counts[xcd * 2 + 1]);
-    tile.valid = k < nf + nb;
+    if(sbK > 0 && L >= genericBlocks) {  // single-bounce tiles of this XCD, sbK per wave (from the back of its list)
+      const int w = (L - genericBlocks) >> 3, first = w * sbK;
+      if(first >= nb) return;
+      uint32_t t[4] = {0u, 0u, 0u, 0u};
+      const int n = min(sbK, nb - first);
+      for(int k = 0; k < n; k++) t[k] = lists[size_t(xcd) * cap + (cap - 1 - (first + k))];
+      if(sbK == 2) indirectSingleBounceTiles<2>(S, F, st, cam, rowBegin, rowEnd, tilesX, t, n, s_stack);
+      else indirectSingleBounceTiles<4>(S, F, st, cam, rowBegin, rowEnd, tilesX, t, n, s_stack);
+      return;
+    }
+    const int k = (L >> 3) >> subShift;
+    tile.valid = sbK > 0 ? (k < nf) : (k < nf + nb);
     const uint32_t t = tile.valid ? lists[size_t(xcd) * cap + (k < nf ? k : cap - 1 - (k - nf))] : 0u;
     tile.y = int(t) / tilesX; tile.x = int(t) - tile.y * tilesX;
   }
@@ -410,53 +586,7 @@ __global__ __launch_bounds__(64, 4) void k_indirect_stage(DevScene S, DevFrame F
   }
   if(!hasSurface) { flushCounters(F, c); return; }
 
-  // ---- ReSTIRIndirect, :228-268 (+ findTemporalNeighbor :74-108) -------------------------------------------------
-  f3 indirect = mk3(0.0f);
-  rt_indirect_reservoir resv;
-  resv.giSample.L = rt_vec3{0, 0, 0}; resv.giSample.xv = rt_vec3{0, 0, 0}; resv.giSample.nv = rt_vec3{0, 0, 0};
-  resv.giSample.xs = rt_vec3{0, 0, 0}; resv.giSample.ns = rt_vec3{0, 0, 0}; resv.giSample.pHat = 0.f;
-  resv.num = 0; resv.weight = 0.f; resv.bigW = 0.f;
-  if(st.ReSTIRState == RT_RESTIR_TEMPORAL || st.ReSTIRState == RT_RESTIR_SPATIOTEMPORAL) {
-    const float reprojDepth = length(mk3(cam.lastPosition) - primState.position);
-    const i2 motionIdx = loadMotion(F, i2{px.x * 2, px.y * 2});
-    if(motionIdx.x >= 0 && motionIdx.x < F.W && motionIdx.y >= 0 && motionIdx.y < F.H && (motionIdx.y < F.histRow0 || motionIdx.y >= F.histRow1)) *F.histMiss = 1u;
-    const uint4 lg = loadG(F.lastG, F, motionIdx);
-    const f3 pnorm = decompress_unit_vec(lg.y);
-    const float pdepth = rt_u2f(lg.x);
-    const uint32_t matHash = lg.w & 0xFF000000u;
-    const i2 coord{motionIdx.x / 2, motionIdx.y / 2};
-    if(inBound(coord, indSize)) {
-      if(hash8bit(primState.matID) == matHash) {
-        if(dot(primState.ffnormal, pnorm) > 0.5f && reprojDepth < pdepth * 1.1f) resv = F.lastIndirectResv[size_t(coord.y) * indSize.x + coord.x];
-      }
-    }
-  }
-  float sampleWeight = 0.0f;
-  if(GISampleValid(gi)) {
-    gi.pHat = resvToScalar(mk3(gi.L));  // pHatIndirect :61-66
-    sampleWeight = gi.pHat / primSamplePdf;
-    if(rt_isnan(sampleWeight) || sampleWeight < 0.0f) sampleWeight = 0.0f;
-  }
-  {  // resvUpdate :54-60
-    const float rr = rnd(c.seed);
-    resv.weight += sampleWeight; resv.num += 1;
-    if(rr * resv.weight < sampleWeight) resv.giSample = gi;
-  }
-  if(resvInvalidW(resv.weight)) { resv.num = 0; resv.weight = 0.f; resv.bigW = 0.f; }
-  resvClamp(resv, st.reservoirClamp * 2);
-  F.thisIndirectResv[size_t(px.y) * indSize.x + px.x] = resv;  // saveNewReservoir
-
-  gi = resv.giSample;
-  if(!resvInvalidW(resv.weight) && GISampleValid(gi)) {
-    const f3 primWi = normalize(mk3(gi.xs) - mk3(gi.xv));
-    Material pm = primState.mat;
-    pm.albedo = mk3(1.0f);
-    const float bigW = resv.weight / (resvToScalar(mk3(resv.giSample.L)) * float(resv.num));  // bigWIndirect :68-70
-    indirect = mk3(gi.L) * metallicWorkflowBSDF(pm, mk3(gi.nv), primWo, primWi) * satDot(mk3(gi.nv), primWi) * bigW;
-  }
-  f3 pixelColor = HDRToLDR(c.clampRadiance(indirect));
-  pixelColor = c.clampRadiance(pixelColor);
-  storeImg(F.denoiseIndA, F, px, mk4(pixelColor, 1.0f));
+  restirIndirectFinish(c, F, st, cam, px, indSize, primState, primWo, gi, primSamplePdf);
   flushCounters(F, c);
 }
 
@@ -673,8 +803,15 @@ hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F,
       static const int subEnv = getenv("RESTIR_IND_SUB") ? atoi(getenv("RESTIR_IND_SUB")) : -1;
       const int nTiles = tilesX * tilesY;
       const int subShift = subEnv >= 0 ? subEnv : (nTiles <= 1536 ? 2 : (nTiles <= 3072 ? 1 : 0));
-      hipLaunchKernelGGL(k_indirect_stage, dim3(grid.x << subShift), block, lds + POOL_BYTES, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY, cap,
-                         (const uint32_t*)F.tileOrder, (const uint32_t*)(F.qcount + 192), subShift);
+      // throughput-bound launches: single-bounce tiles go K per wave (indirectSingleBounceTiles); latency-bound ones keep one
+      // (part of a) tile per wave
+      static const int sbEnv = getenv("RESTIR_IND_SBK") ? atoi(getenv("RESTIR_IND_SBK")) : -1;
+      const int sbK = sbEnv >= 0 ? sbEnv : (subShift > 0 ? 0 : 2);
+      const unsigned genericBlocks = grid.x << subShift;
+      const unsigned sbBlocks = sbK > 0 ? 8u * unsigned((cap + sbK - 1) / sbK) : 0u;
+      const size_t poolBytes = std::max<size_t>(POOL_BYTES, size_t(sbK) * 64 * 33);
+      hipLaunchKernelGGL(k_indirect_stage, dim3(genericBlocks + sbBlocks), block, lds + poolBytes, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY, cap,
+                         (const uint32_t*)F.tileOrder, (const uint32_t*)(F.qcount + 192), subShift, sbK, int(genericBlocks));
       break;
     }
     case RT_STAGE_DENOISE_DIRECT: {

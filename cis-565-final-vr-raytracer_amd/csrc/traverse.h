@@ -376,4 +376,49 @@ RT_DEV void tracePool(const DevScene& S, float4* pool, bool hasC, bool hasS, uin
   waveLdsSync();
 }
 
+// The same pool for rays of ONE kind parked by K pixels per lane (slot k*64 + lane, K <= 4): used by the multi-tile
+// single-bounce body of the indirect stage, where a wave owns K tiles so that the pool holds more rays than the wave has
+// lanes and a lane whose ray ends early pulls another one instead of waiting for the slowest ray of the wave.
+template <int K, bool ANY>
+RT_DEV void tracePoolTiles(const DevScene& S, float4* pool, uint32_t have /* bit k: this lane parked a ray for its k-th pixel */, uint2* stack, TravCounters& tc)
+{
+  unsigned char* list = reinterpret_cast<unsigned char*>(pool + K * 64 * POOL_SLOT_F4);
+  const int lane = int(threadIdx.x) & 63;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  int n = 0;
+#pragma unroll
+  for(int k = 0; k < K; k++) {
+    const bool h = (have >> k) & 1u;
+    const unsigned long long m = __ballot(h ? 1 : 0);
+    if(h) list[n + __popcll(m & lt)] = (unsigned char)(k * 64 + lane);
+    n += __popcll(m);
+  }
+  if(n == 0) return;
+  waveLdsSync();
+  int next = 0, mySlot = 0;
+  bool live = false;
+  Trav T;
+  for(;;) {
+    const unsigned long long idle = __ballot(live ? 0 : 1);
+    if(next < n && idle != 0ull) {
+      const int item = next + __popcll(idle & lt);
+      if(!live && item < n) {
+        mySlot = int(list[item]);
+        const float4 a = pool[mySlot * POOL_SLOT_F4], b = pool[mySlot * POOL_SLOT_F4 + 1];
+        live = travInit<ANY>(T, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), b.z, rt_f2u(b.w));
+        if(!live) pool[mySlot * POOL_SLOT_F4] = make_float4(T.hit.t, rt_u2f(T.hit.gid), T.hit.u, T.hit.v);
+      }
+      next = min(n, next + __popcll(idle));
+    }
+    if(__ballot(live ? 1 : 0) == 0ull) {
+      if(next >= n) break;
+      continue;
+    }
+    const bool still = travRound<ANY>(S, T, live, stack, tc);
+    if(live && !still) pool[mySlot * POOL_SLOT_F4] = make_float4(T.hit.t, rt_u2f(T.hit.gid), T.hit.u, T.hit.v);
+    live = still;
+  }
+  waveLdsSync();
+}
+
 }  // namespace rt
