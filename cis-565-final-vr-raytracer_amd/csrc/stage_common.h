@@ -11,9 +11,8 @@ struct TileCoord { int x, y; bool valid; };
 // stripes of TILE_STRIPE tile rows; stripe s belongs to XCD s % 8, so every XCD's private L2 works on a few compact screen
 // regions (and the BVH subtrees under them) while expensive image regions (foliage rows vs sky rows) are spread over all XCDs.
 constexpr int TILE_STRIPE = 2;
-RT_DEV TileCoord tileOf(int tilesX, int tilesY)
+RT_DEV TileCoord tileOfBlock(int L, int tilesX, int tilesY)
 {
-  const int L = int(blockIdx.x);
   const int xcd = L & 7, k = L >> 3;                 // k-th workgroup of this XCD
   const int perStripe = TILE_STRIPE * tilesX;
   const int s = k / perStripe, off = k - s * perStripe;
@@ -23,6 +22,7 @@ RT_DEV TileCoord tileOf(int tilesX, int tilesY)
   t.valid = t.y < tilesY;
   return t;
 }
+RT_DEV TileCoord tileOf(int tilesX, int tilesY) { return tileOfBlock(int(blockIdx.x), tilesX, tilesY); }
 // grid size (in workgroups) that covers tilesX x tilesY tiles with the mapping above
 inline unsigned tileGrid(int tilesX, int tilesY)
 {

@@ -13,6 +13,7 @@
 // wave-aggregated atomic per wave (ballot + mbcnt).  Per-pixel arithmetic and RNG draw order are exactly those of the
 // fused stages, so every output stays bit-identical (tests/test_gpu_parity.py runs both pipelines against the oracle).
 #include "stage_common.h"
+#include "direct_phases.h"
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -47,7 +48,6 @@ RT_DEV uint32_t queueSlot(uint32_t* counter, bool want)
 
 RT_DEV Ctx makeCtx(const DevScene& S, const rt_state& st, const rt_scene_camera& cam, uint2* stack) { return Ctx(S, st, cam, stack); }
 
-enum : uint32_t { ST_DONE = 0u, ST_RIS = 1u, ST_NONE = 2u };
 constexpr int CNT_SHADOW = 0;
 RT_DEV int cntC(int depth) { return 1 + depth; }   // closest-ray queue consumed at `depth`
 RT_DEV int cntA(int depth) { return 32 + depth; }  // shadow-ray queue whose result is consumed at `depth`
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(64) void k_primary(DevScene S, DevFrame F, rt_state
   }
 }
 
-// direct_stage.comp:155-215: everything between the primary hit and the shadow ray
+// direct_stage.comp:155-215: everything between the primary hit and the shadow ray (direct_phases.h)
 __global__ __launch_bounds__(64) void k_direct_shade(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY, int genOnly)
 {
   const TileCoord tile = tileOf(tilesX, tilesY);
@@ -195,79 +195,20 @@ __global__ __launch_bounds__(64) void k_direct_shade(DevScene S, DevFrame F, rt_
   size_t index = 0;
   if(inside) {
     Ctx c(S, st, cam, nullptr);
-    c.imageCoords = px;
     index = size_t(px.y) * st.size.x + px.x;
     c.seed = tea(uint32_t(st.size.x) * uint32_t(px.y) + uint32_t(px.x), st.time);
-    const Ray r = c.raySpawn(px, i2{st.size.x, st.size.y});
     const float4 h = F.hitRec[index];
     c.hit.t = h.x; c.hit.gid = rt_f2u(h.y); c.hit.u = h.z; c.hit.v = h.w;
-    uint32_t status = ST_DONE;
-    f3 radiance = mk3(0.0f);
-    const bool miss = genOnly ? (c.hit.t >= RT_INFINITY * 0.8f) : (c.hit.t >= RT_INFINITY);  // direct_gen.comp:86 vs direct_stage.comp:155
-    if(miss) {
-      uint4 g = make_uint4(rt_f2u(RT_INFINITY), 0u, 0u, RT_INVALID_MAT_ID);
-      radiance = c.EnvRadiance(r.direction);
-      if(genOnly) { updateGeometryAlbedo(g, radiance); F.thisDirectResv[index] = zeroDirectResv(); F.thisLightId[index] = 0xffffffffu; }
-      F.thisG[index] = g;
-      storeMotion(F, px, i2{0, 0});
-    } else {
-      State state = c.GetState(r.direction);
-      c.GetMaterials(state, r);
-      const i2 motionIdx = createMotionIndex(c, state.position);
-      uint4 gInfo = encodeGeometryInfo(state, c.hit.t);
-      storeMotion(F, px, motionIdx);
-      bool ris = false;
-      if(st.debugging_mode > RT_DBG_INDIRECT_STAGE) { radiance = c.DebugInfo(state); if(genOnly) updateGeometryAlbedo(gInfo, radiance); }
-      else if(state.isEmitter) { radiance = state.mat.emission; if(genOnly) updateGeometryAlbedo(gInfo, radiance); }
-      else ris = true;
-      F.thisG[index] = gInfo;
-      if(genOnly && !ris) { F.thisDirectResv[index] = zeroDirectResv(); F.thisLightId[index] = 0xffffffffu; }  // direct_gen.comp:136-137
-      if(ris) {
-        const f3 wo = -r.direction;
-        state.mat.albedo = mk3(1.0f);
-        rt_direct_reservoir resv = zeroDirectResv();
-        uint32_t lid = 0xffffffffu;
-        rt_light_sample ls;
-        if(!genOnly && st.ReSTIRState == RT_RESTIR_NONE) {
-          // DirectLight (pathtrace.glsl:205-220): the sample's pdf travels in resv.weight, the sample in resv.lightSample
-          const float pdf = c.SampleDirectLightNoVisibility(state.position, ls);
-          resv.lightSample = ls; resv.weight = pdf;
-          status = ST_NONE;
-          wantShadow = !Ctx::IsPdfInvalid(pdf);
-        } else {
-          for(int i = 0; i < st.RISSampleNum; i++) {  // direct_stage.comp:189-200
-            const float p = c.SampleDirectLightNoVisibility(state.position, ls);
-            const f3 pHat = mk3(ls.Li) * metallicWorkflowBSDF(state.mat, state.ffnormal, wo, mk3(ls.wi)) * rt_abs(dot(state.ffnormal, mk3(ls.wi)));
-            float weight = resvToScalar(pHat / p);
-            if(Ctx::IsPdfInvalid(p) || rt_isnan(weight)) weight = 0.0f;
-            if(resvUpdate(resv, ls, weight, rnd(c.seed))) lid = c.lastLightId;
-          }
-          status = ST_RIS;
-          wantShadow = resv.weight != 0.0f;  // a zero-weight reservoir cannot change: its shadow ray is skipped
-        }
-        ls = resv.lightSample;
-        const f3 org = OffsetRay(state.position, state.ffnormal);
-        const float tmax = ((ls.dist - rt_abs(org.x - state.position.x)) - rt_abs(org.y - state.position.y)) - rt_abs(org.z - state.position.z);  // Occlusion, pathtrace.glsl:18-22
-        F.shadowO[index] = make_float4(org.x, org.y, org.z, tmax);
-        F.shadowD[index] = make_float4(ls.wi.x, ls.wi.y, ls.wi.z, rt_u2f(c.seed));
-        F.occ[index] = 0u;
-        F.cand[index] = resv;
-        F.candLid[index] = lid;
-        SurfRec sr;
-        sr.position = toR(state.position); sr.normal = toR(state.normal); sr.ffnormal = toR(state.ffnormal); sr.emission = toR(state.mat.emission);
-        sr.roughness = state.mat.roughness; sr.metallic = state.mat.metallic; sr.matID = state.matID; sr.seed = c.seed;
-        F.surf[index] = sr;
-      }
-    }
-    F.status[index] = status;
-    if(status == ST_DONE && !genOnly) storeImg(F.thisDirectResult, F, px, mk4(c.clampRadiance(radiance), 1.0f));  // direct_stage.comp:285-286
+    float4 so = make_float4(0, 0, 0, 0), sd = make_float4(0, 0, 0, 0);
+    wantShadow = directShadePixel(c, F, st, px, genOnly, so, sd);
+    if(F.status[index] != ST_DONE) { F.shadowO[index] = so; F.shadowD[index] = sd; F.occ[index] = 0u; }
     if(F.counters) { atomicAdd(&F.counters[4], (unsigned long long)c.nShaded); atomicAdd(&F.counters[5], (unsigned long long)c.nRis); }
   }
   const uint32_t slot = queueSlot(&F.qcount[CNT_SHADOW], wantShadow);
   if(wantShadow) F.shadowQ[slot] = uint32_t(index);
 }
 
-// direct_stage.comp:208-270: visibility of the winner, temporal reuse, store, shade
+// direct_stage.comp:208-270: visibility of the winner, temporal reuse, store, shade (direct_phases.h)
 __global__ __launch_bounds__(64) void k_direct_resolve(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY, int genOnly)
 {
   const TileCoord tile = tileOf(tilesX, tilesY);
@@ -276,56 +217,9 @@ __global__ __launch_bounds__(64) void k_direct_resolve(DevScene S, DevFrame F, r
   const i2 px{tile.x * 8 + (lane & 7), rowBegin + tile.y * 8 + (lane >> 3)};
   if(px.x >= st.size.x || px.y >= rowEnd) return;
   const size_t index = size_t(px.y) * st.size.x + px.x;
-  const uint32_t status = F.status[index];
-  if(status == ST_DONE) return;
+  if(F.status[index] == ST_DONE) return;
   Ctx c(S, st, cam, nullptr);
-  c.imageCoords = px;
-  const SurfRec sr = F.surf[index];
-  c.seed = sr.seed;
-  rt_direct_reservoir resv = F.cand[index];
-  uint32_t lid = F.candLid[index];
-  const bool occluded = F.occ[index] != 0u;
-  if(genOnly) {  // direct_gen.comp:127-137
-    if(occluded) resv.weight = 0.0f;
-    F.thisDirectResv[index] = resv;
-    F.thisLightId[index] = lid;
-    return;
-  }
-  const Ray r = c.raySpawn(px, i2{st.size.x, st.size.y});
-  const f3 wo = -r.direction;
-  Material mat;
-  mat.albedo = mk3(1.0f); mat.emission = mk3(sr.emission); mat.metallic = sr.metallic; mat.roughness = sr.roughness; mat.ior = 0.f; mat.transmission = 0.f;
-  const f3 position = mk3(sr.position), normal = mk3(sr.normal), ffnormal = mk3(sr.ffnormal);
-  f3 direct = mk3(0.0f);
-  if(status == ST_NONE) {
-    const float pdf = resv.weight;
-    const rt_light_sample ls = resv.lightSample;
-    if(!Ctx::IsPdfInvalid(pdf) && !occluded)
-      direct = mk3(ls.Li) * metallicWorkflowBSDF(mat, ffnormal, wo, mk3(ls.wi)) * rt_max(dot(ffnormal, mk3(ls.wi)), 0.0f) / pdf;
-  } else {
-    if(occluded) resv.weight = 0.0f;
-    if(st.ReSTIRState == RT_RESTIR_TEMPORAL || st.ReSTIRState == RT_RESTIR_SPATIOTEMPORAL) {
-      const float reprojDepth = length(mk3(cam.lastPosition) - position);
-      const i2 motionIdx = loadMotion(F, px);  // RG16_SINT-saturated; equivalent to the unsaturated index for sizes <= 32767
-      rt_direct_reservoir temporal; uint32_t tlid = 0xffffffffu;
-      if(findTemporalNeighborDirect(F, st, normal, reprojDepth, sr.matID, motionIdx, temporal, tlid)) {
-        if(!resvInvalidW(temporal.weight)) { if(resvMerge(resv, temporal, rnd(c.seed))) lid = tlid; }
-      }
-    }
-    rt_direct_reservoir tempResv = resv;
-    if(resvInvalidW(tempResv.weight)) { tempResv.num = 0; tempResv.weight = 0.f; }
-    resvClamp(tempResv, st.RISSampleNum * st.reservoirClamp);
-    F.thisDirectResv[index] = tempResv;
-    F.thisLightId[index] = lid;
-    const rt_light_sample ls = resv.lightSample;
-    if(!resvInvalidW(resv.weight)) {
-      const f3 LiBsdf = mk3(ls.Li) * metallicWorkflowBSDF(mat, ffnormal, wo, mk3(ls.wi));
-      direct = LiBsdf / resvToScalar(LiBsdf) * resv.weight / float(resv.num);
-    }
-  }
-  if(rt_isnan(direct.x) || rt_isnan(direct.y) || rt_isnan(direct.z)) direct = mk3(0.0f);
-  const f3 radiance = HDRToLDR(c.clampRadiance(mat.emission + direct));
-  storeImg(F.thisDirectResult, F, px, mk4(c.clampRadiance(radiance), 1.0f));
+  directResolvePixel(c, F, st, cam, px, F.occ[index] != 0u, genOnly);
 }
 
 // ================================================================================================================
