@@ -14,7 +14,7 @@ HOST_LIB = os.path.join(_HERE, "host", "librestir_host.so")
 # -ffp-contract=off + correctly rounded divide/sqrt: the bit-reproducibility rules of include/rt_detmath.h
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
              "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-unused-result", "-x", "hip"]
-HIP_SRC = ["rt_api.cpp", "bvh8_builder.cpp", "stages.hip", "wavefront.hip", "stages_sky.hip", "wavefront_sky.hip", "post.hip"]
+HIP_SRC = ["rt_api.cpp", "bvh8_builder.cpp", "stages.hip", "wavefront.hip", "stages_sky.hip", "wavefront_sky.hip", "stages_cnt.hip", "stages_sky_cnt.hip", "post.hip"]
 HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-pthread"]
 HOST_SRC = ["scene.cpp", "scene_gen.cpp", "hdr_sampling.cpp", "gltf_loader.cpp", "jpeg_decoder.cpp", "host_capi.cpp"]
 
@@ -36,13 +36,30 @@ def _deps(d, exts):
 
 
 def build_hip(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950: one object per translation unit, compiled in parallel (the stage kernels exist in four
+    variants, see csrc/stages.hip), then one link into csrc/librestir_hip.so.  Objects go to csrc/_obj (git-ignored)."""
     d = os.path.join(_HERE, "csrc")
     if force or _stale(HIP_LIB, _deps(d, (".cpp", ".hip", ".h"))):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        cmd = [hipcc] + HIP_FLAGS + [os.path.join(d, s) for s in HIP_SRC] + ["-o", HIP_LIB]
+        objdir = os.path.join(d, "_obj")
+        os.makedirs(objdir, exist_ok=True)
+        flags = [f for f in HIP_FLAGS if f != "-shared"]
+        jobs = []
+        for src in HIP_SRC:
+            obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+            cmd = [hipcc] + flags + ["-c", os.path.join(d, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            jobs.append((cmd, obj, subprocess.Popen(cmd)))
+        objs = []
+        for cmd, obj, proc in jobs:
+            if proc.wait() != 0:
+                raise subprocess.CalledProcessError(proc.returncode, cmd)
+            objs.append(obj)
+        link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", HIP_LIB, "-pthread"]
         if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
+            print(" ".join(link), file=sys.stderr)
+        subprocess.check_call(link)
     return HIP_LIB
 
 

@@ -101,8 +101,9 @@ static hipError_t joinInFlight(rt_ctx* c)
 typedef hipError_t (*StageLauncher)(hipStream_t, const DevScene&, const DevFrame&, const rt_state&, const rt_scene_camera&, int, int, int, int);
 static StageLauncher stageLauncher(const rt_ctx* c)
 {
-  if(c->ds.sky) return c->pipeline ? rt::sky::launchStageWavefront : rt::sky::launchStage;
-  return c->pipeline ? rt::base::launchStageWavefront : rt::base::launchStage;
+  // fused kernels come with and without the counter flush (stages.hip); the wavefront kernels always carry it
+  if(c->ds.sky) return c->pipeline ? rt::sky::launchStageWavefront : (c->counting ? rt::sky_cnt::launchStage : rt::sky::launchStage);
+  return c->pipeline ? rt::base::launchStageWavefront : (c->counting ? rt::base_cnt::launchStage : rt::base::launchStage);
 }
 
 static thread_local std::string g_createErr;

@@ -31,8 +31,12 @@ inline unsigned tileGrid(int tilesX, int tilesY)
   return unsigned(8 * perXcd * TILE_STRIPE * tilesX);
 }
 
+#ifndef RT_COUNT
+#define RT_COUNT 1
+#endif
 RT_DEV void flushCounters(const DevFrame& F, const Ctx& c)
 {
+#if RT_COUNT
   if(!F.counters) return;
   atomicAdd(&F.counters[0], (unsigned long long)c.nClosest);
   atomicAdd(&F.counters[1], (unsigned long long)c.nAny);
@@ -42,6 +46,9 @@ RT_DEV void flushCounters(const DevFrame& F, const Ctx& c)
   atomicAdd(&F.counters[5], (unsigned long long)c.nRis);
   atomicAdd(&F.counters[6], (unsigned long long)c.tc.rounds);
   atomicAdd(&F.counters[7], (unsigned long long)c.tc.live);
+#else
+  (void)F; (void)c;
+#endif
 }
 
 // ---- image helpers: Vulkan storage-image semantics (out-of-bounds loads return 0) ------------------------------

@@ -14,6 +14,8 @@ constexpr int STACK_MAX = 64;  // LDS traversal stack entries per lane (8 B each
   }
 RT_DECL_LAUNCH(base)
 RT_DECL_LAUNCH(sky)
+namespace base_cnt { hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F, const rt_state& st, const rt_scene_camera& cam, int stage, int level, int rowBegin, int rowEnd); }
+namespace sky_cnt { hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F, const rt_state& st, const rt_scene_camera& cam, int stage, int level, int rowBegin, int rowEnd); }
 #undef RT_DECL_LAUNCH
 
 // uniform-only terms of sun_and_sky() (sky.h), one thread
