@@ -303,13 +303,30 @@ RT_DEV bool travRound(const DevScene& S, Trav& T, bool live, uint2* stack, TravC
   return live && (travHasTris(T) || travHasNodes(T));
 }
 
+// travRound for callers that already hold the wave's live mask (saves one ballot per round)
+template <int ANY>
+RT_DEV bool travRoundMasked(const DevScene& S, Trav& T, bool live, unsigned long long liveMask, uint2* stack, TravCounters& tc)
+{
+  tc.rounds++; tc.live += live ? 1u : 0u;
+  const bool wantTri = live && travHasTris(T);
+  const int nT = __popcll(__ballot(wantTri ? 1 : 0)), nN = __popcll(liveMask) - nT;
+  if(nT >= nN) { if(wantTri) travTri<ANY>(S, T, tc); }
+  else { if(live && !wantTri) travNode(S, T, stack, tc); }
+  return live && (travHasTris(T) || travHasNodes(T));
+}
+
 template <int ANY>
 RT_DEV bool traceRay(const DevScene& S, f3 o, f3 d, float tmax, uint32_t raySeed, uint2* stack, RayHit& hit, TravCounters& tc)
 {
   Trav T;
   bool live = travInit<ANY>(T, o, d, tmax, raySeed);
   // all lanes that entered this call stay in the loop until the last one is done, so the ballots of travRound see them
-  while(__ballot(live ? 1 : 0) != 0ull) live = travRound<ANY>(S, T, live, stack, tc);
+  // (travRound with its ballots shared between the vote and the loop condition: two per round instead of three)
+  unsigned long long liveMask = __ballot(live ? 1 : 0);
+  while(liveMask != 0ull) {
+    live = travRoundMasked<ANY>(S, T, live, liveMask, stack, tc);
+    liveMask = __ballot(live ? 1 : 0);
+  }
   hit = T.hit;
   return T.found;
 }
@@ -353,7 +370,8 @@ RT_DEV void tracePool(const DevScene& S, float4* pool, bool hasC, bool hasS, uin
   bool live = false;
   Trav T;
   for(;;) {
-    const unsigned long long idle = __ballot(live ? 0 : 1);
+    unsigned long long liveMask = __ballot(live ? 1 : 0);
+    const unsigned long long idle = ~liveMask;   // every lane of the wave is in this loop
     if(next < n && idle != 0ull) {
       const int item = next + __popcll(idle & lt);
       if(!live && item < n) {
@@ -364,12 +382,13 @@ RT_DEV void tracePool(const DevScene& S, float4* pool, bool hasC, bool hasS, uin
         if(!live) pool[mySlot * POOL_SLOT_F4] = make_float4(T.hit.t, rt_u2f(T.hit.gid), T.hit.u, T.hit.v);
       }
       next = min(n, next + __popcll(idle));
+      liveMask = __ballot(live ? 1 : 0);
     }
-    if(__ballot(live ? 1 : 0) == 0ull) {
+    if(liveMask == 0ull) {
       if(next >= n) break;
       continue;
     }
-    const bool still = travRound<2>(S, T, live, stack, tc);
+    const bool still = travRoundMasked<2>(S, T, live, liveMask, stack, tc);
     if(live && !still) pool[mySlot * POOL_SLOT_F4] = make_float4(T.hit.t, rt_u2f(T.hit.gid), T.hit.u, T.hit.v);
     live = still;
   }
@@ -399,7 +418,8 @@ RT_DEV void tracePoolTiles(const DevScene& S, float4* pool, uint32_t have /* bit
   bool live = false;
   Trav T;
   for(;;) {
-    const unsigned long long idle = __ballot(live ? 0 : 1);
+    unsigned long long liveMask = __ballot(live ? 1 : 0);
+    const unsigned long long idle = ~liveMask;   // every lane of the wave is in this loop
     if(next < n && idle != 0ull) {
       const int item = next + __popcll(idle & lt);
       if(!live && item < n) {
@@ -409,12 +429,13 @@ RT_DEV void tracePoolTiles(const DevScene& S, float4* pool, uint32_t have /* bit
         if(!live) pool[mySlot * POOL_SLOT_F4] = make_float4(T.hit.t, rt_u2f(T.hit.gid), T.hit.u, T.hit.v);
       }
       next = min(n, next + __popcll(idle));
+      liveMask = __ballot(live ? 1 : 0);
     }
-    if(__ballot(live ? 1 : 0) == 0ull) {
+    if(liveMask == 0ull) {
       if(next >= n) break;
       continue;
     }
-    const bool still = travRound<ANY>(S, T, live, stack, tc);
+    const bool still = travRoundMasked<ANY>(S, T, live, liveMask, stack, tc);
     if(live && !still) pool[mySlot * POOL_SLOT_F4] = make_float4(T.hit.t, rt_u2f(T.hit.gid), T.hit.u, T.hit.v);
     live = still;
   }
