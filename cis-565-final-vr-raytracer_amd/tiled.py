@@ -338,6 +338,9 @@ class PipelinedTiledFrame(TiledFrame):
             c.wait(self._wD)                                                  # neighbours' history rows of f-1
             b.set_history_rows(max(0, self.y0 - HIST_HALO), min(self.H, self.y1 + HIST_HALO))
             self._run(state, f, abi.STAGE_DIRECT, 0, self.y0, self.y1, self.H)
+            # ---- 2. second half of frame f-1, issued while direct(f) runs: the host's wait for indirect(f-1)'s flag overlaps
+            #         with direct(f) instead of following it
+            self._finish_prev()
             if c.any_flag(self._miss(abi.STAGE_DIRECT)):
                 self.history_fallbacks += 1
                 self._drain()
@@ -359,8 +362,6 @@ class PipelinedTiledFrame(TiledFrame):
             self._wD_prev = self._wD
             self._wD = c.halo_exchange(items, async_op=True)
             self._record(("D", f))
-        # ---- 2. second half of frame f-1 (its indirect stage ran beside direct(f)) ---------------------------------------------
-        self._finish_prev()
         # ---- 3. indirect(f) on the ind stream -----------------------------------------------------------------------------------
         with self._stream("ind"):
             self._wait_ev(("D", f)); self._wait_ev(("done", f - 1))            # this G-buffer band; the noisy-indirect scratch is free
