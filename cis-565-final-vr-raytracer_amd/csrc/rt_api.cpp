@@ -225,14 +225,14 @@ int rt_create(rt_ctx** out, int device)
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     const char* pe = getenv("RESTIR_PRIO");
-    const bool prio = !(pe && atoi(pe) == 0) && hi < lo;
-    if(prio) {
-      (void)hipStreamCreateWithPriority(&c->sideStream, hipStreamNonBlocking, hi);
-      (void)hipStreamCreateWithPriority(&c->indStream, hipStreamNonBlocking, hi);
-    } else {
-      (void)hipStreamCreateWithFlags(&c->sideStream, hipStreamNonBlocking);
-      (void)hipStreamCreateWithFlags(&c->indStream, hipStreamNonBlocking);
-    }
+    const int mode = pe ? atoi(pe) : 1;   // 0 none, 1 ind + side high, 2 ind high, 3 side high
+    const bool can = hi < lo;
+    auto mk = [&](hipStream_t* s, bool high) {
+      if(can && high) (void)hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi);
+      else (void)hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    };
+    mk(&c->sideStream, mode == 1 || mode == 3);
+    mk(&c->indStream, mode == 1 || mode == 2);
   }
   for(int i = 0; i < 4; i++) {
     (void)hipEventCreateWithFlags(&c->evD[i], hipEventDisableTiming);
