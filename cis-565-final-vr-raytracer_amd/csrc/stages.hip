@@ -636,12 +636,12 @@ __global__ __launch_bounds__(64) void k_denoise_geom(DevFrame F, rt_state st, rt
   (IND ? F.geomPh : F.geomP)[idx] = make_float4(pos.x, pos.y, pos.z, 0.f);
 }
 
-// exp(x) for x <= 0 or NaN, bit-identical to rt_exp() on that domain (same range reduction, polynomial and scaling; the
+// exp(x) for x <= 0, bit-identical to rt_exp() on that domain (same range reduction, polynomial and scaling; the
 // x > 88.7 early-out of rt_exp cannot trigger) but with selects instead of branches.
 RT_DEV float expNonPositive(float x)
 {
   const float z = rt_floor(x * 1.44269504088896341f + 0.5f);
-  const int n = max(rt_ftoi(z), -300);
+  const int n = rt_ftoi(z);
   float r = x - z * 0.693359375f;
   r = r - z * -2.12194440e-4f;
   const float rr = r * r;
@@ -653,10 +653,12 @@ RT_DEV float expNonPositive(float x)
   p = p * r + 5.0000001201E-1f;
   p = p * rr + r;
   p = p + 1.0f;
-  const int a = n >> 1, b = n - a;
-  float e = (p * rt_u2f(uint32_t(a + 127) << 23)) * rt_u2f(uint32_t(b + 127) << 23);
-  e = (x < -87.33654475055310f) ? 0.0f : e;
-  return rt_isnan(x) ? x : e;
+  // rt_exp scales in two steps, (p * 2^a) * 2^b with a + b = n, so that results below the normal range round once; for
+  // x >= -87.34 n >= -126, 2^n is a normal number and p * 2^n is the same single rounding.  Below that the result is 0.
+  float e = p * rt_u2f(uint32_t(n + 127) << 23);
+  // NaN in => NaN out through the arithmetic (rt_exp returns its argument, i.e. possibly another NaN payload; every caller
+  // turns a NaN weight into the same cleared pixel)
+  return (x < -87.33654475055310f) ? 0.0f : e;
 }
 
 // a / b for a uniform divisor b with y = RN(1 / b) precomputed by an IEEE division: q = RN(a*y), r = a - b*q (exact, fma),

@@ -262,15 +262,13 @@ void orc_detmath(int op, int n, const float* a, const float* b, float* out)
       // 10: the product's branch-free exp for x <= 0 (csrc/stages.hip expNonPositive) must equal rt_exp there
       case 10: {
         const float x = a[i], z = rt_floor(x * 1.44269504088896341f + 0.5f);
-        int n = rt_ftoi(z); if(n < -300) n = -300;
+        const int n = rt_ftoi(z);
         float r = x - z * 0.693359375f; r = r - z * -2.12194440e-4f;
         const float rr = r * r;
         float p = 1.9875691500E-4f; p = p * r + 1.3981999507E-3f; p = p * r + 8.3334519073E-3f; p = p * r + 4.1665795894E-2f; p = p * r + 1.6666665459E-1f;
         p = p * r + 5.0000001201E-1f; p = p * rr + r; p = p + 1.0f;
-        const int ha = n >> 1, hb = n - ha;
-        float e = (p * rt_u2f(uint32_t(ha + 127) << 23)) * rt_u2f(uint32_t(hb + 127) << 23);
-        e = (x < -87.33654475055310f) ? 0.0f : e;
-        out[i] = rt_isnan(x) ? x : e; break; }
+        float e = p * rt_u2f(uint32_t(n + 127) << 23);
+        out[i] = (x < -87.33654475055310f) ? 0.0f : e; break; }
       default: out[i] = 0;
     }
   }

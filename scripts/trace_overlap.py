@@ -8,8 +8,8 @@ for r in rows:
     k = n.split("(")[0].split("::")[-1].split("<")[0]
     ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), k))
 ev.sort()
-t_end = ev[-1][1]
-win = [e for e in ev if e[0] > t_end - 20_000_000]   # last 20 ms
+t_mid = (ev[0][0] + ev[-1][1]) // 2 if len(sys.argv) < 3 else ev[0][0] + int(float(sys.argv[2]) * 1e6)
+win = [e for e in ev if t_mid <= e[0] < t_mid + 20_000_000]   # 20 ms from the middle of the run (or from argv[2] ms after the first kernel)
 t0 = win[0][0]
 busy = collections.Counter(); total = win[-1][1] - t0
 for s, e, k in win: busy[k] += e - s
