@@ -199,3 +199,39 @@ def test_pick_matches_oracle():
             if a.instanceID >= 0:
                 assert abs(sum(a.baryCoord) - 1.0) < 1e-5 and a.hitT > 0
     assert hits > 20
+
+
+def test_cpp_demo_application_matches_python_host(tmp_path):
+    """host/restir_demo (C++ Scene / AccelStructure / Renderer / RenderOutput classes of host/renderer.hpp in main.cpp's call
+    order) against the same frames driven through the ctypes mirror: the HDR sum (.pfm) and the tonemapped image (.ppm)."""
+    import os, subprocess
+    from helpers import ROOT
+    from restir_amd.renderer import Renderer
+    demo = os.path.join(ROOT, "cis-565-final-vr-raytracer_amd", "host", "restir_demo")
+    if not os.path.exists(demo):
+        pytest.skip("restir_demo not built (run __graft_entry__.build())")
+    gltf = os.path.join(ROOT, "tests", "golden", "mini_scene.gltf")
+    W, H, N = 96, 64, 3
+    out = str(tmp_path / "demo")
+    subprocess.check_call([demo, "-f", gltf, "-w", str(W), "-h", str(H), "-n", str(N), "-o", out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    with open(out + ".pfm", "rb") as f:
+        assert f.readline().strip() == b"PF" and f.readline().split() == [str(W).encode(), str(H).encode()] and float(f.readline()) < 0
+        hdr = np.frombuffer(f.read(), dtype="<f4").reshape(H, W, 3)[::-1]                  # PFM scanlines are bottom-up
+    with open(out + ".ppm", "rb") as f:
+        assert f.readline().strip() == b"P6"; f.readline(); f.readline()
+        ldr = np.frombuffer(f.read(), dtype=np.uint8).reshape(H, W, 3)
+    # the same through Python: RtxState exactly as restir_demo.cpp fills it (no environment for a -f scene without -e)
+    sc = host.Scene(); assert sc.load(gltf)
+    st = host.default_state(W, H, sc, None)
+    st.fireflyClampThreshold = 100.0; st.environmentProb = 0.0; st.envMapLuminIntegInv = 0.0
+    r = Renderer().setup(0); r.load_scene(sc.desc(None)); r.update(W, H)
+    for f in range(N):
+        sc.updateCamera(W, H); r.set_camera(sc.getCamera())
+        st.frame = f; st.time = 1000 + f
+        r.run(st, f)
+    cur = (N - 1) & 1
+    d = r.readback(abi.BUF_DIRECT_RESULT0 + cur).view(np.float32).reshape(H, W, 4)
+    i = r.readback(abi.BUF_INDIRECT_RESULT0 + cur).view(np.float32).reshape(H, W, 4)
+    assert np.array_equal((d[..., :3] + i[..., :3]).view(np.uint32), hdr.view(np.uint32))
+    r.tonemap(abi.Tonemapper(), 0, N - 1)
+    assert np.array_equal(r.readback(abi.BUF_LDR).reshape(H, W, 4)[..., :3], ldr)
