@@ -58,7 +58,16 @@ def lib():
         L.orc_offset_ray.argtypes = [C.c_void_p] * 3
         L.orc_concentric_disk.argtypes = [C.c_float, C.c_float, C.c_void_p]
         L.orc_bsdf_eval.argtypes = [C.c_void_p] * 5
+        L.orc_power_heuristic.argtypes = [C.c_float, C.c_float]; L.orc_power_heuristic.restype = C.c_float
+        L.orc_luminance.argtypes = [C.c_void_p]; L.orc_luminance.restype = C.c_float
+        L.orc_hdr_to_ldr.argtypes = [C.c_void_p] * 2
+        L.orc_ldr_to_hdr.argtypes = [C.c_void_p] * 2
+        L.orc_resv_op.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_int, C.c_void_p]
         L.orc_bsdf_sample.argtypes = [C.c_void_p] * 5
+        L.orc_spherical_uv.argtypes = [C.c_void_p] * 2
+        L.orc_coordinate_system.argtypes = [C.c_void_p] * 2
+        L.orc_post_fn.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_pcg3d.argtypes = [C.c_void_p]
         L.orc_detmath.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib

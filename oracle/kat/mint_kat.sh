@@ -5,3 +5,5 @@ HERE="$(cd "$(dirname "$0")" && pwd)"
 bash "$HERE/build_ref.sh"
 "$HERE/../_ref/kat_ref" > "$HERE/../../tests/golden/kat_reference.json"
 echo "wrote tests/golden/kat_reference.json"
+"$HERE/../_ref/kat_float" > "$HERE/../../tests/golden/kat_reference_float.json"
+echo "wrote tests/golden/kat_reference_float.json"

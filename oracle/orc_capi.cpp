@@ -242,6 +242,34 @@ void orc_bsdf_sample(const float* m, const float* n, const float* wo, const floa
   out[0] = dir.x; out[1] = dir.y; out[2] = dir.z; out[3] = pdf; out[4] = bsdf.x; out[5] = bsdf.y; out[6] = bsdf.z;
 }
 
+// ---- scalar helpers + reservoir arithmetic for the known-answer vectors minted from the reference's GLSL (tests/test_kat_float.py)
+void orc_spherical_uv(const float* d, float* out) { vec2 uv = GetSphericalUv(V3(d[0], d[1], d[2])); out[0] = uv.x; out[1] = uv.y; }
+void orc_coordinate_system(const float* n, float* out) { vec3 t, b; CreateCoordinateSystem(V3(n[0], n[1], n[2]), t, b); out[0] = t.x; out[1] = t.y; out[2] = t.z; out[3] = b.x; out[4] = b.y; out[5] = b.z; }
+float orc_power_heuristic(float f, float g) { return powerHeuristic(f, g); }
+float orc_luminance(const float* c) { return luminance(V3(c[0], c[1], c[2])); }
+void orc_hdr_to_ldr(const float* c, float* out) { vec3 r = HDRToLDR(V3(c[0], c[1], c[2])); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+void orc_ldr_to_hdr(const float* c, float* out) { vec3 r = LDRToHDR(V3(c[0], c[1], c[2])); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+// One step of the op stream of oracle/kat/kat_float.cpp over a (DirectReservoir, IndirectReservoir) pair.
+// ops: 0 update(w, r, tag)  1 merge(rhs{num, weight, tag}, r) [direct only]  2 clamp(c)  3 checkValidity  4 reset
+void orc_resv_op(rt_direct_reservoir* d, rt_indirect_reservoir* g, int op, float w, float r, float tag, uint32_t rn, int c, int* invalid)
+{
+  switch(op) {
+    case 0: {
+      rt_light_sample ls = zeroLightSample(); ls.Li = rt_vec3{tag, tag, tag}; ls.wi = rt_vec3{0, 0, 1}; ls.dist = tag; resvUpdate(*d, ls, w, r);
+      rt_gi_sample gs; memset(&gs, 0, sizeof(gs)); gs.L = rt_vec3{tag, tag, tag}; gs.pHat = tag; resvUpdate(*g, gs, w, r);
+    } break;
+    case 1: {
+      rt_direct_reservoir rhs; memset(&rhs, 0, sizeof(rhs)); rhs.lightSample.Li = rt_vec3{tag, tag, tag}; rhs.lightSample.wi = rt_vec3{0, 0, 1}; rhs.lightSample.dist = tag;
+      rhs.num = rn; rhs.weight = w;
+      if(!resvInvalid(rhs)) resvMerge(*d, rhs, r);
+    } break;
+    case 2: resvClamp(*d, c); resvClamp(*g, c); break;
+    case 3: resvCheckValidity(*d); resvCheckValidity(*g); break;
+    default: resvReset(*d); resvReset(*g); break;
+  }
+  invalid[0] = resvInvalid(*d) ? 1 : 0; invalid[1] = resvInvalid(*g) ? 1 : 0;
+}
+
 // ---- numerics contract (include/rt_detmath.h) on arrays -----------------------------------------------------
 void orc_detmath(int op, int n, const float* a, const float* b, float* out)
 {

@@ -6,7 +6,8 @@
 // PARITY UNPINNED for this file: the reference draws this pass with a fragment shader into a swapchain (needs a Vulkan
 // device + glslang); no golden image exists.  Restated choices that the reference leaves to the driver are listed in
 // include/rt_abi.h at rt_tonemap (image mean for the top mip level, nearest texel for tm.zoom, global operator for the
-// "local" bit).  pcg3d is pinned by tests/golden/kat_reference.json (minted from random.glsl itself).
+// "local" bit).  The pass's pure helpers ARE pinned by vectors minted from the GLSL itself (tests/test_kat_float.py): pcg3d,
+// toneExposure and the dither step bit-exactly, toneMapUncharted to 1 ulp; main()'s sequence is restated.
 #include "orc_stages.h"
 
 namespace orc {
@@ -130,3 +131,17 @@ void Frame::tonemap(const rt_tonemapper& tm, int dbg, int frames)
 }
 
 }  // namespace orc
+
+// ---- display-pass helpers for the known-answer vectors minted from the reference's GLSL (tests/test_kat_float.py) ----
+// op 0: toneMapUncharted(in[0..2])                       1: dither(sRGBToLinear(in[0..2]), noise = in[3..5], 1/255)
+// op 2: toneExposure(key = in[0], Ywhite = in[1], RGB = in[2..4], logAvgLum = in[5])
+extern "C" void orc_post_fn(int op, const float* in, float* out)
+{
+  using namespace orc;
+  vec3 r{0, 0, 0};
+  if(op == 0) r = toneMapUncharted(vec3{in[0], in[1], in[2]});
+  else if(op == 1) r = dither(sRGBToLinear(vec3{in[0], in[1], in[2]}), vec3{in[3], in[4], in[5]}, 1.0f / 255.0f);
+  else if(op == 2) { rt_tonemapper tm; memset(&tm, 0, sizeof(tm)); tm.key = in[0]; tm.Ywhite = in[1]; r = toneExposure(tm, vec3{in[2], in[3], in[4]}, in[5]); }
+  out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+extern "C" void orc_pcg3d(uint32_t* v) { orc::pcg3d(v); }

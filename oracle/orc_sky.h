@@ -3,9 +3,11 @@
 //   calc_sun_color   :139-162      sky_color_xyz :165-223      sky_luminance :226-254      calc_env_color :257-272
 //   calc_irrad       :274-294      tweak_saturation :297-314   arch_vectortweak :317-330   arch_colortweak :333-362
 //   calc_physical_scale :365-436   night_brightness_adjustment :439-450                    sun_and_sky :453-601
-// PARITY UNPINNED: GLSL leaves exp/pow/acos/sin/cos/tan precision to the driver; here they are the contract functions of
+// PINNED WITHIN TOLERANCE: tests/test_kat_float.py compares sun_and_sky() with vectors minted from sun_and_sky.glsl itself
+// compiled on a vector shim (oracle/kat/kat_float.cpp): <= 7e-5 relative over 6 parameter sets x 48 directions.  Not bit-exact
+// by construction: GLSL leaves exp/pow/acos/sin/cos/tan precision to the driver; here they are the contract functions of
 // include/rt_detmath.h and every expression is evaluated left to right as written in the GLSL (all literals are floats there).
-// tests/test_sky.py checks this file against an independent float64 numpy statement of the same model.
+// tests/test_sky.py additionally checks this file against an independent float64 numpy statement of the same model.
 #pragma once
 #include "orc_math.h"
 #include "../include/rt_abi.h"

@@ -12,9 +12,10 @@
 //   src/renderer.cpp    :154-206   -> Frame::renderFrame
 //
 // PARITY UNPINNED: the reference has no tests, golden vectors or fixtures and cannot be
-// built here (Vulkan ray query + un-vendored nvpro_core).  The integer/bit-exact pieces are pinned by the
-// known-answer vectors under tests/golden/ that were minted from the reference's own source files
-// (oracle/kat/mint_kat.sh); everything else is a restatement checked by property tests.
+// built here (Vulkan ray query + un-vendored nvpro_core).  The per-sample arithmetic the stages call (RNG, packing,
+// reservoirs, BSDF, sky) is pinned by the known-answer vectors under tests/golden/ that were minted from the
+// reference's own source files (oracle/kat/mint_kat.sh; tests/test_kat.py, tests/test_kat_float.py); the stage-level
+// control flow in this file is a line-by-line restatement checked by property tests.
 #include "orc_stages.h"
 #include <thread>
 
