@@ -64,7 +64,10 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        import datetime
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this host driver
+        # a stuck exchange should end the run with an error instead of hanging it
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"), timeout=datetime.timedelta(seconds=300))
 
     W, H = args.width, args.height
     scene = host.Scene().makeProcedural(abi.PROC_BISTRO_EXT, args.scale, 1)
