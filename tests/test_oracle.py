@@ -205,3 +205,76 @@ def test_indirect_temporal_reuse_keeps_the_expectation():
     ratio = means["temporal"].sum((0, 1)) / means["single"].sum((0, 1))
     assert means["single"].mean() > 0.1
     assert np.all(np.abs(ratio - 1.0) < 0.05), ratio
+
+
+def test_direct_light_estimator_matches_area_quadrature():
+    """The whole light-sampling chain (uniform id -> alias table -> uniform barycentrics -> `Li = emission/area`, pdf =
+    table pdf * d^2 / (area * |cos|), times trigSampProb; pathtrace.glsl:103-139, 161-183, 205-220) must integrate to
+      E[direct] = sum_tri (emission / area_tri) * integral_tri f(wo, wi) cos+ |cos_l| / d^2 V dA
+    whatever the selection probabilities are.  The mean of 300 NEE frames is compared with a midpoint quadrature of that
+    integral (BSDF through orc_bsdf_eval, visibility through orc_trace_any) on a grid of Cornell-box pixels."""
+    W = H = 48
+    K = 300
+    sc, _ = make_scene(abi.PROC_CORNELL)
+    desc = sc.desc()
+    st = host.default_state(W, H, sc, None)
+    st.environmentProb = 0.0; st.fireflyClampThreshold = 1e6; st.ReSTIRState = abi.RESTIR_NONE; st.denoise = 0
+    o = Oracle(0); o.upload_scene(desc); o.resize(W, H)
+    sc.updateCamera(W, H); sc.updateCamera(W, H)
+    acc = np.zeros((H, W, 3))
+    for f in range(K):
+        st.time = 4000 + f; sc.updateCamera(W, H); cam = sc.getCamera(); o.set_camera(cam); o.run_stage(st, f, abi.STAGE_DIRECT)
+        y = o.readback(abi.BUF_DIRECT_RESULT0 + (f & 1)).view(np.float32).reshape(H, W, 4)[..., :3].astype(np.float64)
+        acc += y / (1.0 - np.minimum(y, 0.999999))
+    mean = acc / K
+    g = o.readback(abi.BUF_GBUFFER0 + ((K - 1) & 1)).view(np.uint32).reshape(H, W, 4)
+
+    nl = desc.lightInfo.trigLightSize
+    assert nl >= 2
+    lights = np.frombuffer(C.string_at(desc.trigLights, nl * 96), dtype=np.uint8).reshape(nl, 96)
+    mats = np.frombuffer(C.string_at(desc.materials, desc.numMaterials * 80), dtype=np.uint8).reshape(-1, 80)
+    vi = np.array(list(cam.viewInverse.m), dtype=np.float64).reshape(4, 4).T
+    pi = np.array(list(cam.projInverse.m), dtype=np.float64).reshape(4, 4).T
+    n_q = 20                                                          # midpoints of an n_q x n_q barycentric grid, both halves
+    a, b = (np.mgrid[0:n_q, 0:n_q] + 0.5) / n_q
+    lower = (a + b) < 1.0
+    bary = np.concatenate([np.stack([a[lower], b[lower]], -1), np.stack([1 - a[~lower], 1 - b[~lower]], -1)])  # folds the square onto the triangle
+    lum = lambda c: c @ np.array([0.2126, 0.7152, 0.0722])  # noqa: E731
+    est, quad = [], []
+    out3, out8 = np.zeros(3, np.float32), np.zeros(8, np.float32)
+    for py in range(3, H, 6):
+        for px in range(3, W, 6):
+            tex = g[py, px]
+            if (tex[3] & 0xFF000000) == 0xFF000000 or lum(mean[py, px]) > 5.0:
+                continue
+            u, v = (px + 0.5) / W * 2 - 1, (py + 0.5) / H * 2 - 1
+            t = pi @ np.array([u, v, 1.0, 1.0]); d = vi[:3, :3] @ (t[:3] / np.linalg.norm(t[:3]))
+            pos = vi[:3, 3] + d * float(tex[0:1].view(np.float32)[0])
+            lib().orc_decompress_unit_vec(int(tex[1]), out3.ctypes.data)
+            n = out3.astype(np.float64).copy()
+            if np.dot(n, -d) < 0: n = -n                               # ffnormal
+            zb = int(tex[2])
+            m = np.array([1, 1, 1, (zb & 0xff) / 255.0, ((zb >> 8) & 0xff) / 255.0], np.float32)   # albedo forced to 1 (direct_stage.comp:179)
+            total = np.zeros(3)
+            for L in lights:
+                v0, v1, v2 = (L[8 + 12 * k: 20 + 12 * k].view(np.float32).astype(np.float64) for k in range(3))
+                emission = mats[int(L[0:4].view(np.uint32)[0])][36:48].view(np.float32).astype(np.float64)
+                nl_vec = np.cross(v1 - v0, v2 - v0); area = 0.5 * np.linalg.norm(nl_vec); nl_vec /= 2 * area
+                ys = v0 + bary[:, :1] * (v1 - v0) + bary[:, 1:] * (v2 - v0)
+                dirs = ys - pos; dist = np.linalg.norm(dirs, axis=1); wi = dirs / dist[:, None]
+                rays = np.zeros((len(ys), 8), np.float32)
+                rays[:, 0:3] = pos + n * 1e-3; rays[:, 3:6] = wi; rays[:, 6] = dist * 0.999
+                vis = o.trace_any(rays) == 0
+                cosl = np.abs(wi @ nl_vec)
+                for k in np.nonzero(vis)[0]:
+                    w32 = wi[k].astype(np.float32)
+                    lib().orc_bsdf_eval(m.ctypes.data, n.astype(np.float32).ctypes.data, (-d).astype(np.float32).ctypes.data, w32.ctypes.data, out8.ctypes.data)
+                    total += (emission / area) * out8[0:3] * max(float(np.dot(n, wi[k])), 0.0) * cosl[k] / dist[k] ** 2 * (area / len(ys))
+            est.append(mean[py, px]); quad.append(total)
+    est, quad = np.array(est), np.array(quad)
+    assert len(est) >= 40 and lum(quad).sum() > 1.0
+    ratio = est.sum(0) / quad.sum(0)
+    assert np.all(np.abs(ratio - 1.0) < 0.03), ratio                  # measured: within 1 %
+    lit = lum(quad) > 0.2 * lum(quad).mean()
+    per_pixel = lum(est)[lit] / lum(quad)[lit]
+    assert abs(np.median(per_pixel) - 1.0) < 0.05, np.median(per_pixel)
