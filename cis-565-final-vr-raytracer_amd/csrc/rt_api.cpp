@@ -299,6 +299,29 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
     if(uint64_t(pm.firstIndex) + pm.indexCount > d->numIndices || uint64_t(pm.vertexOffset) + pm.vertexCount > d->numVertices || pm.indexCount % 3 != 0)
       return fail(c, RT_ERR_INVALID_ARG, "rt_upload_scene: prim mesh range out of bounds");
     if(pm.materialIndex >= int32_t(d->numMaterials)) return fail(c, RT_ERR_INVALID_ARG, "rt_upload_scene: material index out of range");
+    for(uint32_t k = 0; k < pm.indexCount; k++)
+      if(d->indices[pm.firstIndex + k] >= pm.vertexCount) return fail(c, RT_ERR_INVALID_ARG, "rt_upload_scene: vertex index beyond the prim mesh's vertex range");
+  }
+  // everything the kernels use as an array index is checked here: a bad id must come back as an error, not as a GPU fault
+  const int32_t nTex = d->textures ? int32_t(d->numTextures) : 0;
+  for(uint32_t i = 0; i < d->numMaterials; i++) {
+    const rt_material& m = d->materials[i];
+    const int32_t ids[5] = {m.pbrBaseColorTexture, m.pbrMetallicRoughnessTexture, m.emissiveTexture, m.normalTexture, m.transmissionTexture};
+    for(int32_t id : ids)
+      if(id < -1 || id >= nTex) return fail(c, RT_ERR_INVALID_ARG, "rt_upload_scene: material references a missing texture");
+  }
+  if(d->trigLights)
+    for(uint32_t i = 0; i < d->lightInfo.trigLightSize; i++)
+      if(d->trigLights[i].matIndex >= d->numMaterials || d->trigLights[i].impSamp.alias < 0 || uint32_t(d->trigLights[i].impSamp.alias) >= d->lightInfo.trigLightSize)
+        return fail(c, RT_ERR_INVALID_ARG, "rt_upload_scene: triangle light with a bad material or alias index");
+  if(d->puncLights)
+    for(uint32_t i = 0; i < d->lightInfo.puncLightSize; i++)
+      if(d->puncLights[i].impSamp.alias < 0 || uint32_t(d->puncLights[i].impSamp.alias) >= d->lightInfo.puncLightSize)
+        return fail(c, RT_ERR_INVALID_ARG, "rt_upload_scene: punctual light with a bad alias index");
+  if(d->envRgba32f && d->envAccel && d->envWidth > 0 && d->envHeight > 0) {
+    const int64_t n = int64_t(d->envWidth) * d->envHeight;
+    for(int64_t i = 0; i < n; i++)
+      if(d->envAccel[i].alias < 0 || d->envAccel[i].alias >= n) return fail(c, RT_ERR_INVALID_ARG, "rt_upload_scene: environment alias table entry out of range");
   }
   RT_HIP(c, hipSetDevice(c->device));
   RT_HIP(c, syncAll(c));

@@ -316,7 +316,9 @@ int rt_destroy(rt_ctx* ctx);
 /* Run every later launch on a caller-owned hipStream_t (NULL = ctx-owned stream). Lets the caller
  * order RCCL halo exchanges with the stages without host syncs. */
 int rt_set_stream(rt_ctx* ctx, void* hipStream);
-/* Scene::load's buffer uploads (scene.cpp:94-112) + HdrSampling::loadEnvironment upload (hdr_sampling.cpp:79-95). */
+/* Scene::load's buffer uploads (scene.cpp:94-112) + HdrSampling::loadEnvironment upload (hdr_sampling.cpp:79-95).
+ * Every value the kernels use as an array index (vertex indices, material / texture ids, light material ids, alias-table
+ * entries) is range-checked here: RT_ERR_INVALID_ARG instead of a device fault.  (The reference trusts nvh::GltfScene.) */
 int rt_upload_scene(rt_ctx* ctx, const rt_scene_desc* scene);
 /* AccelStructure::create (accelstruct.cpp:55-65): host-built flat BVH8 over world-space triangles. */
 int rt_build_accel(rt_ctx* ctx);

@@ -178,6 +178,42 @@ def test_error_paths():
     r.set_camera(sc.getCamera()); r.run(st, 0); r.sync()
 
 
+def test_malformed_scene_is_rejected_not_faulted():
+    """Everything the kernels use as an array index is validated by rt_upload_scene: a bad id is an error code, never a GPU fault."""
+    import ctypes as C
+    from restir_amd.renderer import Renderer, RtError
+    r = Renderer().setup(0)
+    sc, env = make_scene(abi.PROC_SPONZA, 0.01, 1, (64, 32))
+    good = sc.desc(env)
+
+    def corrupted(patch):
+        d = abi.SceneDesc.from_buffer_copy(good)
+        keep = patch(d)                       # returns the patched host array (kept alive during the call)
+        with pytest.raises(RtError):
+            r.load_scene(d)
+        return keep
+
+    def bad_index(d):
+        a = (C.c_uint32 * d.numIndices).from_buffer_copy(C.string_at(d.indices, d.numIndices * 4)); a[5] = 0x7fffffff
+        d.indices = C.cast(a, C.c_void_p).value; return a
+    def bad_texture(d):
+        a = bytearray(C.string_at(d.materials, d.numMaterials * 80)); a[16:20] = (123456).to_bytes(4, "little")   # pbrBaseColorTexture
+        b = (C.c_uint8 * len(a)).from_buffer(a); d.materials = C.cast(b, C.c_void_p).value; return (a, b)
+    def bad_light_material(d):
+        a = bytearray(C.string_at(d.trigLights, d.lightInfo.trigLightSize * 96)); a[0:4] = (99999).to_bytes(4, "little")
+        b = (C.c_uint8 * len(a)).from_buffer(a); d.trigLights = C.cast(b, C.c_void_p).value; return (a, b)
+    def bad_env_alias(d):
+        n = d.envWidth * d.envHeight
+        a = bytearray(C.string_at(d.envAccel, n * 16)); a[16:20] = (n + 7).to_bytes(4, "little")
+        b = (C.c_uint8 * len(a)).from_buffer(a); d.envAccel = C.cast(b, C.c_void_p).value; return (a, b)
+    assert good.lightInfo.trigLightSize > 0 and good.envAccel
+    for patch in (bad_index, bad_texture, bad_light_material, bad_env_alias):
+        corrupted(patch)
+    r.load_scene(good); r.update(64, 48)                             # the context is still usable afterwards
+    st = host.default_state(64, 48, sc, env)
+    sc.updateCamera(64, 48); r.set_camera(sc.getCamera()); r.run(st, 0); r.sync()
+
+
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
