@@ -43,7 +43,7 @@ def build_hip(force=False, verbose=False):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         objdir = os.path.join(d, "_obj")
         os.makedirs(objdir, exist_ok=True)
-        flags = [f for f in HIP_FLAGS if f != "-shared"]
+        flags = [f for f in HIP_FLAGS if f != "-shared"] + os.environ.get("RESTIR_EXTRA_HIPFLAGS", "").split()   # experiments only
         jobs = []
         for src in HIP_SRC:
             obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")

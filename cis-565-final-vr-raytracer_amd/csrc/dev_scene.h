@@ -40,7 +40,7 @@ struct DevScene {
   uint32_t numTris, numNodes;
   const struct SkyPre* sky;         // != nullptr: procedural sun & sky replaces the HDR map (_sunAndSky.in_use == 1)
   int32_t stackEntries;             // LDS traversal stack entries per lane for this tree (multiple of 4, >= max depth)
-  int32_t pad0;
+  int32_t coopLive;                 // traversal: cooperative triangle steps when at most this many rays of a wave are live (0 = off)
 };
 
 // wavefront scratch records (internal; never cross the ABI)

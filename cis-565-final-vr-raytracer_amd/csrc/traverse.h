@@ -248,27 +248,24 @@ RT_DEV void travNode(const DevScene& S, Trav& T, uint2* stack, TravCounters& tc)
   T.tgroup = make_uint2(n1.y, hitmask & 0x00FFFFFFu);
 }
 
-// Triangle step (precondition: travHasTris): test one pending triangle.
-template <int MODE>
-RT_DEV void travTri(const DevScene& S, Trav& T, TravCounters& tc)
+// One triangle candidate of a ray: intersect, range / closest-so-far test, opacity (micro-map first, texture only when the
+// micro-map cell is mixed).  The verdict depends on (ray, triangle) only — never on the order candidates are visited in.
+RT_DEV bool triCandidate(const DevScene& S, uint32_t triIndex, f3 o, f3 d, bool ANY, float tmax, float curT, uint32_t curG, uint32_t seed, float& t, float& u, float& v,
+                         uint32_t& gid)
 {
-  const bool ANY = MODE == 2 ? T.isAny : MODE == 1;
-  const uint32_t bit = 31u - uint32_t(__clz(int(T.tgroup.y)));
-  T.tgroup.y &= ~(1u << bit);
-  const uint4* tp = reinterpret_cast<const uint4*>(S.tris + (T.tgroup.x + bit));
+  const uint4* tp = reinterpret_cast<const uint4*>(S.tris + triIndex);
   const uint4 a = tp[0], b = tp[1], c = tp[2], om = tp[3];
   Tri48 R;
   R.v0x = rt_u2f(a.x); R.v0y = rt_u2f(a.y); R.v0z = rt_u2f(a.z); R.e1x = rt_u2f(a.w);
   R.e1y = rt_u2f(b.x); R.e1z = rt_u2f(b.y); R.e2x = rt_u2f(b.z); R.e2y = rt_u2f(b.w);
   R.e2z = rt_u2f(c.x); R.globalId = c.y; R.flags = c.z; R.alphaIdx = c.w;
-  tc.tris++;
-  float t, u, v;
-  if(!intersectTri(R, T.o, T.d, t, u, v)) return;
+  gid = R.globalId;
+  if(!intersectTri(R, o, d, t, u, v)) return false;
   if(ANY) {
-    if(!(t > 0.0f && t < T.tmax)) return;
+    if(!(t > 0.0f && t < tmax)) return false;
   } else {
-    if(!(t > 0.0f && t < RT_INFINITY)) return;
-    if(!(t < T.hit.t || (t == T.hit.t && R.globalId < T.hit.gid))) return;
+    if(!(t > 0.0f && t < RT_INFINITY)) return false;
+    if(!(t < curT || (t == curT && R.globalId < curG))) return false;
   }
   if(!(R.flags & TRI_OPAQUE)) {
     // opacity micro-map first: most candidates resolve without touching the texture
@@ -278,13 +275,83 @@ RT_DEV void travTri(const DevScene& S, Trav& T, TravCounters& tc)
     const uint32_t state = (word >> ((cell & 15) * 2)) & 3u;
     bool accept;
     if(state == 1u) accept = true;
-    else if(state == 2u) { uint32_t hs = T.seed ^ (R.globalId * 2654435761u); accept = !(rnd(hs) > 0.0f); }
-    else accept = hitTestAlpha(S, R.alphaIdx, R.globalId, u, v, T.seed);
-    if(!accept) return;
+    else if(state == 2u) { uint32_t hs = seed ^ (R.globalId * 2654435761u); accept = !(rnd(hs) > 0.0f); }
+    else accept = hitTestAlpha(S, R.alphaIdx, R.globalId, u, v, seed);
+    if(!accept) return false;
   }
-  T.hit.t = t; T.hit.gid = R.globalId; T.hit.u = u; T.hit.v = v;
+  return true;
+}
+
+// Triangle step (precondition: travHasTris): test one pending triangle.
+template <int MODE>
+RT_DEV void travTri(const DevScene& S, Trav& T, TravCounters& tc)
+{
+  const bool ANY = MODE == 2 ? T.isAny : MODE == 1;
+  const uint32_t bit = 31u - uint32_t(__clz(int(T.tgroup.y)));
+  T.tgroup.y &= ~(1u << bit);
+  tc.tris++;
+  float t, u, v; uint32_t gid;
+  if(!triCandidate(S, T.tgroup.x + bit, T.o, T.d, ANY, T.tmax, T.hit.t, T.hit.gid, T.seed, t, u, v, gid)) return;
+  T.hit.t = t; T.hit.gid = gid; T.hit.u = u; T.hit.v = v;
   T.found = true;
   if(ANY) { T.tgroup.y = 0u; T.ngroup.y = 0u; T.sp = 0; }  // first accepted hit terminates the query
+}
+
+RT_DEV float laneF(float v, int l) { return rt_u2f(uint32_t(__builtin_amdgcn_readlane(int(rt_f2u(v)), l))); }
+RT_DEV uint32_t laneU(uint32_t v, int l) { return uint32_t(__builtin_amdgcn_readlane(int(v), l)); }
+
+// Cooperative triangle step for the tail of a wave.  When only a few rays of a wave are still live, a round is bound by the
+// latency of one dependent load, not by issue slots, and a ray that crosses foliage holds 5-20 pending triangles per node:
+// one per round, it keeps its whole wave waiting.  Here every lane that is in the loop (live or not) takes ONE of the pending
+// triangles of ray `l` — ray and triangle list are broadcast with readlane — and the verdicts are merged with the rule the
+// sequential step applies one by one: closest = lexicographic minimum of (t, globalId); any-hit = the first accepted in list
+// order.  Verdicts do not depend on visiting order (triCandidate), so the result is the one travTri would reach.
+template <int MODE>
+RT_DEV void travTriCoop(const DevScene& S, Trav& T, unsigned long long triMask, TravCounters& tc)
+{
+  const int lane = int(threadIdx.x) & 63;
+  const unsigned long long present = __ballot(1);
+  const int rank = __popcll(present & ((1ull << lane) - 1ull)), np = __popcll(present);
+  while(triMask != 0ull) {
+    const int l = __builtin_ctzll(triMask);
+    triMask &= triMask - 1ull;
+    const f3 o = mk3(laneF(T.o.x, l), laneF(T.o.y, l), laneF(T.o.z, l)), d = mk3(laneF(T.d.x, l), laneF(T.d.y, l), laneF(T.d.z, l));
+    const uint32_t tbase = laneU(T.tgroup.x, l), seed = laneU(T.seed, l);
+    uint32_t tbits = laneU(T.tgroup.y, l);
+    const float tmax = laneF(T.tmax, l);
+    const bool ANY = MODE == 2 ? (laneU(T.isAny ? 1u : 0u, l) != 0u) : MODE == 1;
+    float bt = laneF(T.hit.t, l), bu = 0.0f, bv = 0.0f;
+    uint32_t bg = laneU(T.hit.gid, l);
+    bool found = false;
+    if(lane == l) tc.tris += uint32_t(__popc(tbits));
+    while(tbits != 0u && !(ANY && found)) {
+      int mine = -1, j = 0;
+      while(tbits != 0u && j < np) {  // the j-th pending triangle (list order: highest bit first) goes to the j-th lane present
+        const int k = 31 - __clz(int(tbits));
+        tbits &= ~(1u << k);
+        if(rank == j) mine = k;
+        j++;
+      }
+      float t = 0.0f, u = 0.0f, v = 0.0f; uint32_t gid = 0u;
+      bool ok = false;
+      if(mine >= 0) ok = triCandidate(S, tbase + uint32_t(mine), o, d, ANY, tmax, bt, bg, seed, t, u, v, gid);
+      unsigned long long okm = __ballot(ok ? 1 : 0);
+      while(okm != 0ull) {
+        const int w = __builtin_ctzll(okm);
+        okm &= okm - 1ull;
+        const float wt = laneF(t, w); const uint32_t wg = laneU(gid, w);
+        if(ANY || wt < bt || (wt == bt && wg < bg)) { bt = wt; bg = wg; bu = laneF(u, w); bv = laneF(v, w); found = true; }
+        if(ANY) break;  // list order = rank order = lane order: the lowest accepted lane is the one travTri would have stopped at
+      }
+    }
+    if(lane == l) {
+      T.tgroup.y = 0u;
+      if(found) {
+        T.hit.t = bt; T.hit.gid = bg; T.hit.u = bu; T.hit.v = bv; T.found = true;
+        if(ANY) { T.ngroup.y = 0u; T.sp = 0; }
+      }
+    }
+  }
 }
 
 // One scheduling round for a (partial) wave: every lane that is `live` votes for the kind of step it is ready for; the
@@ -309,8 +376,12 @@ RT_DEV bool travRoundMasked(const DevScene& S, Trav& T, bool live, unsigned long
 {
   tc.rounds++; tc.live += live ? 1u : 0u;
   const bool wantTri = live && travHasTris(T);
-  const int nT = __popcll(__ballot(wantTri ? 1 : 0)), nN = __popcll(liveMask) - nT;
-  if(nT >= nN) { if(wantTri) travTri<ANY>(S, T, tc); }
+  const unsigned long long triMask = __ballot(wantTri ? 1 : 0);
+  const int nLive = __popcll(liveMask), nT = __popcll(triMask), nN = nLive - nT;
+  if(nLive <= S.coopLive) {  // tail of the wave (wave-uniform): all pending triangles at once, then a node step for every live ray
+    if(nT > 0) travTriCoop<ANY>(S, T, triMask, tc);
+    if(live && travHasNodes(T)) travNode(S, T, stack, tc);
+  } else if(nT >= nN) { if(wantTri) travTri<ANY>(S, T, tc); }
   else { if(live && !wantTri) travNode(S, T, stack, tc); }
   return live && (travHasTris(T) || travHasNodes(T));
 }
