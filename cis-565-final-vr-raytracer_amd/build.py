@@ -12,8 +12,10 @@ HIP_LIB = os.path.join(_HERE, "csrc", "librestir_hip.so")
 HOST_LIB = os.path.join(_HERE, "host", "librestir_host.so")
 
 # -ffp-contract=off + correctly rounded divide/sqrt: the bit-reproducibility rules of include/rt_detmath.h
+# -fno-slp-vectorize: the SLP vectorizer forms v_pk_mul/add/fma_f32 pairs, which issue at the rate of two scalar ops on this part
+# (measured) and cost the v_mov that packs their operands: without it every kernel is 3-4 % faster (scripts/ab_flags.sh)
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-             "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-unused-result", "-x", "hip"]
+             "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize", "-Wno-unused-result", "-x", "hip"]
 HIP_SRC = ["rt_api.cpp", "bvh8_builder.cpp", "stages.hip", "wavefront.hip", "stages_sky.hip", "wavefront_sky.hip", "stages_cnt.hip", "stages_sky_cnt.hip", "post.hip"]
 HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-pthread"]
 HOST_SRC = ["scene.cpp", "scene_gen.cpp", "hdr_sampling.cpp", "gltf_loader.cpp", "jpeg_decoder.cpp", "host_capi.cpp"]

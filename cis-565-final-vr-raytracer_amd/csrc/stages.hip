@@ -640,7 +640,9 @@ __global__ __launch_bounds__(64) void k_denoise_geom(DevFrame F, rt_state st, rt
 RT_DEV float expNonPositive(float x)
 {
   const float z = rt_floor(x * 1.44269504088896341f + 0.5f);
-  const int n = rt_ftoi(z);
+  // n = rt_ftoi(z) wherever it matters: z <= 0 here, and below -127 (x < -88.4) the result is forced to 0 further down, so the
+  // conversion is clamped instead of range-checked (three branches per call otherwise); a NaN clamps to -127 and e = NaN * 0
+  const int n = int(fmaxf(z, -127.0f));
   float r = x - z * 0.693359375f;
   r = r - z * -2.12194440e-4f;
   const float rr = r * r;
@@ -664,7 +666,7 @@ RT_DEV float expNonPositive(float x)
 // q' = RN(q + r*y) is the correctly rounded quotient (Markstein 1990, Theorem 7.1: holds when y is the correctly rounded
 // reciprocal and no intermediate leaves the normal range).  launchStage enables this path only for 1e-6 <= b <= 1e6; then the
 // residual r is a normal number whenever |a/b| >= 2^-25, and below that exp(-a/b) is exactly 1 whatever the last bit of the
-// quotient.  Non-finite a takes the plain division.
+// quotient.  Above 1e30 (a * y could overflow for the smallest divisors) and for a non-finite a the plain division runs.
 template <bool FAST>
 RT_DEV float divUniform(float a, float b, float y)
 {
@@ -672,7 +674,7 @@ RT_DEV float divUniform(float a, float b, float y)
   const float q = a * y;
   const float r = __builtin_fmaf(-b, q, a);
   const float q2 = __builtin_fmaf(r, y, q);
-  return (a <= 3.0e38f) ? q2 : a / b;
+  return (a <= 1.0e30f) ? q2 : a / b;   // (kept as a branch: measured 10 % faster filters than a select of `a`)
 }
 
 __device__ constexpr float kGauss[5][5] = {{.0030f, .0133f, .0219f, .0133f, .0030f},

@@ -286,11 +286,11 @@ void orc_detmath(int op, int n, const float* a, const float* b, float* out)
       case 8: out[i] = rt_tan(a[i]); break;
       // 9: the product's division shortcut for a uniform divisor (csrc/stages.hip divUniform): q' = fma(a - b*q, y, q), y = RN(1/b).
       //    Restated here only so that tests/test_detmath.py can check it against IEEE division on the CPU.
-      case 9: { const float y = 1.0f / b[i], q = a[i] * y, r = fmaf(-b[i], q, a[i]); out[i] = fmaf(r, y, q); break; }
+      case 9: { const float y = 1.0f / b[i], q = a[i] * y, r = fmaf(-b[i], q, a[i]); out[i] = (a[i] <= 1.0e30f) ? fmaf(r, y, q) : a[i] / b[i]; break; }
       // 10: the product's branch-free exp for x <= 0 (csrc/stages.hip expNonPositive) must equal rt_exp there
       case 10: {
         const float x = a[i], z = rt_floor(x * 1.44269504088896341f + 0.5f);
-        const int n = rt_ftoi(z);
+        const int n = int(fmaxf(z, -127.0f));
         float r = x - z * 0.693359375f; r = r - z * -2.12194440e-4f;
         const float rr = r * r;
         float p = 1.9875691500E-4f; p = p * r + 1.3981999507E-3f; p = p * r + 8.3334519073E-3f; p = p * r + 4.1665795894E-2f; p = p * r + 1.6666665459E-1f;

@@ -66,6 +66,14 @@ def test_uniform_divisor_shortcut_is_ieee_division():
     a = (np.float32(0.4) * np.exp(rng.uniform(-80, np.log(2.0 ** -25), 20000))).astype(np.float32)
     q1 = det("div_uniform", a, np.full_like(a, 0.4)); q2 = a / np.float32(0.4)
     assert (det("exp", -q1) == 1.0).all() and (det("exp", -q2) == 1.0).all()
+    # above 1e30 (where a * (1/b) could overflow for the smallest divisor) and for non-finite numerators the plain division runs
+    big = np.concatenate([np.exp(rng.uniform(np.log(1e29), np.log(3.4e38), 5000)), [1e30, 1.0000001e30, 3.4028235e38, np.inf]]).astype(np.float32)
+    for b in (1e-6, 0.4, 1e6):
+        got = det("div_uniform", big, np.full_like(big, b))
+        with np.errstate(over="ignore"):
+            want = big / np.float32(b)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.isnan(det("div_uniform", [np.nan], [0.4])[0])
 
 
 def test_branch_free_exp_equals_rt_exp_on_nonpositive_arguments():
