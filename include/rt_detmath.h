@@ -47,20 +47,21 @@ RT_HD float rt_clamp(float x, float lo, float hi) { return rt_min(rt_max(x, lo),
 RT_HD float rt_sqrt(float x) { return sqrtf(x); }   /* IEEE correctly rounded on both targets */
 RT_HD float rt_floor(float x) { return floorf(x); } /* exact */
 
-/* float -> int32 with defined behaviour everywhere (C leaves NaN / out-of-range undefined; GLSL too) */
+/* float -> int32 with defined behaviour everywhere (C leaves NaN / out-of-range undefined; GLSL too):
+ * NaN -> 0, x >= 2147483520 -> 2147483520, x <= -2^31 -> INT32_MIN, else truncation toward zero.
+ * Written with clamps + one select instead of early returns: the same function, but three fewer branches per call on the GPU
+ * (rt_max(NaN, lo) = lo by its definition as a select; the last select restores the NaN case). */
 RT_HD int32_t rt_ftoi(float x)
 {
-  if(rt_isnan(x)) return 0;
-  if(x >= 2147483520.0f) return 2147483520;
-  if(x <= -2147483648.0f) return (int32_t)(-2147483647 - 1);
-  return (int32_t)x; /* truncation toward zero */
+  const float c = rt_min(rt_max(x, -2147483648.0f), 2147483520.0f);
+  const int32_t r = (int32_t)c; /* in range: truncation toward zero */
+  return rt_isnan(x) ? 0 : r;
 }
-/* float -> uint32 (GLSL uint(x)) */
+/* float -> uint32 (GLSL uint(x)): NaN or x <= 0 -> 0, x >= 4294967040 -> 4294967040, else truncation */
 RT_HD uint32_t rt_ftou(float x)
 {
-  if(rt_isnan(x) || x <= 0.0f) return 0u;
-  if(x >= 4294967040.0f) return 4294967040u;
-  return (uint32_t)x;
+  const float c = rt_min(rt_max(x, 0.0f), 4294967040.0f); /* rt_max(NaN, 0) = 0 */
+  return (uint32_t)c;
 }
 
 /* 2^n for n in [-126, 127] */

@@ -297,6 +297,9 @@ void orc_detmath(int op, int n, const float* a, const float* b, float* out)
         p = p * r + 5.0000001201E-1f; p = p * rr + r; p = p + 1.0f;
         float e = p * rt_u2f(uint32_t(n + 127) << 23);
         out[i] = (x < -87.33654475055310f) ? 0.0f : e; break; }
+      // 11 / 12: rt_ftoi / rt_ftou as floats (every value they return is exactly representable)
+      case 11: out[i] = float(rt_ftoi(a[i])); break;
+      case 12: out[i] = float(rt_ftou(a[i])); break;
       default: out[i] = 0;
     }
   }

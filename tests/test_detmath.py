@@ -3,7 +3,7 @@ import ctypes as C
 import numpy as np
 from oracle.binding import lib
 
-OPS = {"exp": 0, "log": 1, "pow": 2, "sin": 3, "cos": 4, "asin": 5, "acos": 6, "atan2": 7, "tan": 8, "div_uniform": 9, "exp_nonpos": 10}
+OPS = {"exp": 0, "log": 1, "pow": 2, "sin": 3, "cos": 4, "asin": 5, "acos": 6, "atan2": 7, "tan": 8, "div_uniform": 9, "exp_nonpos": 10, "ftoi": 11, "ftou": 12}
 
 
 def det(op, a, b=None):
@@ -86,3 +86,19 @@ def test_branch_free_exp_equals_rt_exp_on_nonpositive_arguments():
 def test_tan_is_sin_over_cos():
     x = np.linspace(-1.5, 1.5, 100001, dtype=np.float32)
     assert ulp_err(det("tan", x), np.tan(x.astype(np.float64))).max() <= 8.0
+
+
+def test_float_to_int_conversions_follow_their_specification():
+    """rt_ftoi / rt_ftou (include/rt_detmath.h) are written with clamps + a select (no branches on the GPU); they must be the
+    function the contract states: NaN -> 0; saturation at 2147483520 / INT32_MIN resp. 0 / 4294967040; truncation otherwise.
+    (The header's implementation was also compared with the early-return form over all 2^32 bit patterns when it was written.)"""
+    rng = np.random.default_rng(9)
+    bits = np.concatenate([rng.integers(0, 2 ** 32, 4_000_000, dtype=np.uint64).astype(np.uint32),
+                           np.array([0, 0x80000000, 0x7f800000, 0xff800000, 0x7fc00000, 0xffc00000, 0x7f800001, 0xff800001, 0x4effffff, 0x4f000000, 0xcf000000, 0xcf000001,
+                                     0x4f7fffff, 0x4f800000, 0x3f7fffff, 0xbf7fffff, 0x3f800000, 0xbf800000], dtype=np.uint32)])
+    x = bits.view(np.float32)
+    with np.errstate(invalid="ignore"):
+        xi = np.where(np.isnan(x), 0.0, np.clip(np.trunc(x.astype(np.float64)), -2147483648.0, 2147483520.0))
+        xu = np.where(np.isnan(x), 0.0, np.clip(np.trunc(x.astype(np.float64)), 0.0, 4294967040.0))
+    assert np.array_equal(det("ftoi", x).astype(np.float64), xi)
+    assert np.array_equal(det("ftou", x).astype(np.float64), xu)
