@@ -210,6 +210,7 @@ def main():
         # HBM traffic of the same kernel from the PMC passes (scripts/pmc.sh: separate rocprofv3 --pmc runs of this command;
         # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950's FETCH_SIZE counts wide reads at half their size — MI355X_MICROARCH.md,
         # HBM section — so it is doubled; WRITE_SIZE is taken as reported).  The file is refreshed with the profiles.
+        t = None
         try:
             with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as fh:
                 t = json.load(fh).get({0: "k_direct_stage", 1: "k_indirect_stage", 2: "k_denoise", 3: "k_denoise", 4: "k_compose"}[dom])
@@ -224,6 +225,17 @@ def main():
                                          "frac": round((b_screen + b_trav) / (sdur * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                                          "stage_ms_per_frame": {STAGE_NAMES[i]: round(serial_ms[i], 4) for i in range(5)},
                                          "frame_ms": round(sum(serial_ms), 4)}
+            # What actually bounds the kernel: VALU issue.  Wave-level VALU instructions per launch from the same PMC
+            # passes (SQ_INSTS_VALU; a wave64 instruction occupies its SIMD16 for 4 cycles) against 1024 SIMDs x 2.4 GHz, and the
+            # fraction of lanes active in those instructions (SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU)).
+            try:
+                if t and t.get("INSTS_VALU"):
+                    issue_ms = t["INSTS_VALU"] * 4.0 / (1024 * 2.4e9) * 1e3
+                    out["roofline"]["valu"] = {"wave_insts_per_launch": round(t["INSTS_VALU"]), "issue_ms_at_peak": round(issue_ms, 4),
+                                               "issue_frac_serial": round(issue_ms / sdur, 4), "lane_utilisation": round(t["THREAD_CYCLES_VALU"] / (64.0 * t["INSTS_VALU"]), 4),
+                                               "source": "profiles/pmc_traffic.json (SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU per launch)"}
+            except (NameError, KeyError, ZeroDivisionError):
+                pass
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(abi, host, scene, env, st, desc, W, H, args.cpu_rows, first_timed)
     if rank == 0:

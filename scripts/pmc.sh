@@ -29,8 +29,10 @@ with open(out + "/summary.txt", "w") as fo:
             fo.write("   %-28s %16.1f per launch (%d launches)\n" % (c, v / calls[(k, c)], calls[(k, c)]))
 import json
 traffic = {k.replace("void ", "").split("<")[0].split("::")[-1]: {"FETCH_SIZE_KB": d.get("FETCH_SIZE", 0) / max(1, calls[(k, "FETCH_SIZE")]),
-                                                              "WRITE_SIZE_KB": d.get("WRITE_SIZE", 0) / max(1, calls[(k, "WRITE_SIZE")])}
-           for k, d in agg.items() if k.startswith(("rt::", "void rt::"))}
+                                                              "WRITE_SIZE_KB": d.get("WRITE_SIZE", 0) / max(1, calls[(k, "WRITE_SIZE")]),
+                                                              "INSTS_VALU": d.get("SQ_INSTS_VALU", 0) / max(1, calls[(k, "SQ_INSTS_VALU")]),
+                                                              "THREAD_CYCLES_VALU": d.get("SQ_THREAD_CYCLES_VALU", 0) / max(1, calls[(k, "SQ_THREAD_CYCLES_VALU")])}
+           for k, d in agg.items() if k.startswith(("rt::", "void rt::")) and "_cnt::" not in k}   # not the instrumented (counting) variants
 json.dump(traffic, open(out + "/pmc_traffic.json", "w"), indent=1)
 print(open(out + "/summary.txt").read())
 PY
