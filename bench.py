@@ -234,7 +234,13 @@ def main():
                     out["roofline"]["valu"] = {"wave_insts_per_launch": round(t["INSTS_VALU"]), "issue_ms_at_peak": round(issue_ms, 4),
                                                "issue_frac_serial": round(issue_ms / sdur, 4), "lane_utilisation": round(t["THREAD_CYCLES_VALU"] / (64.0 * t["INSTS_VALU"]), 4),
                                                "source": "profiles/pmc_traffic.json (SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU per launch)"}
-            except (NameError, KeyError, ZeroDivisionError):
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as fh:
+                    fr = json.load(fh).get("_frame")
+                if fr and "valu" in out["roofline"] and world == 1 and args.emulate_world <= 1:
+                    f_ms = fr["INSTS_VALU"] * 4.0 / (1024 * 2.4e9) * 1e3   # every kernel of one frame
+                    out["roofline"]["valu"].update({"frame_wave_insts": round(fr["INSTS_VALU"]), "frame_issue_ms_at_peak": round(f_ms, 4),
+                                                    "frame_issue_frac": round(f_ms / out["ms_per_step"], 4)})
+            except (NameError, KeyError, ZeroDivisionError, OSError, ValueError):
                 pass
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(abi, host, scene, env, st, desc, W, H, args.cpu_rows, first_timed)

@@ -33,6 +33,9 @@ traffic = {k.replace("void ", "").split("<")[0].split("::")[-1]: {"FETCH_SIZE_KB
                                                               "INSTS_VALU": d.get("SQ_INSTS_VALU", 0) / max(1, calls[(k, "SQ_INSTS_VALU")]),
                                                               "THREAD_CYCLES_VALU": d.get("SQ_THREAD_CYCLES_VALU", 0) / max(1, calls[(k, "SQ_THREAD_CYCLES_VALU")])}
            for k, d in agg.items() if k.startswith(("rt::", "void rt::")) and "_cnt::" not in k}   # not the instrumented (counting) variants
+frames = max(1, calls[("rt::base::k_direct_stage", "SQ_INSTS_VALU")])
+traffic["_frame"] = {"INSTS_VALU": sum(d.get("SQ_INSTS_VALU", 0) for k, d in agg.items() if k.startswith(("rt::base::", "void rt::base::"))) / frames,
+                     "note": "sum over the kernels of one frame (count-free variants), SQ_INSTS_VALU per launch x launches per frame"}
 json.dump(traffic, open(out + "/pmc_traffic.json", "w"), indent=1)
 print(open(out + "/summary.txt").read())
 PY
