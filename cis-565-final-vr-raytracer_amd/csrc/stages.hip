@@ -639,20 +639,20 @@ __global__ __launch_bounds__(64) void k_denoise_geom(DevFrame F, rt_state st, rt
 // x > 88.7 early-out of rt_exp cannot trigger) but with selects instead of branches.
 RT_DEV float expNonPositive(float x)
 {
-  const float z = rt_floor(x * 1.44269504088896341f + 0.5f);
-  // n = rt_ftoi(z) wherever it matters: z <= 0 here, and below -127 (x < -88.4) the result is forced to 0 further down, so the
-  // conversion is clamped instead of range-checked (three branches per call otherwise); a NaN clamps to -127 and e = NaN * 0
+  const float z = rt_floor(rt_fma(x, 1.44269504088896341f, 0.5f));
+  // n = (int)z wherever it matters: z <= 0 here, and below -127 (x < -88.4) the result is forced to 0 further down, so the
+  // conversion is clamped instead of range-checked; a NaN clamps to -127 and e = NaN * 0
   const int n = int(fmaxf(z, -127.0f));
-  float r = x - z * 0.693359375f;
-  r = r - z * -2.12194440e-4f;
+  float r = rt_fma(z, -0.693359375f, x);
+  r = rt_fma(z, 2.12194440e-4f, r);
   const float rr = r * r;
   float p = 1.9875691500E-4f;
-  p = p * r + 1.3981999507E-3f;
-  p = p * r + 8.3334519073E-3f;
-  p = p * r + 4.1665795894E-2f;
-  p = p * r + 1.6666665459E-1f;
-  p = p * r + 5.0000001201E-1f;
-  p = p * rr + r;
+  p = rt_fma(p, r, 1.3981999507E-3f);
+  p = rt_fma(p, r, 8.3334519073E-3f);
+  p = rt_fma(p, r, 4.1665795894E-2f);
+  p = rt_fma(p, r, 1.6666665459E-1f);
+  p = rt_fma(p, r, 5.0000001201E-1f);
+  p = rt_fma(p, rr, r);
   p = p + 1.0f;
   // rt_exp scales in two steps, (p * 2^a) * 2^b with a + b = n, so that results below the normal range round once; for
   // x >= -87.34 n >= -126, 2^n is a normal number and p * 2^n is the same single rounding.  Below that the result is 0.

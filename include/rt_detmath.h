@@ -67,23 +67,35 @@ RT_HD uint32_t rt_ftou(float x)
 /* 2^n for n in [-126, 127] */
 RT_HD float rt_pow2i(int n) { return rt_u2f((uint32_t)(n + 127) << 23); }
 
+/* a*b + c with ONE rounding (IEEE fusedMultiplyAdd) on both targets: v_fma_f32 on the GPU, fmaf() — a hardware FMA when the host
+ * code is built with -mfma, glibc's exact software fma otherwise — on the CPU.  The compilers never form it on their own
+ * (-ffp-contract=off); where the contract wants a fused step it says so with rt_fma. */
+#if defined(__HIP_DEVICE_COMPILE__)
+RT_HD float rt_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+#else
+RT_HD float rt_fma(float a, float b, float c) { return fmaf(a, b, c); }
+#endif
+
+/* exp: Cody-Waite reduction by ln2 in two pieces, degree-5 polynomial (Cephes expf coefficients), every multiply-add step fused
+ * (rt_fma): one instruction per step on the GPU, where exp is the hot function of the A-Trous filters (75 calls per pixel and
+ * level), and one rounding instead of two per step. */
 RT_HD float rt_exp(float x)
 {
   if(rt_isnan(x)) return x;
   if(x > 88.72283905206835f) return rt_u2f(0x7f800000u);
   if(x < -87.33654475055310f) return 0.0f;
-  float z = rt_floor(x * 1.44269504088896341f + 0.5f);
+  float z = rt_floor(rt_fma(x, 1.44269504088896341f, 0.5f));
   int   n = (int)z;
-  x = x - z * 0.693359375f;
-  x = x - z * -2.12194440e-4f;
+  x = rt_fma(z, -0.693359375f, x);
+  x = rt_fma(z, 2.12194440e-4f, x);
   float zz = x * x;
   float p = 1.9875691500E-4f;
-  p = p * x + 1.3981999507E-3f;
-  p = p * x + 8.3334519073E-3f;
-  p = p * x + 4.1665795894E-2f;
-  p = p * x + 1.6666665459E-1f;
-  p = p * x + 5.0000001201E-1f;
-  p = p * zz + x;
+  p = rt_fma(p, x, 1.3981999507E-3f);
+  p = rt_fma(p, x, 8.3334519073E-3f);
+  p = rt_fma(p, x, 4.1665795894E-2f);
+  p = rt_fma(p, x, 1.6666665459E-1f);
+  p = rt_fma(p, x, 5.0000001201E-1f);
+  p = rt_fma(p, zz, x);
   p = p + 1.0f;
   int a = n >> 1;
   int b = n - a;

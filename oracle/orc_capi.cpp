@@ -289,12 +289,12 @@ void orc_detmath(int op, int n, const float* a, const float* b, float* out)
       case 9: { const float y = 1.0f / b[i], q = a[i] * y, r = fmaf(-b[i], q, a[i]); out[i] = (a[i] <= 1.0e30f) ? fmaf(r, y, q) : a[i] / b[i]; break; }
       // 10: the product's branch-free exp for x <= 0 (csrc/stages.hip expNonPositive) must equal rt_exp there
       case 10: {
-        const float x = a[i], z = rt_floor(x * 1.44269504088896341f + 0.5f);
+        const float x = a[i], z = rt_floor(rt_fma(x, 1.44269504088896341f, 0.5f));
         const int n = int(fmaxf(z, -127.0f));
-        float r = x - z * 0.693359375f; r = r - z * -2.12194440e-4f;
+        float r = rt_fma(z, -0.693359375f, x); r = rt_fma(z, 2.12194440e-4f, r);
         const float rr = r * r;
-        float p = 1.9875691500E-4f; p = p * r + 1.3981999507E-3f; p = p * r + 8.3334519073E-3f; p = p * r + 4.1665795894E-2f; p = p * r + 1.6666665459E-1f;
-        p = p * r + 5.0000001201E-1f; p = p * rr + r; p = p + 1.0f;
+        float p = 1.9875691500E-4f; p = rt_fma(p, r, 1.3981999507E-3f); p = rt_fma(p, r, 8.3334519073E-3f); p = rt_fma(p, r, 4.1665795894E-2f);
+        p = rt_fma(p, r, 1.6666665459E-1f); p = rt_fma(p, r, 5.0000001201E-1f); p = rt_fma(p, rr, r); p = p + 1.0f;
         float e = p * rt_u2f(uint32_t(n + 127) << 23);
         out[i] = (x < -87.33654475055310f) ? 0.0f : e; break; }
       // 11 / 12: rt_ftoi / rt_ftou as floats (every value they return is exactly representable)
