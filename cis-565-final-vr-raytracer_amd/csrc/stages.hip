@@ -466,10 +466,11 @@ __global__ __launch_bounds__(64, 4) void k_indirect_stage(DevScene S, DevFrame F
     if(sbK > 0 && L >= genericBlocks) {  // single-bounce tiles of this XCD, sbK per wave (from the back of its list)
       const int w = (L - genericBlocks) >> 3, first = w * sbK;
       if(first >= nb) return;
-      uint32_t t[2] = {0u, 0u};
+      uint32_t t[3] = {0u, 0u, 0u};
       const int n = min(sbK, nb - first);
       for(int k = 0; k < n; k++) t[k] = lists[size_t(xcd) * cap + (cap - 1 - (first + k))];
-      indirectSingleBounceTiles<2>(S, F, st, cam, rowBegin, rowEnd, tilesX, t, n, s_stack);  // (4 per wave was measured: slower, spills)
+      if(sbK == 3) indirectSingleBounceTiles<3>(S, F, st, cam, rowBegin, rowEnd, tilesX, t, n, s_stack);
+      else indirectSingleBounceTiles<2>(S, F, st, cam, rowBegin, rowEnd, tilesX, t, n, s_stack);  // (4 per wave was measured: slower, spills)
       return;
     }
     const int k = (L >> 3) >> subShift;
@@ -821,7 +822,7 @@ hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F,
       // throughput-bound launches: single-bounce tiles go K per wave (indirectSingleBounceTiles); latency-bound ones keep one
       // (part of a) tile per wave
       static const int sbEnv = getenv("RESTIR_IND_SBK") ? atoi(getenv("RESTIR_IND_SBK")) : -1;
-      const int sbK = sbEnv >= 0 ? std::min(sbEnv, 2) : (subShift > 0 ? 0 : 2);
+      const int sbK = sbEnv >= 0 ? std::min(sbEnv, 3) : (subShift > 0 ? 0 : 3);   // 3 per wave: fewer wave instructions than 2 (frames in flight: -1.3 %), longer stage alone (+4 %)
       const unsigned genericBlocks = grid.x << subShift;
       const unsigned sbBlocks = sbK > 0 ? 8u * unsigned((cap + sbK - 1) / sbK) : 0u;
       const size_t poolBytes = std::max<size_t>(POOL_BYTES, size_t(sbK) * 64 * 33);
