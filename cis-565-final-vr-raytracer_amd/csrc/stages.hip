@@ -39,7 +39,10 @@ namespace RT_VARIANT {
 // ------------------------------------------------------------------------------------------------------------
 // direct_stage.comp
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64, 5) void k_direct_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY)
+#ifndef RT_DIRECT_LB
+#define RT_DIRECT_LB 5
+#endif
+__global__ __launch_bounds__(64, RT_DIRECT_LB) void k_direct_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY)
 {
   extern __shared__ uint2 s_stack[];
   const TileCoord tile = tileOf(tilesX, tilesY);
@@ -450,7 +453,12 @@ RT_DEV void indirectSingleBounceTiles(const DevScene& S, const DevFrame& F, cons
   flushCounters(F, c);
 }
 
-__global__ __launch_bounds__(64, 4) void k_indirect_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY, int cap,
+// 5 waves/SIMD (96 VGPRs, a few more spills) instead of 4: the stage alone is no faster, but with frames in flight its waves
+// share the SIMDs with the next frame's direct stage and the frame is 2.7 % shorter (3, 4, 6 measured: 3.96 / 3.47 / 3.42 vs 3.37 ms)
+#ifndef RT_INDIRECT_LB
+#define RT_INDIRECT_LB 5
+#endif
+__global__ __launch_bounds__(64, RT_INDIRECT_LB) void k_indirect_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY, int cap,
                                                           const uint32_t* lists, const uint32_t* counts, int subShift, int sbK, int genericBlocks)
 {
   // subShift > 0 (small launches: row bands of a multi-GPU frame, small images): a tile is split over 2 or 4 waves that own
