@@ -53,6 +53,7 @@ struct rt_ctx {
   DevFrame scratch{};
   int histRow0 = 0, histRow1 = 1 << 30;  // rt_set_history_rows
   int pipeline = 0;  // 0 = one fused kernel per reference stage (default, fastest measured), 1 = wavefront
+  hipEvent_t evWf = nullptr; bool wfChained = false;   // wavefront stages issued through rt_run_stage are chained (shared queues)
   bool counting = false;
   unsigned long long* dCounters = nullptr;
   // timing: per frame one event set; event 0 = frame start, event k = end of launch k.  Sets are harvested lazily.
@@ -239,6 +240,7 @@ int rt_create(rt_ctx** out, int device)
     (void)hipEventCreateWithFlags(&c->evI[i], hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->evDone[i], hipEventDisableTiming);
   }
+  (void)hipEventCreateWithFlags(&c->evWf, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming);
   if(const char* e = getenv("RESTIR_OVERLAP")) c->overlap = atoi(e);
@@ -266,6 +268,7 @@ int rt_destroy(rt_ctx* c)
   for(auto& E : c->evSets) for(int i = 0; i < rt_ctx::MAX_EV; i++) (void)hipEventDestroy(E.ev[i]);
   if(c->ownStream) (void)hipStreamDestroy(c->ownStream);
   if(c->sideStream) (void)hipStreamDestroy(c->sideStream);
+  if(c->evWf) (void)hipEventDestroy(c->evWf);
   if(c->evFork) (void)hipEventDestroy(c->evFork);
   if(c->evJoin) (void)hipEventDestroy(c->evJoin);
   delete c;
@@ -548,7 +551,12 @@ int rt_run_stage(rt_ctx* c, const rt_state* st, int frames, int stage, int level
   RT_HIP(c, joinInFlight(c));
   DevFrame F = makeFrame(c, frames);
   if(stage == RT_STAGE_INDIRECT) F.histMiss = c->scratch.qcount + 251;  // per-stage-kind flag (rt_history_miss_stage)
+  // The wavefront organisation keeps its ray queues in ONE set of scratch buffers: two of its stages must never overlap.  A
+  // caller that spreads stages over several streams (tiled.PipelinedTiledFrame) is serialised here with an event chain; the
+  // fused kernels (default) have no shared scratch between stage kinds and run concurrently.
+  if(c->pipeline == 1 && c->wfChained) RT_HIP(c, hipStreamWaitEvent(c->stream, c->evWf, 0));
   RT_HIP(c, stageLauncher(c)(c->stream, c->ds, F, *st, c->cam, stage, level, rowBegin, rowEnd));
+  if(c->pipeline == 1) { RT_HIP(c, hipEventRecord(c->evWf, c->stream)); c->wfChained = true; }
   return RT_OK;
 }
 
