@@ -68,5 +68,24 @@ def test_random_configurations_bit_exact():
     assert run_sweep(int(os.environ.get("RESTIR_FUZZ_CASES", "24")), int(os.environ.get("RESTIR_FUZZ_SEED", "1"))) == 0
 
 
+KNOBS = ["RESTIR_IND_SUB=0 RESTIR_IND_SBK=3", "RESTIR_IND_SUB=0 RESTIR_IND_SBK=2", "RESTIR_IND_SUB=1 RESTIR_IND_SBK=0",
+         "RESTIR_IND_SUB=0 RESTIR_IND_SBK=0 RESTIR_COOP=64", "RESTIR_OVERLAP=0 RESTIR_COOP=0", "RESTIR_PIPELINE=wavefront RESTIR_OVERLAP=1"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("knobs", KNOBS)
+def test_launch_shape_knobs_do_not_change_the_bits(knobs):
+    """The tuning switches of DESIGN.md §12 only change how the work is laid out over waves and streams (tiles per wave, waves per
+    tile, cooperative-tail threshold, stream overlap, kernel organisation).  Small images pick the small-launch shapes on their own,
+    so the shapes of a full-size frame are forced here; the library reads some switches once per process, hence a subprocess."""
+    import subprocess
+    env = dict(os.environ)
+    env.update(dict(kv.split("=") for kv in knobs.split()))
+    cases = os.environ.get("RESTIR_FUZZ_KNOB_CASES", "10")
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), cases, "313"], env=env, cwd=os.path.dirname(os.path.abspath(__file__)),
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and f"cases {cases} mismatching 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 if __name__ == "__main__":
     sys.exit(1 if run_sweep(int(sys.argv[1]) if len(sys.argv) > 1 else 30, int(sys.argv[2]) if len(sys.argv) > 2 else 1) else 0)
