@@ -99,7 +99,7 @@ RT_DEV uint32_t packUnorm4x8(f4 v)
 }
 RT_DEV f4 unpackUnorm4x8(uint32_t p)
 {
-  return mk4(float(p & 0xffu) / 255.0f, float((p >> 8) & 0xffu) / 255.0f, float((p >> 16) & 0xffu) / 255.0f, float(p >> 24) / 255.0f);
+  return mk4(unorm8ToFloat(p & 0xffu), unorm8ToFloat((p >> 8) & 0xffu), unorm8ToFloat((p >> 16) & 0xffu), unorm8ToFloat(p >> 24));
 }
 RT_DEV uint32_t compress_unit_vec(f3 nv)  // :111-139
 {

@@ -47,7 +47,7 @@ RT_DEV int wrapCoord(int i, int n, int mode)
 RT_DEV f4 texelBGRA(const DevTexture& t, int x, int y)
 {
   uint32_t p = *reinterpret_cast<const uint32_t*>(t.bgra + (size_t(y) * t.w + x) * 4);
-  return mk4(float((p >> 16) & 0xffu) / 255.0f, float((p >> 8) & 0xffu) / 255.0f, float(p & 0xffu) / 255.0f, float(p >> 24) / 255.0f);
+  return mk4(unorm8ToFloat((p >> 16) & 0xffu), unorm8ToFloat((p >> 8) & 0xffu), unorm8ToFloat(p & 0xffu), unorm8ToFloat(p >> 24));
 }
 RT_DEV f4 sampleTexture(const DevScene& S, int id, f2 uv)
 {
@@ -104,7 +104,7 @@ RT_DEV float rnd(uint32_t& seed)  // rand(), random.glsl:98-102
 // order.  Only the alpha channel of the bilinear fetch is evaluated (same arithmetic).
 RT_DEV float texelAlpha(const uint8_t* bgra, int w, int x, int y)
 {
-  return float(bgra[(size_t(y) * w + x) * 4 + 3]) / 255.0f;
+  return unorm8ToFloat(bgra[(size_t(y) * w + x) * 4 + 3]);
 }
 RT_DEV bool hitTestAlpha(const DevScene& S, uint32_t alphaIdx, uint32_t gid, float u, float v, uint32_t raySeed)
 {

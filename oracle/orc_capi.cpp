@@ -300,6 +300,8 @@ void orc_detmath(int op, int n, const float* a, const float* b, float* out)
       // 11 / 12: rt_ftoi / rt_ftou as floats (every value they return is exactly representable)
       case 11: out[i] = float(rt_ftoi(a[i])); break;
       case 12: out[i] = float(rt_ftou(a[i])); break;
+      // 13: the product's b / 255 for 8-bit texel and G-buffer channels (csrc/dev_math.h unorm8ToFloat), restated for the CPU test
+      case 13: { const float y = 1.0f / 255.0f, q = a[i] * y; out[i] = fmaf(fmaf(-255.0f, q, a[i]), y, q); break; }
       default: out[i] = 0;
     }
   }

@@ -3,7 +3,7 @@ import ctypes as C
 import numpy as np
 from oracle.binding import lib
 
-OPS = {"exp": 0, "log": 1, "pow": 2, "sin": 3, "cos": 4, "asin": 5, "acos": 6, "atan2": 7, "tan": 8, "div_uniform": 9, "exp_nonpos": 10, "ftoi": 11, "ftou": 12}
+OPS = {"exp": 0, "log": 1, "pow": 2, "sin": 3, "cos": 4, "asin": 5, "acos": 6, "atan2": 7, "tan": 8, "div_uniform": 9, "exp_nonpos": 10, "ftoi": 11, "ftou": 12, "unorm8": 13}
 
 
 def det(op, a, b=None):
@@ -102,3 +102,10 @@ def test_float_to_int_conversions_follow_their_specification():
         xu = np.where(np.isnan(x), 0.0, np.clip(np.trunc(x.astype(np.float64)), 0.0, 4294967040.0))
     assert np.array_equal(det("ftoi", x).astype(np.float64), xi)
     assert np.array_equal(det("ftou", x).astype(np.float64), xu)
+
+
+def test_unorm8_shortcut_is_the_division_by_255():
+    """csrc/dev_math.h unorm8ToFloat (texel and G-buffer channel decode): 3 fused steps instead of an IEEE division, equal to
+    b / 255.0f for all 256 inputs."""
+    b = np.arange(256, dtype=np.float32)
+    assert np.array_equal(det("unorm8", b).view(np.uint32), (b / np.float32(255.0)).view(np.uint32))
