@@ -41,6 +41,8 @@ struct DevScene {
   const struct SkyPre* sky;         // != nullptr: procedural sun & sky replaces the HDR map (_sunAndSky.in_use == 1)
   int32_t stackEntries;             // LDS traversal stack entries per lane for this tree (multiple of 4, >= max depth)
   int32_t coopLive;                 // traversal: cooperative triangle steps when at most this many rays of a wave are live (0 = off)
+  float triPad;                     // box padding of the build (2e-5 x largest |coordinate|): an accepted hit point lies inside its triangle's padded box
+  int32_t pad2;
 };
 
 // wavefront scratch records (internal; never cross the ABI)

@@ -442,6 +442,7 @@ int rt_build_accel(rt_ctx* c)
   if((rc = upload(c, c->accelAllocs, bo.instances.data(), bo.instances.size(), &c->ds.instances))) return rc;
   c->ds.numNodes = uint32_t(bo.nodes.size()); c->ds.numTris = uint32_t(bo.tris.size());
   c->ds.stackEntries = std::max(8, ((bo.maxDepth + 1 + 3) / 4) * 4);
+  c->ds.triPad = bo.pad;
   { const char* e = getenv("RESTIR_COOP"); c->ds.coopLive = e ? std::max(0, std::min(64, atoi(e))) : 4; }
   c->numNodes = bo.nodes.size(); c->numTris = bo.tris.size(); c->maxDepth = bo.maxDepth;
   RT_HIP(c, hipDeviceSynchronize());

@@ -72,6 +72,7 @@ void Scene::build()
   for(const Tri& T : tris)
     for(const vec3* v : {&T.v0, &T.v1, &T.v2}) scale = std::max(scale, std::max(std::fabs(v->x), std::max(std::fabs(v->y), std::fabs(v->z))));
   const float pad = 2e-5f * scale;  // makes box culling strictly weaker than the triangle test (DESIGN.md §Traversal soundness)
+  triPad = pad;
 
   std::vector<uint32_t> order(n);
   std::iota(order.begin(), order.end(), 0u);
@@ -144,7 +145,14 @@ bool Scene::intersectTri(const Tri& T, vec3 o, vec3 d, float& t, float& u, float
   v = dot(d, q) * inv;
   if(!(v >= 0.0f && u + v <= 1.0f)) return false;
   t = dot(e2, q) * inv;
-  return !rt_isnan(t);
+  if(rt_isnan(t)) return false;
+  // an accepted hit point lies inside the triangle's box widened by the build's padding (csrc/traverse.h intersectTri: a sliver's
+  // quotients are rounding noise; without this the result would depend on which triangles share a leaf with it)
+  const vec3 h = o + d * t, w1 = T.v0 + e1, w2 = T.v0 + e2;
+  const float pad = triPad;
+  const vec3 lo = V3(rt_min(rt_min(T.v0.x, w1.x), w2.x) - pad, rt_min(rt_min(T.v0.y, w1.y), w2.y) - pad, rt_min(rt_min(T.v0.z, w1.z), w2.z) - pad);
+  const vec3 hi = V3(rt_max(rt_max(T.v0.x, w1.x), w2.x) + pad, rt_max(rt_max(T.v0.y, w1.y), w2.y) + pad, rt_max(rt_max(T.v0.z, w1.z), w2.z) + pad);
+  return h.x >= lo.x && h.x <= hi.x && h.y >= lo.y && h.y <= hi.y && h.z >= lo.z && h.z <= hi.z;
 }
 
 static inline uint32_t pcgStep(uint32_t& state)  // random.glsl:59-65

@@ -66,7 +66,8 @@ struct Scene {
   std::vector<float> env;  // rgba32f
   std::vector<rt_impt_samp> envAccel;
 
-  std::vector<Tri> tris;          // flattened, index = (instance order, primitive order)
+  std::vector<Tri> tris;
+  float triPad = 0.0f;   // box padding of the build; also bounds where an accepted hit may lie (intersectTri)          // flattened, index = (instance order, primitive order)
   std::vector<uint32_t> leafTris_; // BVH leaf order -> index into tris
   std::vector<BvhNode> nodes;
   mutable Counters counters;

@@ -6,6 +6,7 @@
 // GLSL leaves the value of uninitialised variables / `out` parameters undefined; the oracle defines them as 0
 // (DESIGN.md §Deviations #3).  Transcendentals come from include/rt_detmath.h.
 #pragma once
+#include <cstdio>
 #include <cmath>
 #include "orc_scene.h"
 #include "orc_sky.h"
@@ -305,6 +306,7 @@ struct Shader {
   uint32_t hitTri = 0xffffffffu;
   float hitU = 0, hitV = 0;
   uint32_t lastLightId = 0xffffffffu;  // oracle-side bookkeeping for RT_BUF_LIGHT_ID
+  bool dbgPrint = false;
 
   Shader(const Scene& s, const rt_state& r, const rt_scene_camera& c) : S(s), rtx(r), cam(c) {}
 
@@ -567,6 +569,11 @@ struct Shader {
     float pdf = SampleDirectLightNoVisibility(state.position, ls);
     if(IsPdfInvalid(pdf)) return InvalidPdf;
     Ray shadowRay{OffsetRay(state.position, state.ffnormal), toV(ls.wi)};
+    if(dbgPrint) {
+      const float md = ((ls.dist - rt_abs(shadowRay.origin.x - state.position.x)) - rt_abs(shadowRay.origin.y - state.position.y)) - rt_abs(shadowRay.origin.z - state.position.z);
+      fprintf(stderr, "ORC   shadow o %08x %08x %08x d %08x %08x %08x dist %08x tmax %08x pdf %08x seed %08x\n", rt_f2u(shadowRay.origin.x), rt_f2u(shadowRay.origin.y), rt_f2u(shadowRay.origin.z),
+              rt_f2u(shadowRay.direction.x), rt_f2u(shadowRay.direction.y), rt_f2u(shadowRay.direction.z), rt_f2u(ls.dist), rt_f2u(md), rt_f2u(pdf), seed);
+    }
     if(Occlusion(shadowRay, state, ls.dist)) return InvalidPdf;
     radiance = toV(ls.Li);
     dir = toV(ls.wi);

@@ -17,6 +17,8 @@
 // reference's own source files (oracle/kat/mint_kat.sh; tests/test_kat.py, tests/test_kat_float.py); the stage-level
 // control flow in this file is a line-by-line restatement checked by property tests.
 #include "orc_stages.h"
+#include <cstdio>
+#include <cstdlib>
 #include <thread>
 
 namespace orc {
@@ -446,13 +448,19 @@ static void pathTraceIndirect(Shader& sh, State state, Ray ray, bool multiBounce
   gi = newGISample();
   primSamplePdf = 0.0f;
   state.mat.albedo = V3(1.0f);
-  auto addL = [&](vec3 v) { gi.L = toR(toV(gi.L) + v); };
+  static const char* dbgEnv = getenv("ORC_DEBUG_PIXEL");
+  int dx = -1, dy = -1; if(dbgEnv) sscanf(dbgEnv, "%d,%d", &dx, &dy);
+  const bool dbg = sh.imageCoords.x == dx && sh.imageCoords.y == dy;
+  auto addL = [&](vec3 v) { gi.L = toR(toV(gi.L) + v); if(dbg) fprintf(stderr, "ORC   addL %08x %08x %08x -> L %g %g %g\n", rt_f2u(v.x), rt_f2u(v.y), rt_f2u(v.z), gi.L.x, gi.L.y, gi.L.z); };
+  sh.dbgPrint = dbg;
+  if(dbg) fprintf(stderr, "ORC pixel %d %d multiBounce %d seed %08x\n", dx, dy, int(multiBounce), sh.seed);
 
   for(int depth = 1; depth <= st.maxDepth; depth++) {
     vec3 wo = -ray.direction;
     if(depth > 1 && st.MIS > 0) {
       vec3 Li = V3(0.0f), wi = V3(0.0f);
       float lightPdf = sh.SampleDirectLight(state, Li, wi);
+      if(dbg) fprintf(stderr, "ORC  depth %d NEE lightPdf %08x Li %g %g %g wi %08x %08x %08x lid %08x seed %08x\n", depth, rt_f2u(lightPdf), Li.x, Li.y, Li.z, rt_f2u(wi.x), rt_f2u(wi.y), rt_f2u(wi.z), sh.lastLightId, sh.seed);
       if(!Shader::IsPdfInvalid(lightPdf)) {
         float BSDFPdf = sh.Pdf(state, wo, state.ffnormal, wi);
         float weight = MIS(st, lightPdf, BSDFPdf);
@@ -475,6 +483,7 @@ static void pathTraceIndirect(Shader& sh, State state, Ray ray, bool multiBounce
     ray.origin = OffsetRay(state.position, state.ffnormal);
     ray.direction = sampleWi;
     sh.ClosestHit(ray);
+    if(dbg) fprintf(stderr, "ORC  depth %d bounce dir %08x %08x %08x pdf %08x hitT %08x seed %08x\n", depth, rt_f2u(sampleWi.x), rt_f2u(sampleWi.y), rt_f2u(sampleWi.z), rt_f2u(samplePdf), rt_f2u(sh.hitT), sh.seed);
 
     if(sh.hitT >= RT_INFINITY - 1e-4f) {
       if(depth > 1) {

@@ -278,3 +278,28 @@ def test_direct_light_estimator_matches_area_quadrature():
     lit = lum(quad) > 0.2 * lum(quad).mean()
     per_pixel = lum(est)[lit] / lum(quad)[lit]
     assert abs(np.median(per_pixel) - 1.0) < 0.05, np.median(per_pixel)
+
+
+def test_sliver_triangle_cannot_hit_outside_its_box():
+    """The ray behind tests/test_gpu_fuzz.py::test_regression_sliver_triangle: a shadow ray of the interior scene that ends next to
+    an emissive sliver (two vertices an ulp apart, area 7e-11).  Raw Moller-Trumbore reports a hit on it at t = 4 — metres from the
+    triangle.  With the hit-point-in-padded-box rule (orc_scene.cpp / csrc/traverse.h intersectTri) the ray is unoccluded up to its
+    tmax, and the oracle's BVH and its brute-force tracer agree on the closest hit (the light's neighbour, just beyond tmax)."""
+    import test_gpu_fuzz as F
+    rng = np.random.default_rng(302)
+    for _ in range(384):
+        F._skip_case(rng)
+    kind, scale = F.KINDS[rng.integers(len(F.KINDS))]
+    rng.integers(33, 260); rng.integers(17, 150); rng.integers(3)
+    sc, env = make_scene(kind, scale, int(rng.integers(1, 1000)), (64, 32))
+    assert kind == abi.PROC_BISTRO_INT
+    o = Oracle(1); o.upload_scene(sc.desc(env)); o.resize(16, 16)
+    bits = lambda *h: np.array([int(x, 16) for x in h], dtype=np.uint32).view(np.float32)  # noqa: E731
+    ray = np.zeros((1, 8), np.float32)
+    ray[0, 0:3] = bits("c0882ef8", "40644ccd", "40bfff00"); ray[0, 3:6] = bits("3f4a7797", "bc115996", "bf1ca54f")
+    ray[0, 6] = bits("411ce318")[0]; ray[0, 7] = bits("0d490c4e")[0]
+    assert o.trace_any(ray)[0] == 0
+    far = ray.copy(); far[0, 6] = 1e28
+    a, b = o.trace_closest(far), o.trace_closest(far, brute=True)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert a[0, 0] > ray[0, 6] and abs(a[0, 0] - 9.8057) < 1e-3
