@@ -146,7 +146,7 @@ RT_DEV bool hitTestAlpha(const DevScene& S, uint32_t alphaIdx, uint32_t gid, flo
 // above are rounding noise and can "hit" anywhere along the ray — whether such a triangle is tested at all would then depend on how
 // the tree groups it.  A hit therefore only counts if its point o + t*d lies inside the triangle's bounding box widened by the
 // build's box padding; every box of the tree contains that padded box, so no conservative box test can have culled it.
-RT_DEV bool intersectTri(const Tri48& T, f3 o, f3 d, float pad, float& t, float& u, float& v)
+RT_DEV bool intersectTri(const Tri48& T, f3 o, f3 d, float& t, float& u, float& v)
 {
   const f3 e1 = mk3(T.e1x, T.e1y, T.e1z), e2 = mk3(T.e2x, T.e2y, T.e2z), v0 = mk3(T.v0x, T.v0y, T.v0z);
   const f3 p = cross(d, e2);
@@ -164,7 +164,12 @@ RT_DEV bool intersectTri(const Tri48& T, f3 o, f3 d, float pad, float& t, float&
   v = dot(d, q) * inv;
   if(!(v >= 0.0f && u + v <= 1.0f)) return false;
   t = dot(e2, q) * inv;
-  if(rt_isnan(t)) return false;
+  return !rt_isnan(t);
+}
+// second half of the test (see above); evaluated only for the few candidates that survive the range / closer-than-best tests
+RT_DEV bool hitInsidePaddedBox(const Tri48& T, f3 o, f3 d, float pad, float t)
+{
+  const f3 e1 = mk3(T.e1x, T.e1y, T.e1z), e2 = mk3(T.e2x, T.e2y, T.e2z), v0 = mk3(T.v0x, T.v0y, T.v0z);
   const f3 h = o + d * t, v1 = v0 + e1, v2 = v0 + e2;
   const f3 lo = mk3(rt_min(rt_min(v0.x, v1.x), v2.x) - pad, rt_min(rt_min(v0.y, v1.y), v2.y) - pad, rt_min(rt_min(v0.z, v1.z), v2.z) - pad);
   const f3 hi = mk3(rt_max(rt_max(v0.x, v1.x), v2.x) + pad, rt_max(rt_max(v0.y, v1.y), v2.y) + pad, rt_max(rt_max(v0.z, v1.z), v2.z) + pad);
@@ -277,13 +282,14 @@ RT_DEV bool triCandidate(const DevScene& S, uint32_t triIndex, f3 o, f3 d, bool 
   R.e1y = rt_u2f(b.x); R.e1z = rt_u2f(b.y); R.e2x = rt_u2f(b.z); R.e2y = rt_u2f(b.w);
   R.e2z = rt_u2f(c.x); R.globalId = c.y; R.flags = c.z; R.alphaIdx = c.w;
   gid = R.globalId;
-  if(!intersectTri(R, o, d, S.triPad, t, u, v)) return false;
+  if(!intersectTri(R, o, d, t, u, v)) return false;
   if(ANY) {
     if(!(t > 0.0f && t < tmax)) return false;
   } else {
     if(!(t > 0.0f && t < RT_INFINITY)) return false;
     if(!(t < curT || (t == curT && R.globalId < curG))) return false;
   }
+  if(!hitInsidePaddedBox(R, o, d, S.triPad, t)) return false;
   if(!(R.flags & TRI_OPAQUE)) {
     // opacity micro-map first: most candidates resolve without touching the texture
     const int ci = min(int(u * 8.0f), 7), cj = min(int(v * 8.0f), 7);
