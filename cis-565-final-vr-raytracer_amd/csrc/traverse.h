@@ -170,9 +170,10 @@ RT_DEV bool intersectTri(const Tri48& T, f3 o, f3 d, float& t, float& u, float& 
 RT_DEV bool hitInsidePaddedBox(const Tri48& T, f3 o, f3 d, float pad, float t)
 {
   const f3 e1 = mk3(T.e1x, T.e1y, T.e1z), e2 = mk3(T.e2x, T.e2y, T.e2z), v0 = mk3(T.v0x, T.v0y, T.v0z);
-  const f3 h = o + d * t, v1 = v0 + e1, v2 = v0 + e2;
-  const f3 lo = mk3(rt_min(rt_min(v0.x, v1.x), v2.x) - pad, rt_min(rt_min(v0.y, v1.y), v2.y) - pad, rt_min(rt_min(v0.z, v1.z), v2.z) - pad);
-  const f3 hi = mk3(rt_max(rt_max(v0.x, v1.x), v2.x) + pad, rt_max(rt_max(v0.y, v1.y), v2.y) + pad, rt_max(rt_max(v0.z, v1.z), v2.z) + pad);
+  // min(v0, v0 + e1, v0 + e2) = v0 + min(0, e1, e2) exactly (rounded addition is monotonic): one v_min3 / v_max3 per bound
+  const f3 h = o + d * t;
+  const f3 lo = mk3((v0.x + fminf(fminf(0.0f, e1.x), e2.x)) - pad, (v0.y + fminf(fminf(0.0f, e1.y), e2.y)) - pad, (v0.z + fminf(fminf(0.0f, e1.z), e2.z)) - pad);
+  const f3 hi = mk3((v0.x + fmaxf(fmaxf(0.0f, e1.x), e2.x)) + pad, (v0.y + fmaxf(fmaxf(0.0f, e1.y), e2.y)) + pad, (v0.z + fmaxf(fmaxf(0.0f, e1.z), e2.z)) + pad);
   return h.x >= lo.x && h.x <= hi.x && h.y >= lo.y && h.y <= hi.y && h.z >= lo.z && h.z <= hi.z;
 }
 
