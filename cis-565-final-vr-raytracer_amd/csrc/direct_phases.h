@@ -78,8 +78,6 @@ RT_DEV bool directShadePixel(Ctx& c, const DevFrame& F, const rt_state& st, i2 p
   }
   F.status[index] = status;
   if(status == ST_DONE && !genOnly) storeImg(F.thisDirectResult, F, px, mk4(c.clampRadiance(radiance), 1.0f));  // direct_stage.comp:285-286
-  F.status[index] = status;
-  if(status == ST_DONE && !genOnly) storeImg(F.thisDirectResult, F, px, mk4(c.clampRadiance(radiance), 1.0f));  // direct_stage.comp:285-286
   return wantShadow;
 }
 

@@ -106,6 +106,9 @@ RT_DEV float texelAlpha(const uint8_t* bgra, int w, int x, int y)
 {
   return unorm8ToFloat(bgra[(size_t(y) * w + x) * 4 + 3]);
 }
+// seed of the draw for one (ray, triangle) pair; never the ray's own seed (triangle 0 included), so the pixel's next rand() does
+// not repeat the alpha draw
+RT_DEV uint32_t candidateSeed(uint32_t raySeed, uint32_t gid) { return (raySeed ^ 0x9e3779b9u) + (gid + 1u) * 2654435761u; }
 RT_DEV bool hitTestAlpha(const DevScene& S, uint32_t alphaIdx, uint32_t gid, float u, float v, uint32_t raySeed)
 {
   const uint4* rp = reinterpret_cast<const uint4*>(S.alphaRec + alphaIdx);
@@ -136,7 +139,7 @@ RT_DEV bool hitTestAlpha(const DevScene& S, uint32_t alphaIdx, uint32_t gid, flo
   float opacity;
   if(int(r3.w) == RT_ALPHA_MASK) opacity = baseColorAlpha > rt_u2f(r1.w) ? 1.0f : 0.0f;
   else opacity = baseColorAlpha;
-  uint32_t s = raySeed ^ (gid * 2654435761u);
+  uint32_t s = candidateSeed(raySeed, gid);
   const float r = rnd(s);
   return !(r > opacity);
 }
@@ -299,7 +302,7 @@ RT_DEV bool triCandidate(const DevScene& S, uint32_t triIndex, f3 o, f3 d, bool 
     const uint32_t state = (word >> ((cell & 15) * 2)) & 3u;
     bool accept;
     if(state == 1u) accept = true;
-    else if(state == 2u) { uint32_t hs = seed ^ (R.globalId * 2654435761u); accept = !(rnd(hs) > 0.0f); }
+    else if(state == 2u) { uint32_t hs = candidateSeed(seed, R.globalId); accept = !(rnd(hs) > 0.0f); }
     else accept = hitTestAlpha(S, R.alphaIdx, R.globalId, u, v, seed);
     if(!accept) return false;
   }

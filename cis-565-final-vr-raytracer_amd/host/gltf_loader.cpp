@@ -9,6 +9,7 @@
 // samplers; PNG images (8-bit, non-interlaced, via zlib) and JPEG images (baseline / progressive, jpeg_decoder.cpp).
 #include "scene.hpp"
 #include <zlib.h>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -282,12 +283,18 @@ bool loadGltfFile(const std::string& filename, GltfScene& out, std::string& erro
     a.ncomp = type == "SCALAR" ? 1 : type == "VEC2" ? 2 : type == "VEC3" ? 3 : type == "VEC4" ? 4 : type == "MAT4" ? 16 : 1;
     a.comp = ac.integer("componentType", 5126);
     const size_t csz = (a.comp == 5120 || a.comp == 5121) ? 1 : (a.comp == 5122 || a.comp == 5123) ? 2 : 4;
-    a.count = size_t(ac.number("count", 0));
+    // count / stride / offsets come from the file as doubles: reject anything that is not a finite, non-negative integer small
+    // enough that the byte range below cannot wrap (a malformed file must not become an out-of-bounds read)
+    auto asSize = [](double v, size_t limit, size_t& out) { if(!(v >= 0.0) || !(v <= double(limit)) || v != std::floor(v)) return false; out = size_t(v); return true; };
+    const size_t bufSize = buffers[size_t(b)].size();
+    size_t viewOff = 0, accOff = 0, strideIn = 0;
+    if(!asSize(ac.number("count", 0), size_t(1) << 40, a.count) || !asSize(view.number("byteStride", 0), 4096, strideIn) ||
+       !asSize(view.number("byteOffset", 0), bufSize, viewOff) || !asSize(ac.number("byteOffset", 0), bufSize, accOff)) return false;
     a.normalized = ac.boolean("normalized", false);
-    a.stride = size_t(view.number("byteStride", 0));
-    if(!a.stride) a.stride = csz * size_t(a.ncomp);
-    const size_t off = size_t(view.number("byteOffset", 0)) + size_t(ac.number("byteOffset", 0));
-    if(a.count && off + (a.count - 1) * a.stride + csz * size_t(a.ncomp) > buffers[size_t(b)].size()) return false;
+    a.stride = strideIn ? strideIn : csz * size_t(a.ncomp);
+    const size_t off = viewOff + accOff, elem = csz * size_t(a.ncomp);
+    if(off > bufSize || elem > bufSize - off) return false;
+    if(a.count && (a.count - 1) > (bufSize - off - elem) / a.stride) return false;   // division form: no multiplication that could overflow
     a.data = buffers[size_t(b)].data() + off;
     return true;
   };
@@ -379,10 +386,10 @@ bool loadGltfFile(const std::string& filename, GltfScene& out, std::string& erro
       if(size_t(pm.materialIndex) >= out.materials.size()) pm.materialIndex = 0;
       for(size_t v = 0; v < pos.count; v++) out.positions.push_back(V3{readComp(pos, v, 0), readComp(pos, v, 1), readComp(pos, v, 2)});
       Accessor nrm, tng, uv, col;
-      const bool hn = accessor(attr->integer("NORMAL", -1), nrm) && nrm.count == pos.count;
+      const bool hn = accessor(attr->integer("NORMAL", -1), nrm) && nrm.count == pos.count && nrm.ncomp >= 3;
       const bool ht = accessor(attr->integer("TANGENT", -1), tng) && tng.count == pos.count && tng.ncomp == 4;
-      const bool hu = accessor(attr->integer("TEXCOORD_0", -1), uv) && uv.count == pos.count;
-      const bool hc = accessor(attr->integer("COLOR_0", -1), col) && col.count == pos.count;
+      const bool hu = accessor(attr->integer("TEXCOORD_0", -1), uv) && uv.count == pos.count && uv.ncomp >= 2;
+      const bool hc = accessor(attr->integer("COLOR_0", -1), col) && col.count == pos.count && (col.ncomp == 3 || col.ncomp == 4);
       haveNormals = haveNormals && hn; haveTangents = haveTangents && ht;
       for(size_t v = 0; v < pos.count; v++) {
         out.normals.push_back(hn ? V3{readComp(nrm, v, 0), readComp(nrm, v, 1), readComp(nrm, v, 2)} : V3{0, 0, 0});

@@ -466,6 +466,9 @@ class RendererTensors:
         self.r, self.torch = renderer, torch
         self._cache = {}
         self._streams = None
+        # rt_create gives the context its own non-blocking stream; NCCL's work.wait() only orders torch's current stream.  Bind the
+        # renderer to it here so that halo exchanges and all-gathers are ordered against the stage kernels even when the caller forgets
+        renderer.set_stream(torch.cuda.current_stream().cuda_stream)
     def run_stage(self, state, frames, stage, level, r0, r1):
         self.r.run_stage(state, frames, stage, level, r0, r1)
     def set_history_rows(self, r0, r1):

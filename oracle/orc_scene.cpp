@@ -185,7 +185,7 @@ bool Scene::hitTest(const Tri& T, uint32_t triIndex, float u, float v, uint32_t 
   float opacity;
   if(mat.alphaMode == RT_ALPHA_MASK) opacity = baseColorAlpha > mat.alphaCutoff ? 1.0f : 0.0f;
   else opacity = baseColorAlpha;
-  uint32_t s = raySeed ^ (triIndex * 2654435761u);
+  uint32_t s = candidateSeed(raySeed, triIndex);
   float r = rt_u2f(0x3f800000u | (pcgStep(s) >> 9)) - 1.0f;
   return !(r > opacity);
 }

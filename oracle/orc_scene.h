@@ -129,6 +129,9 @@ struct Scene {
   // ---- ray queries --------------------------------------------------------------------------------
   bool intersectTri(const Tri& T, vec3 o, vec3 d, float& t, float& u, float& v) const;
   bool hitTest(const Tri& T, uint32_t triIndex, float u, float v, uint32_t raySeed) const;
+  // seed of HitTest's stochastic draw for one (ray, triangle) pair (DESIGN.md §6 deviation 1).  Never equal to the ray's own
+  // seed for triangle 0 (the pixel's next rand() would otherwise repeat the alpha draw).
+  static uint32_t candidateSeed(uint32_t raySeed, uint32_t triIndex) { return (raySeed ^ 0x9e3779b9u) + (triIndex + 1u) * 2654435761u; }
   // ClosestHit (traceray_rq.glsl:108-147): tmin 0, tmax INFINITY
   Hit closestHit(vec3 o, vec3 d, uint32_t raySeed) const;
   // AnyHit (traceray_rq.glsl:153-185)
