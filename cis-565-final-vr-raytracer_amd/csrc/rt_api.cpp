@@ -228,21 +228,23 @@ int rt_create(rt_ctx** out, int device)
     const char* pe = getenv("RESTIR_PRIO");
     const int mode = pe ? atoi(pe) : 1;   // 0 none, 1 ind + side high, 2 ind high, 3 side high
     const bool can = hi < lo;
+    bool ok = true;
     auto mk = [&](hipStream_t* s, bool high) {
-      if(can && high) (void)hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi);
-      else (void)hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+      if(can && high) ok = ok && hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi) == hipSuccess;
+      else ok = ok && hipStreamCreateWithFlags(s, hipStreamNonBlocking) == hipSuccess;
     };
     mk(&c->sideStream, mode == 1 || mode == 3);
     mk(&c->indStream, mode == 1 || mode == 2);
+    for(int i = 0; i < 4; i++) {
+      ok = ok && hipEventCreateWithFlags(&c->evD[i], hipEventDisableTiming) == hipSuccess;
+      ok = ok && hipEventCreateWithFlags(&c->evI[i], hipEventDisableTiming) == hipSuccess;
+      ok = ok && hipEventCreateWithFlags(&c->evDone[i], hipEventDisableTiming) == hipSuccess;
+    }
+    ok = ok && hipEventCreateWithFlags(&c->evWf, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming) == hipSuccess;
+    if(!ok) { g_createErr = "rt_create: creating the internal streams / events failed"; rt_destroy(c); return RT_ERR_HIP; }
   }
-  for(int i = 0; i < 4; i++) {
-    (void)hipEventCreateWithFlags(&c->evD[i], hipEventDisableTiming);
-    (void)hipEventCreateWithFlags(&c->evI[i], hipEventDisableTiming);
-    (void)hipEventCreateWithFlags(&c->evDone[i], hipEventDisableTiming);
-  }
-  (void)hipEventCreateWithFlags(&c->evWf, hipEventDisableTiming);
-  (void)hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming);
-  (void)hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming);
   if(const char* e = getenv("RESTIR_OVERLAP")) c->overlap = atoi(e);
   if(const char* e = getenv("RESTIR_PIPELINE")) c->pipeline = (strcmp(e, "wavefront") == 0) ? 1 : 0;
   if(hipMalloc(reinterpret_cast<void**>(&c->dCounters), 8 * sizeof(unsigned long long)) != hipSuccess) { g_createErr = "rt_create: hipMalloc failed"; delete c; return RT_ERR_OOM; }
@@ -838,6 +840,16 @@ int rt_accel_stats(rt_ctx* c, uint64_t* numNodes, uint64_t* numTris, int* maxDep
   if(numNodes) *numNodes = c->numNodes;
   if(numTris) *numTris = c->numTris;
   if(maxDepth) *maxDepth = c->maxDepth;
+  return RT_OK;
+}
+
+int rt_measure_valu_peak(rt_ctx* c, int variant, int wavesPerSimd, double* waveInstPerSec)
+{
+  if(!c || !waveInstPerSec || variant < 0 || variant > 1 || wavesPerSimd < 1 || wavesPerSimd > 8) return RT_ERR_INVALID_ARG;
+  RT_HIP(c, hipSetDevice(c->device));
+  RT_HIP(c, syncAll(c));
+  double seconds = 0.0;
+  RT_HIP(c, measureValuIssue(c->stream, variant, wavesPerSimd, waveInstPerSec, &seconds));
   return RT_OK;
 }
 

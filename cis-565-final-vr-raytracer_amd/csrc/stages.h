@@ -23,6 +23,8 @@ struct SkyPre;
 hipError_t launchSkyPrepare(hipStream_t stream, const rt_sun_and_sky& ss, SkyPre* out);
 hipError_t launchPick(hipStream_t stream, const DevScene& S, const rt_mat4& viewInv, const rt_mat4& projInv, float pickX, float pickY, rt_pick_result* out);
 // RenderOutput::run + post.frag as compute (post.hip)
+// csrc/microbench.hip
+hipError_t measureValuIssue(hipStream_t stream, int variant, int wavesPerSimd, double* waveInstPerSec, double* seconds);
 hipError_t launchTonemap(hipStream_t stream, const float4* direct, const float4* indirect, double* rowSums, float* mean, const rt_tonemapper& tm, int dbg, int W, int H,
                          uint32_t* ldr);
 }

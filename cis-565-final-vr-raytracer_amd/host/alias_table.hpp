@@ -3,7 +3,7 @@
 // split them into an "over-full" and an "under-full" stack in index order, then repeatedly top up the most recent
 // under-full bucket from the most recent over-full one.  The resulting {prob, failId} pairs feed
 // ImptSampData.q / .alias of the light records (scene.cpp:700-772).  Validated against the reference header
-// compiled in place (oracle/kat/mint_kat.sh -> tests/golden/alias_table.json).
+// compiled in place (oracle/kat/mint_kat.sh -> "alias_table" in tests/golden/kat_reference.json, tests/test_kat.py).
 #pragma once
 #include <vector>
 

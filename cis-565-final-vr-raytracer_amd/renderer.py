@@ -15,7 +15,7 @@ _lib = None
 # every symbol include/rt_abi.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_build_accel", "rt_resize", "rt_set_camera",
                "rt_render_frame", "rt_run_stage", "rt_readback", "rt_upload_history", "rt_buffer_bytes", "rt_device_ptr",
-               "rt_set_counting", "rt_get_counters", "rt_sync", "rt_last_error", "rt_abi_version", "rt_set_pipeline", "rt_set_history_rows", "rt_history_miss", "rt_set_overlap", "rt_tonemap", "rt_set_sun_and_sky", "rt_pick", "rt_history_miss_stage", "rt_rotate_buffers"]
+               "rt_set_counting", "rt_get_counters", "rt_sync", "rt_last_error", "rt_abi_version", "rt_set_pipeline", "rt_set_history_rows", "rt_history_miss", "rt_set_overlap", "rt_tonemap", "rt_set_sun_and_sky", "rt_pick", "rt_history_miss_stage", "rt_rotate_buffers", "rt_measure_valu_peak"]
 
 
 def hip_lib():
@@ -60,6 +60,7 @@ def hip_lib():
         L.rt_set_history_rows.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.rt_history_miss.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.rt_get_counters.argtypes = [C.c_void_p, C.c_void_p]
+        L.rt_measure_valu_peak.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.rt_accel_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
         _lib = L
     return _lib
@@ -201,6 +202,12 @@ class Renderer:
         c = abi.Counters()
         self._chk(hip_lib().rt_get_counters(self._h, C.byref(c)), "rt_get_counters")
         return c
+
+    def measure_valu_peak(self, variant=0, waves_per_simd=8):
+        """wave-level VALU instructions per second of a chain-free loop on this device (csrc/microbench.hip)"""
+        v = C.c_double()
+        self._chk(hip_lib().rt_measure_valu_peak(self._h, variant, waves_per_simd, C.byref(v)), "rt_measure_valu_peak")
+        return v.value
 
     def accel_stats(self):
         n, t, d = C.c_uint64(), C.c_uint64(), C.c_int()

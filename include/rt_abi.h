@@ -400,6 +400,11 @@ int rt_set_sun_and_sky(rt_ctx* ctx, const rt_sun_and_sky* ss);
  * G-buffers and the motion buffer are invalidated by rt_render_frame (rt_run_stage never rotates buffers).
  * Also settable with RESTIR_OVERLAP=0|1|2 before rt_create. */
 int rt_set_overlap(rt_ctx* ctx, int mode);
+/* Measured VALU issue ceiling of the device the ctx lives on (csrc/microbench.hip): wave-level VALU instructions per second of a
+ * chain-free loop.  variant 0 = the instruction mix of the traced kernels, 1 = v_fma_f32 only; wavesPerSimd in 1..8.
+ * bench.py prices `roofline.valu` against this measurement instead of an assumed cycles-per-instruction figure.
+ * (Introspection like rt_get_counters; no counterpart in the reference.) */
+int rt_measure_valu_peak(rt_ctx* ctx, int variant, int wavesPerSimd, double* waveInstPerSec);
 /* Wait for all work on the ctx stream. */
 int rt_sync(rt_ctx* ctx);
 /* Last error message of this ctx (or of rt_create when ctx == NULL). Never NULL. */

@@ -5,7 +5,7 @@ TAG=${1:-pmc}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-run() { rocprofv3 --pmc $2 --output-format csv -d $OUT -o $1 -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2>&1; }
+run() { rocprofv3 --pmc $2 --output-format csv -d $OUT -o $1 -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --profile-run > /dev/null 2>&1; }
 run sq1 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM"
 run sq2 "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_INST_LEVEL_VMEM SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
 run sq3 "SQ_LEVEL_WAVES SQ_CYCLES SQ_INSTS_BRANCH SQ_IFETCH SQ_INST_CYCLES_VMEM_RD SQ_LDS_IDX_ACTIVE"

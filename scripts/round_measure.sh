@@ -10,7 +10,7 @@ timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')
 timeout 300 cis-565-final-vr-raytracer_amd/host/restir_demo -f tests/golden/mini_scene.gltf -w 640 -h 360 -n 8 -o $O/demo_mini > $O/demo.log 2>&1; tail -2 $O/demo.log
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; cat $O/bench.json
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o stats -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/prof_bench.json 2> $O/prof.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o stats -- python $R/bench.py --steps 100 --warmup 20 --no-cpu-baseline --profile-run > $O/prof_bench.json 2> $O/prof.err
 cat $O/prof_bench.json
 ls $O/prof
 cd $R && timeout 1200 bash scripts/pmc.sh $TAG/pmc > $O/pmc.log 2>&1; tail -40 $O/pmc.log
