@@ -87,6 +87,8 @@ struct DevFrame {
   // history and redo the frame; single-GPU: [0, H) and the flag never fires.
   int32_t histRow0, histRow1;
   uint32_t* histMiss;
+  // highest a-trous level that runs on the LDS-tile filter kernel (k_denoise_tile), -1 = none: chosen per launch by rt_api.cpp
+  int32_t denoiseTileMax;
 };
 
 }  // namespace rt

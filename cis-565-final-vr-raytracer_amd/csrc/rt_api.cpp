@@ -512,6 +512,12 @@ static DevFrame makeFrame(rt_ctx* c, int frames)
 {
   const int cur = frames & 1, last = (frames + 1) & 1;  // m_descSet[(frames+1)%2]: this = [!i] (renderer.cpp:157, 346-356)
   DevFrame F{};
+  // A-Trous kernel choice (bit-identical results): the LDS-tile kernel computes every pair weight once and wins on levels 0-1 when
+  // the launch has the chip to itself (-17 % / -29 % direct / indirect), but its 256-thread / 36 KB workgroups fit badly between
+  // the traversal waves of the frames in flight (+5 % frame time, profiles/r02_denoise_tile_ab.txt): serial schedules use it,
+  // the frames-in-flight schedule keeps the per-pixel gather.  RESTIR_DENOISE_TILE=<max level | -1> overrides.
+  static const int tileEnv = getenv("RESTIR_DENOISE_TILE") ? atoi(getenv("RESTIR_DENOISE_TILE")) : -2;
+  F.denoiseTileMax = tileEnv != -2 ? tileEnv : (c->overlap == 2 ? -1 : 1);
   F.thisG = static_cast<uint4*>(c->bufs[RT_BUF_GBUFFER0 + cur]); F.lastG = static_cast<const uint4*>(c->bufs[RT_BUF_GBUFFER0 + last]);
   F.motion = static_cast<short2*>(c->bufs[RT_BUF_MOTION]);
   F.thisDirectResv = static_cast<rt_direct_reservoir*>(c->bufs[RT_BUF_DIRECT_RESV0 + cur]);

@@ -769,6 +769,145 @@ __global__ __launch_bounds__(64) void k_denoise(DevFrame F, rt_state st, const f
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// waveletFilter on chip.  The weight of tap q in pixel p's sum is, bit for bit, the weight of tap p in pixel q's sum:
+// |a - b| = |b - a|, (a - b)^2 = (b - a)^2 component by component, the material test is symmetric and the 5x5 kernel is
+// point symmetric.  So one workgroup takes a 16 x 16 tile of ONE a-trous sub-lattice (the pixels with equal coordinates modulo
+// 2^level: on it the dilated stencil is a dense 5 x 5), stages colour (+ luminance), normal + material hash and position of the
+// tile and its 2-pixel ring in LDS once, computes every pair weight ONCE (12 "forward" offsets per source pixel, sources =
+// the tile plus the two lattice rows above it and the two lattice columns either side) into LDS, and then every pixel gathers
+// its 25 taps in the reference's order (j outer, i inner: float sums are order dependent) — forward taps read the pixel's own
+// weights, backward taps the neighbour's.  Per pixel: 13 + (ring overhead) weight evaluations instead of 25, no global gathers
+// inside the loop, no 64-bit address arithmetic.  Same expressions => same bits as k_denoise (kept for RESTIR_DENOISE_TILE=0).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int DT_T = 16;             // tile edge in lattice pixels
+constexpr int DT_S = DT_T + 4;       // staged edge (2-pixel ring)
+constexpr int DT_SRC_ROWS = DT_T + 2;  // weight sources: ring rows above + tile rows
+constexpr int DT_NSRC = DT_SRC_ROWS * DT_S;
+constexpr int DT_NFWD = 12;
+// forward half of the stencil in (i, j), j > 0 or (j == 0 and i > 0)
+__device__ constexpr int8_t kFwdI[DT_NFWD] = {1, 2, -2, -1, 0, 1, 2, -2, -1, 0, 1, 2};
+__device__ constexpr int8_t kFwdJ[DT_NFWD] = {0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2};
+RT_DEV int fwdIndex(int i, int j) { return j == 0 ? i - 1 : (j == 1 ? 4 + i : 9 + i); }   // inverse of the two tables
+
+template <bool IND, bool FAST>
+RT_DEV float denoisePairWeight(f3 color, float lum, f3 norm, f3 pos, f3 colorQ, float lumQ, f3 normQ, f3 posQ, float gauss, float sigL, float sigN, float sigD, float yL,
+                               float yN, float yD)
+{
+  const float distColor = IND ? dot(color - colorQ, color - colorQ) : rt_abs(lum - lumQ);
+  const float wColor = expNonPositive(-divUniform<FAST>(distColor, sigL, yL)) + 1e-2f;
+  const float distNorm2 = dot(norm - normQ, norm - normQ);
+  const float wNorm = rt_min(1.0f, expNonPositive(-divUniform<FAST>(distNorm2, sigN, yN)));
+  const float distPos2 = dot(pos - posQ, pos - posQ);
+  const float wDepth = expNonPositive(-divUniform<FAST>(distPos2, sigD, yD)) + 1e-2f;
+  return wColor * wNorm * wDepth * gauss;
+}
+
+template <bool IND, bool FAST>
+__global__ __launch_bounds__(256) void k_denoise_tile(DevFrame F, rt_state st, const float4* src, float4* dst, int level, int rowBegin, int rowEnd, int tilesX, int tilesY,
+                                                      float yL, float yN, float yD)
+{
+  __shared__ float4 sC[DT_S * DT_S];            // colour.xyz, luminance (direct filter)
+  __shared__ float4 sN[DT_S * DT_S];            // normal.xyz, material hash bits (RT_INVALID_MAT_ID: no tap)
+  __shared__ float4 sP[DT_S * DT_S];            // reconstructed position
+  __shared__ float sW[DT_NFWD * DT_NSRC];       // forward pair weights, [offset][source]; -1 = no tap
+  const int step = 1 << level;
+  // consecutive work items (the step^2 sub-lattices of one tile region share their cache lines) go to the same XCD; a workgroup
+  // loops over work items gridDim.x / 8 apart (persistent launch: the LDS this kernel holds per CU is bounded by the grid size,
+  // so that traversal kernels of the neighbouring frames in flight keep their LDS stacks)
+  const int total = tilesX * tilesY * step * step, perXcd = (total + 7) / 8;
+  for(int local = int(blockIdx.x >> 3); local < perXcd; local += int(gridDim.x >> 3)) {
+  const int work = int(blockIdx.x & 7u) * perXcd + local;
+  if(work >= total) break;
+  __syncthreads();   // the previous item's gather is done before its LDS is overwritten
+  const int sub = work % (step * step), tileIdx = work / (step * step);
+  const int a = sub % step, b = sub / step;
+  const int X0 = (tileIdx % tilesX) * DT_T, Y0 = (tileIdx / tilesX) * DT_T;
+  const i2 bound = IND ? i2{st.size.x / 2, st.size.y / 2} : i2{st.size.x, st.size.y};
+  const float sigLumin = IND ? st.sigLuminIndirect : st.sigLuminDirect;
+  const float sigNormal = IND ? st.sigNormalIndirect : st.sigNormalDirect;
+  const float sigDepth = IND ? st.sigDepthIndirect : st.sigDepthDirect;
+  const int last = IND ? 4 : 3;
+  const float4* gN = IND ? F.geomNh : F.geomN;
+  const float4* gP = IND ? F.geomPh : F.geomP;
+  const int tid = int(threadIdx.x);
+
+  // ---- 1. stage the tile and its ring ----
+  for(int idx = tid; idx < DT_S * DT_S; idx += 256) {
+    const int lx = idx % DT_S, ly = idx / DT_S;
+    const int px = a + step * (X0 - 2 + lx), py = rowBegin + b + step * (Y0 - 2 + ly);
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f), n = make_float4(0.f, 0.f, 0.f, rt_u2f(RT_INVALID_MAT_ID)), q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if(px >= 0 && py >= 0 && px < bound.x && py < bound.y) {
+      const size_t gi = size_t(py) * bound.x + px;
+      n = gN[gi]; q = gP[gi];
+      c = src[size_t(py) * F.W + px];
+      c.w = IND ? 0.0f : luminance(mk3(c.x, c.y, c.z));
+    }
+    sC[idx] = c; sN[idx] = n; sP[idx] = q;
+  }
+  __syncthreads();
+
+  // ---- 2. every pair weight once ----
+  for(int sidx = tid; sidx < DT_NSRC; sidx += 256) {
+    const int sx = sidx % DT_S, sy = sidx / DT_S;
+    const float4 cN = sN[sidx], cP = sP[sidx], cC = sC[sidx];
+    const uint32_t hash = rt_f2u(cN.w);
+    const bool srcInTile = sx >= 2 && sx < DT_T + 2 && sy >= 2;
+#pragma unroll
+    for(int k = 0; k < DT_NFWD; k++) {
+      const int i = kFwdI[k], j = kFwdJ[k];
+      const int tx = sx + i, ty = sy + j;
+      float w = -1.0f;
+      if(tx >= 0 && tx < DT_S) {
+        const bool tgtInTile = tx >= 2 && tx < DT_T + 2 && ty >= 2 && ty < DT_T + 2;
+        const int tidx = ty * DT_S + tx;
+        const float4 qN = sN[tidx];
+        if((srcInTile || tgtInTile) && hash != RT_INVALID_MAT_ID && rt_f2u(qN.w) == hash) {
+          const float4 qP = sP[tidx], qC = sC[tidx];
+          w = denoisePairWeight<IND, FAST>(mk3(cC.x, cC.y, cC.z), cC.w, mk3(cN.x, cN.y, cN.z), mk3(cP.x, cP.y, cP.z), mk3(qC.x, qC.y, qC.z), qC.w, mk3(qN.x, qN.y, qN.z),
+                                           mk3(qP.x, qP.y, qP.z), kGauss[i + 2][j + 2], sigLumin, sigNormal, sigDepth, yL, yN, yD);
+        }
+      }
+      sW[k * DT_NSRC + sidx] = w;
+    }
+  }
+  __syncthreads();
+
+  // ---- 3. gather in the reference's tap order ----
+  const int ux = tid % DT_T, uy = tid / DT_T;
+  const i2 coord{a + step * (X0 + ux), rowBegin + b + step * (Y0 + uy)};
+  if(coord.x >= bound.x || coord.y >= bound.y || coord.y >= rowEnd) continue;
+  const int cx = ux + 2, cy = uy + 2, cidx = cy * DT_S + cx;
+  const float4 cN = sN[cidx];
+  f3 res = mk3(0.0f);
+  if(rt_f2u(cN.w) != RT_INVALID_MAT_ID) {
+    const float4 cC = sC[cidx], cP = sP[cidx];
+    f3 sum = mk3(0.0f);
+    float sumWeight = 0.0f;
+#pragma unroll
+    for(int j = -2; j <= 2; j++)
+#pragma unroll
+      for(int i = -2; i <= 2; i++) {
+        float w;
+        if(i == 0 && j == 0)
+          w = denoisePairWeight<IND, FAST>(mk3(cC.x, cC.y, cC.z), cC.w, mk3(cN.x, cN.y, cN.z), mk3(cP.x, cP.y, cP.z), mk3(cC.x, cC.y, cC.z), cC.w, mk3(cN.x, cN.y, cN.z),
+                                           mk3(cP.x, cP.y, cP.z), kGauss[2][2], sigLumin, sigNormal, sigDepth, yL, yN, yD);
+        else if(j > 0 || (j == 0 && i > 0)) w = sW[fwdIndex(i, j) * DT_NSRC + cidx];
+        else w = sW[fwdIndex(-i, -j) * DT_NSRC + (cidx + j * DT_S + i)];
+        if(w != -1.0f) {
+          const float4 q = sC[cidx + j * DT_S + i];
+          sum += mk3(q.x, q.y, q.z) * w;
+          sumWeight += w;
+        }
+      }
+    res = (sumWeight < 1e-5f) ? mk3(0.0f) : sum / sumWeight;
+    if(hasNan(res) || res.x < 0 || res.y < 0 || res.z < 0 || res.x > 1e8f || res.y > 1e8f || res.z > 1e8f) res = mk3(0.0f);
+  }
+  if(level == last) res = LDRToHDR(res);
+  storeImg(dst, F, coord, mk4(res, 1.0f));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // compose.comp:23-43
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_compose(DevFrame F, rt_state st, int rowBegin, int rowEnd, int tilesX, int tilesY)
@@ -796,6 +935,7 @@ __global__ __launch_bounds__(64) void k_compose(DevFrame F, rt_state st, int row
 // ------------------------------------------------------------------------------------------------------------
 // divUniform's fast path: the divisor must keep every intermediate in the normal range (see there)
 static bool uniformDivOk(float s) { return s >= 1e-6f && s <= 1e6f; }
+// RESTIR_DENOISE_TILE=0 selects the per-pixel gather kernels (k_denoise) for A/B runs; results are bit-identical
 
 hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F, const rt_state& st, const rt_scene_camera& cam, int stage, int level,
                        int rowBegin, int rowEnd)
@@ -848,6 +988,16 @@ hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F,
         const int gty = (g1 - g0 + 7) / 8;
         hipLaunchKernelGGL(k_denoise_geom<false>, dim3(tileGrid(tilesX, gty)), block, 0, stream, F, st, cam, g0, g1, tilesX, gty);
       }
+      if(level <= F.denoiseTileMax) {
+        const int stp = 1 << level, ltx = ((gw + stp - 1) / stp + DT_T - 1) / DT_T, lty = ((rowEnd - rowBegin + stp - 1) / stp + DT_T - 1) / DT_T;
+        const unsigned nwg = std::min(8u * unsigned((ltx * lty * stp * stp + 7) / 8), denoiseTileGridCap());
+        if(uniformDivOk(st.sigLuminDirect) && uniformDivOk(st.sigNormalDirect) && uniformDivOk(st.sigDepthDirect))
+          hipLaunchKernelGGL((k_denoise_tile<false, true>), dim3(nwg), dim3(256), 0, stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, ltx, lty,
+                             1.0f / st.sigLuminDirect, 1.0f / st.sigNormalDirect, 1.0f / st.sigDepthDirect);
+        else
+          hipLaunchKernelGGL((k_denoise_tile<false, false>), dim3(nwg), dim3(256), 0, stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, ltx, lty, 0.f, 0.f, 0.f);
+        break;
+      }
       if(uniformDivOk(st.sigLuminDirect) && uniformDivOk(st.sigNormalDirect) && uniformDivOk(st.sigDepthDirect))
         hipLaunchKernelGGL((k_denoise<false, true>), grid, block, 0, stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, tilesX, tilesY,
                            1.0f / st.sigLuminDirect, 1.0f / st.sigNormalDirect, 1.0f / st.sigDepthDirect);
@@ -865,6 +1015,16 @@ hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F,
         const int g0 = std::max(0, rowBegin - 32) & ~7, g1 = std::min(gh, rowEnd + 32);
         const int gty = (g1 - g0 + 7) / 8;
         hipLaunchKernelGGL(k_denoise_geom<true>, dim3(tileGrid(tilesX, gty)), block, 0, stream, F, st, cam, g0, g1, tilesX, gty);
+      }
+      if(level <= F.denoiseTileMax) {
+        const int stp = 1 << level, ltx = ((gw + stp - 1) / stp + DT_T - 1) / DT_T, lty = ((rowEnd - rowBegin + stp - 1) / stp + DT_T - 1) / DT_T;
+        const unsigned nwg = std::min(8u * unsigned((ltx * lty * stp * stp + 7) / 8), denoiseTileGridCap());
+        if(uniformDivOk(st.sigLuminIndirect) && uniformDivOk(st.sigNormalIndirect) && uniformDivOk(st.sigDepthIndirect))
+          hipLaunchKernelGGL((k_denoise_tile<true, true>), dim3(nwg), dim3(256), 0, stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, ltx, lty,
+                             1.0f / st.sigLuminIndirect, 1.0f / st.sigNormalIndirect, 1.0f / st.sigDepthIndirect);
+        else
+          hipLaunchKernelGGL((k_denoise_tile<true, false>), dim3(nwg), dim3(256), 0, stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, ltx, lty, 0.f, 0.f, 0.f);
+        break;
       }
       if(uniformDivOk(st.sigLuminIndirect) && uniformDivOk(st.sigNormalIndirect) && uniformDivOk(st.sigDepthIndirect))
         hipLaunchKernelGGL((k_denoise<true, true>), grid, block, 0, stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, tilesX, tilesY,
