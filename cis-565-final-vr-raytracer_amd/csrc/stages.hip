@@ -935,6 +935,8 @@ __global__ __launch_bounds__(64) void k_compose(DevFrame F, rt_state st, int row
 // ------------------------------------------------------------------------------------------------------------
 // divUniform's fast path: the divisor must keep every intermediate in the normal range (see there)
 static bool uniformDivOk(float s) { return s >= 1e-6f && s <= 1e6f; }
+// RESTIR_DENOISE_WGS: upper bound of resident k_denoise_tile workgroups (multiple of 8; each holds 36.5 KB of LDS); default: one per work item
+static unsigned denoiseTileGridCap() { static const unsigned v = getenv("RESTIR_DENOISE_WGS") ? (unsigned(atoi(getenv("RESTIR_DENOISE_WGS"))) + 7u) / 8u * 8u : 1u << 30; return std::max(8u, v); }
 // RESTIR_DENOISE_TILE=0 selects the per-pixel gather kernels (k_denoise) for A/B runs; results are bit-identical
 
 hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F, const rt_state& st, const rt_scene_camera& cam, int stage, int level,
