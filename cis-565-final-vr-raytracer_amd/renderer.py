@@ -15,7 +15,9 @@ _lib = None
 # every symbol include/rt_abi.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_build_accel", "rt_resize", "rt_set_camera",
                "rt_render_frame", "rt_run_stage", "rt_readback", "rt_upload_history", "rt_buffer_bytes", "rt_device_ptr",
-               "rt_set_counting", "rt_get_counters", "rt_sync", "rt_last_error", "rt_abi_version", "rt_set_pipeline", "rt_set_history_rows", "rt_history_miss", "rt_set_overlap", "rt_tonemap", "rt_set_sun_and_sky", "rt_pick", "rt_history_miss_stage", "rt_rotate_buffers", "rt_measure_valu_peak"]
+               "rt_set_counting", "rt_get_counters", "rt_sync", "rt_last_error", "rt_abi_version", "rt_set_pipeline", "rt_set_history_rows", "rt_history_miss", "rt_set_overlap", "rt_tonemap", "rt_set_sun_and_sky", "rt_pick", "rt_history_miss_stage", "rt_rotate_buffers", "rt_measure_valu_peak",
+               "rt_mgpu_create", "rt_mgpu_destroy", "rt_mgpu_upload_scene", "rt_mgpu_resize", "rt_mgpu_set_camera", "rt_mgpu_render_frame", "rt_mgpu_readback",
+               "rt_mgpu_sync", "rt_mgpu_set_balance", "rt_mgpu_set_serialize", "rt_mgpu_get_stats", "rt_mgpu_last_error"]
 
 
 def hip_lib():
@@ -61,6 +63,18 @@ def hip_lib():
         L.rt_history_miss.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.rt_get_counters.argtypes = [C.c_void_p, C.c_void_p]
         L.rt_measure_valu_peak.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.rt_mgpu_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int)]
+        for n in ["rt_mgpu_destroy", "rt_mgpu_sync"]:
+            getattr(L, n).argtypes = [C.c_void_p]
+        L.rt_mgpu_upload_scene.argtypes = [C.c_void_p, C.c_void_p]
+        L.rt_mgpu_resize.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.rt_mgpu_set_camera.argtypes = [C.c_void_p, C.c_void_p]
+        L.rt_mgpu_render_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.rt_mgpu_readback.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        L.rt_mgpu_set_balance.argtypes = [C.c_void_p, C.c_int]
+        L.rt_mgpu_set_serialize.argtypes = [C.c_void_p, C.c_int]
+        L.rt_mgpu_get_stats.argtypes = [C.c_void_p, C.c_void_p]
+        L.rt_mgpu_last_error.argtypes = [C.c_void_p]; L.rt_mgpu_last_error.restype = C.c_char_p
         L.rt_accel_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
         _lib = L
     return _lib
@@ -213,3 +227,63 @@ class Renderer:
         n, t, d = C.c_uint64(), C.c_uint64(), C.c_int()
         self._chk(hip_lib().rt_accel_stats(self._h, C.byref(n), C.byref(t), C.byref(d)), "rt_accel_stats")
         return {"nodes": n.value, "triangles": t.value, "max_depth": d.value}
+
+
+class MgpuStats(C.Structure):  # rt_mgpu_stats
+    _fields_ = [("numRanks", C.c_int32), ("frames", C.c_uint32), ("historyFallbacks", C.c_uint32), ("pad", C.c_uint32), ("haloBytes", C.c_uint64),
+                ("bandBegin", C.c_int32 * 16), ("bandEnd", C.c_int32 * 16), ("tracedMs", C.c_float * 16), ("filterMs", C.c_float * 16)]
+
+
+class MultiGpuRenderer:
+    """rt_mgpu_*: one process drives N devices (csrc/mgpu.cpp) — the Renderer interface over the native row-tiled frame."""
+    def __init__(self):
+        self._h = None
+        self.size = (0, 0)
+
+    def setup(self, devices):
+        devices = list(devices)
+        arr = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        rc = hip_lib().rt_mgpu_create(C.byref(h), len(devices), arr)
+        if rc != 0:
+            raise RtError(f"rt_mgpu_create failed ({rc}): {hip_lib().rt_last_error(None).decode()}")
+        self._h, self.world = h, len(devices)
+        return self
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RtError(f"{what} failed ({rc}): {hip_lib().rt_mgpu_last_error(self._h).decode()}")
+
+    def destroy(self):
+        if self._h:
+            hip_lib().rt_mgpu_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    def load_scene(self, desc): self._chk(hip_lib().rt_mgpu_upload_scene(self._h, C.byref(desc)), "rt_mgpu_upload_scene")
+    def update(self, width, height):
+        self._chk(hip_lib().rt_mgpu_resize(self._h, width, height), "rt_mgpu_resize")
+        self.size = (width, height)
+    def set_camera(self, cam): self._chk(hip_lib().rt_mgpu_set_camera(self._h, C.byref(cam)), "rt_mgpu_set_camera")
+    def run(self, state, frames): self._chk(hip_lib().rt_mgpu_render_frame(self._h, C.byref(state), frames), "rt_mgpu_render_frame")
+    def sync(self): self._chk(hip_lib().rt_mgpu_sync(self._h), "rt_mgpu_sync")
+    def set_balance(self, on): self._chk(hip_lib().rt_mgpu_set_balance(self._h, 1 if on else 0), "rt_mgpu_set_balance")
+    def set_serialize(self, on): self._chk(hip_lib().rt_mgpu_set_serialize(self._h, 1 if on else 0), "rt_mgpu_set_serialize")
+    def stats(self):
+        s = MgpuStats()
+        self._chk(hip_lib().rt_mgpu_get_stats(self._h, C.byref(s)), "rt_mgpu_get_stats")
+        return s
+    def readback(self, buf):
+        W, H = self.size
+        half = buf in (abi.BUF_INDIRECT_RESV0, abi.BUF_INDIRECT_RESV0 + 1, abi.BUF_INDIRECT_RESV0 + 2)
+        elem = {abi.BUF_MOTION: 4, abi.BUF_LIGHT_ID0: 4, abi.BUF_LIGHT_ID0 + 1: 4, abi.BUF_LDR: 4, abi.BUF_DIRECT_RESV0: 36, abi.BUF_DIRECT_RESV0 + 1: 36,
+                abi.BUF_DIRECT_RESV0 + 2: 36, abi.BUF_INDIRECT_RESV0: 76, abi.BUF_INDIRECT_RESV0 + 1: 76, abi.BUF_INDIRECT_RESV0 + 2: 76}.get(buf, 16)
+        n = ((W // 2) * (H // 2) if half else W * H) * elem
+        out = np.empty(n, dtype=np.uint8)
+        self._chk(hip_lib().rt_mgpu_readback(self._h, buf, out.ctypes.data, out.nbytes), "rt_mgpu_readback")
+        return out

@@ -400,6 +400,43 @@ int rt_set_sun_and_sky(rt_ctx* ctx, const rt_sun_and_sky* ss);
  * G-buffers and the motion buffer are invalidated by rt_render_frame (rt_run_stage never rotates buffers).
  * Also settable with RESTIR_OVERLAP=0|1|2 before rt_create. */
 int rt_set_overlap(rt_ctx* ctx, int mode);
+/* ------------------------------------------------------------------------------------------------------------------
+ * Multi-GPU context (csrc/mgpu.cpp): the row-tiled frame of BASELINE.json / SURVEY.md §8(e) for a host that owns all the
+ * GPUs of the node from ONE process — "multi-GPU ctx internally drives 8 streams" (§8b threading row).  One worker thread,
+ * one rt_ctx and one HIP stream per device; halos and history rows move with hipMemcpyPeerAsync over xGMI; band heights
+ * are cost weighted from the ranks' measured stage times.  Call order == the single-GPU context's:
+ *     rt_mgpu_create -> rt_mgpu_upload_scene (upload + BVH8 build on every device) -> rt_mgpu_resize
+ *     per frame: rt_mgpu_set_camera, rt_mgpu_render_frame (returns when the frame is complete on every device)
+ *     rt_mgpu_readback assembles a buffer of the last frame from the ranks that own its rows (same layout as rt_readback).
+ * Every output is bit-identical to the single-GPU frame.  `devices` may name the same device more than once (used by the
+ * tests on a one-GPU machine).  The caller's thread discipline is the reference's: one thread issues the calls.
+ * (One-process-per-GPU hosts use restir_amd/tiled.py over torch.distributed / RCCL instead.)
+ * ---------------------------------------------------------------------------------------------------------------- */
+#define RT_MGPU_MAX_RANKS 16
+typedef struct rt_mgpu rt_mgpu;
+typedef struct {
+  int32_t numRanks;
+  uint32_t frames;                               /* frames rendered since creation */
+  uint32_t historyFallbacks;                     /* frames whose temporal reuse left band + halo (full history pulled, stages re-run) */
+  uint32_t pad;
+  uint64_t haloBytes;                            /* bytes pulled from peers during the last frame, all ranks */
+  int32_t bandBegin[RT_MGPU_MAX_RANKS], bandEnd[RT_MGPU_MAX_RANKS]; /* full-res row range of every rank in the last frame */
+  float tracedMs[RT_MGPU_MAX_RANKS];             /* direct + indirect stage of the last frame, HIP events on the rank's stream */
+  float filterMs[RT_MGPU_MAX_RANKS];             /* 4 + 5 A-Trous passes + compose */
+} rt_mgpu_stats;
+int rt_mgpu_create(rt_mgpu** out, int numRanks, const int* devices /* NULL: devices 0..numRanks-1 */);
+int rt_mgpu_destroy(rt_mgpu* m);
+int rt_mgpu_upload_scene(rt_mgpu* m, const rt_scene_desc* scene);
+int rt_mgpu_resize(rt_mgpu* m, int width, int height);
+int rt_mgpu_set_camera(rt_mgpu* m, const rt_scene_camera* cam);
+int rt_mgpu_render_frame(rt_mgpu* m, const rt_state* state, int frames);
+int rt_mgpu_readback(rt_mgpu* m, int buffer, void* dst, size_t bytes);
+int rt_mgpu_sync(rt_mgpu* m);
+int rt_mgpu_set_balance(rt_mgpu* m, int mode);    /* 1 (default): cost-weighted band heights; 0: equal heights */
+int rt_mgpu_set_serialize(rt_mgpu* m, int on);    /* measurement aid when several ranks share ONE device: ranks take turns on the GPU */
+int rt_mgpu_get_stats(rt_mgpu* m, rt_mgpu_stats* out);
+const char* rt_mgpu_last_error(rt_mgpu* m);
+
 /* Measured VALU issue ceiling of the device the ctx lives on (csrc/microbench.hip): wave-level VALU instructions per second of a
  * chain-free loop.  variant 0 = the instruction mix of the traced kernels, 1 = v_fma_f32 only; wavesPerSimd in 1..8.
  * bench.py prices `roofline.valu` against this measurement instead of an assumed cycles-per-instruction figure.
