@@ -44,8 +44,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-run", action="store_true", help="only the warm-up + K timed frames + the counting pass (for rocprofv3 --pmc / --kernel-trace runs)")
-    ap.add_argument("--emulate-world", type=int, default=0, help="(1 GPU) time ONE rank of an N-way row-tiled frame with communication stubbed out")
-    ap.add_argument("--emulate-rank", type=int, default=-1)
+    ap.add_argument("--emulate-world", type=int, default=0, help="(1 GPU) N ranks of the native row-tiled frame (rt_mgpu_*) on this device, taking turns: per-rank stage times of a chip to itself")
+    ap.add_argument("--equal-bands", action="store_true", help="with --emulate-world: equal-height bands instead of cost-weighted ones")
     ap.add_argument("--cpu-rows", type=int, default=256, help="height of the row band the CPU baseline renders")
     args = ap.parse_args()
 
@@ -92,14 +92,7 @@ def main():
     Frame = tiled.TiledFrame if os.environ.get("RESTIR_TILED") == "serial" else tiled.PipelinedTiledFrame
     frame = Frame(tiled.RendererTensors(r), comm, W, H) if world > 1 else None
     if world == 1 and args.emulate_world > 1:
-        class StubComm(tiled.LocalComm):   # per-rank compute + host overhead of the tiled schedule, no real peers
-            world = args.emulate_world
-            rank = args.emulate_rank if args.emulate_rank >= 0 else args.emulate_world // 2
-            def all_gather_rows(self, *a, **k): return None
-            def halo_exchange(self, items, async_op=False): return []
-            def gather_rows_to(self, *a, **k): return None
-            def any_flag(self, flag): return False
-        frame = Frame(tiled.RendererTensors(r), StubComm(), W, H)
+        return emulate_world(args, abi, host, scene, env, st, desc, r, W, H, local_rank)
 
     scene.updateCamera(W, H)  # prime the camera history (static camera: SURVEY.md §8d)
 
@@ -325,6 +318,57 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def emulate_world(args, abi, host, scene, env, st, desc, single, W, H, device):
+    """Per-rank compute of the N-way row-tiled frame on ONE GPU: the native multi-GPU context with every rank on this device and
+    the ranks taking turns (rt_mgpu_set_serialize), so each rank's HIP-event times are those of a GPU to itself.  Exchanges run
+    as device-to-device copies: their volume is reported, their xGMI time is not measured here.  NOT a benchmark result — the
+    driver measures real scaling; this is the load-balance / critical-path instrument DESIGN.md §7 quotes."""
+    from restir_amd.renderer import MultiGpuRenderer
+    n = args.emulate_world
+    single.update(W, H)
+    scene.updateCamera(W, H)
+    def cam(f):
+        st.time = 1000 + f
+        scene.updateCamera(W, H)
+        return scene.getCamera()
+    # single-GPU reference on the same frames: serial sum of kernels (the quantity the per-rank times are comparable with)
+    single.set_overlap(0)
+    for f in range(args.warmup):
+        single.set_camera(cam(f)); single.run(st, f)
+    single.sync(); single.set_counting(False)
+    for f in range(args.warmup, args.warmup + args.steps):
+        single.set_camera(cam(f)); single.run(st, f)
+    c = single.counters()
+    one = sum(c.stageMs[i] for i in range(5)) / max(1, c.framesTimed)
+    single.destroy()
+    m = MultiGpuRenderer().setup([device] * n)
+    m.load_scene(desc); m.update(W, H)
+    m.set_serialize(True); m.set_balance(not args.equal_bands)
+    scene2 = host.Scene().makeProcedural(abi.PROC_BISTRO_EXT, args.scale, 1)
+    scene2.updateCamera(W, H)
+    acc = np.zeros((n, 2)); halo = 0; bands = None
+    for f in range(args.warmup + args.steps):
+        st.time = 1000 + f
+        scene2.updateCamera(W, H)
+        m.set_camera(scene2.getCamera()); m.run(st, f)
+        if f >= args.warmup:
+            s = m.stats()
+            acc += np.array([[s.tracedMs[r], s.filterMs[r]] for r in range(n)])
+            halo += s.haloBytes
+            bands = [(s.bandBegin[r], s.bandEnd[r]) for r in range(n)]
+    acc /= args.steps
+    tot = acc.sum(axis=1)
+    out = {"metric": "per-rank ms/frame of the N-way row-tiled frame, ranks emulated one at a time on ONE GPU (not a benchmark result)",
+           "n_ranks": n, "steps": args.steps, "warmup": args.warmup, "balance": "equal bands" if args.equal_bands else "cost-weighted bands",
+           "single_gpu_serial_ms": round(one, 4), "rank_ms": [round(float(x), 4) for x in tot], "rank_traced_ms": [round(float(x), 4) for x in acc[:, 0]],
+           "rank_filter_ms": [round(float(x), 4) for x in acc[:, 1]], "bands_last_frame": bands, "slowest_rank_ms": round(float(tot.max()), 4),
+           "max_over_min": round(float(tot.max() / max(1e-6, tot.min())), 3), "projected_speedup_compute_only": round(one / float(tot.max()), 2),
+           "halo_bytes_per_frame": int(halo / args.steps), "fallbacks": m.stats().historyFallbacks}
+    print(json.dumps(out), flush=True)
+    m.destroy()
+    return None
 
 
 def cpu_baseline(abi, host, scene, env, st, desc, W, H, rows, frame0):
