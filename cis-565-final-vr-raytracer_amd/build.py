@@ -18,7 +18,7 @@ HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "
              "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize", "-Wno-unused-result", "-x", "hip"]
 HIP_SRC = ["rt_api.cpp", "mgpu.cpp", "bvh8_builder.cpp", "stages.hip", "wavefront.hip", "stages_sky.hip", "wavefront_sky.hip", "stages_cnt.hip", "stages_sky_cnt.hip", "post.hip", "microbench.hip"]
 HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-pthread"]
-HOST_SRC = ["scene.cpp", "scene_gen.cpp", "hdr_sampling.cpp", "gltf_loader.cpp", "jpeg_decoder.cpp", "host_capi.cpp"]
+HOST_SRC = ["scene.cpp", "scene_gen.cpp", "hdr_sampling.cpp", "gltf_loader.cpp", "jpeg_decoder.cpp", "png_writer.cpp", "host_capi.cpp"]
 
 
 def _stale(target, sources):

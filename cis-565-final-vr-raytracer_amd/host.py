@@ -25,6 +25,7 @@ def host_lib():
         for name, args in {
             "rth_scene_destroy": [C.c_void_p], "rth_scene_load": [C.c_void_p, C.c_char_p],
             "rth_scene_make_procedural": [C.c_void_p, C.c_int, C.c_float, C.c_uint32], "rth_scene_save_gltf": [C.c_void_p, C.c_char_p], "rth_decode_jpeg": [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
+            "rth_decode_png": [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t], "rth_write_png": [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int],
             "rth_scene_set_camera": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float],
             "rth_scene_get_camera_pose": [C.c_void_p, C.c_void_p], "rth_scene_update_camera": [C.c_void_p, C.c_int, C.c_int],
             "rth_scene_get_camera": [C.c_void_p, C.c_void_p], "rth_scene_light_weights": [C.c_void_p, C.c_void_p, C.c_void_p],
@@ -132,5 +133,23 @@ def decode_jpeg(data):
     out = np.empty(64 << 20, dtype=np.uint8)
     rc = host_lib().rth_decode_jpeg(buf.ctypes.data, buf.size, C.byref(w), C.byref(h), out.ctypes.data, out.size)
     if rc != 0:
+        return None
+    return out[: w.value * h.value * 4].reshape(h.value, w.value, 4).copy()
+
+
+def write_png(path, rgba, keep_alpha=False):
+    """host/png_writer.cpp: (H, W, 4) uint8 array, R first (the layout of BUF_LDR) -> 8-bit PNG file."""
+    a = np.ascontiguousarray(rgba, dtype=np.uint8)
+    h, w = a.shape[:2]
+    if host_lib().rth_write_png(path.encode(), a.ctypes.data, w, h, 1 if keep_alpha else 0) != 0:
+        raise IOError(f"cannot write {path}")
+
+
+def decode_png(data):
+    """host/gltf_loader.cpp's PNG reader on a bytes object -> (H, W, 4) uint8 BGRA array, or None."""
+    buf = np.frombuffer(data, dtype=np.uint8)
+    w, h = C.c_int(), C.c_int()
+    out = np.empty(64 << 20, dtype=np.uint8)
+    if host_lib().rth_decode_png(buf.ctypes.data, buf.size, C.byref(w), C.byref(h), out.ctypes.data, out.size) != 0:
         return None
     return out[: w.value * h.value * 4].reshape(h.value, w.value, 4).copy()

@@ -241,6 +241,8 @@ M4 nodeLocalMatrix(const Json& n)
 }
 
 }  // namespace
+// exported for the host C API (PNG round-trip test of host/png_writer.cpp)
+bool decodePngImage(const uint8_t* d, size_t n, TextureImage& img) { return decodePng(d, n, img); }
 
 bool loadGltfFile(const std::string& filename, GltfScene& out, std::string& error)
 {

@@ -6,6 +6,7 @@
 using namespace rth;
 
 namespace rth { bool decodeJpeg(const uint8_t* d, size_t n, TextureImage& img); }  // jpeg_decoder.cpp
+namespace rth { bool decodePngImage(const uint8_t* d, size_t n, TextureImage& img); }   // gltf_loader.cpp
 extern "C" {
 
 void* rth_scene_create() { return new(std::nothrow) Scene(); }
@@ -16,6 +17,16 @@ int rth_decode_jpeg(const uint8_t* data, size_t n, int* w, int* h, uint8_t* out,
 {
   TextureImage t;
   if(!rth::decodeJpeg(data, n, t)) return -1;
+  *w = t.width; *h = t.height;
+  if(t.bgra.size() > cap) return -2;
+  memcpy(out, t.bgra.data(), t.bgra.size());
+  return 0;
+}
+int rth_write_png(const char* path, const uint8_t* rgba, int w, int h, int keepAlpha) { return rth::writePng(path, rgba, w, h, keepAlpha != 0) ? 0 : -1; }
+int rth_decode_png(const uint8_t* data, size_t n, int* w, int* h, uint8_t* out, size_t cap)
+{
+  TextureImage t;
+  if(!rth::decodePngImage(data, n, t)) return -1;
   *w = t.width; *h = t.height;
   if(t.bgra.size() > cap) return -2;
   memcpy(out, t.bgra.data(), t.bgra.size());

@@ -76,7 +76,7 @@ int main(int argc, char** argv)
     pfm << "PF\n" << W << " " << H << "\n-1.0\n";
     for(int y = H - 1; y >= 0; y--) for(int x = 0; x < W; x++) { float c[3]; for(int k = 0; k < 3; k++) c[k] = d[(size_t(y) * W + x) * 4 + k] + i[(size_t(y) * W + x) * 4 + k]; pfm.write(reinterpret_cast<const char*>(c), 12); }
   }
-  {  // the displayed frame: RenderOutput::run (post.frag: Uncharted 2 tone curve + dither) -> PPM
+  {  // the displayed frame: RenderOutput::run (post.frag: Uncharted 2 tone curve + dither) -> PPM + PNG
     RenderOutput offscreen;
     offscreen.setup(render.context());
     offscreen.create(W, H);
@@ -86,6 +86,7 @@ int main(int argc, char** argv)
     std::ofstream ppm(out + ".ppm", std::ios::binary);
     ppm << "P6\n" << W << " " << H << "\n255\n";
     for(size_t p = 0; p < size_t(W) * H; p++) ppm.write(reinterpret_cast<const char*>(&rgba[p * 4]), 3);
+    if(!writePng(out + ".png", rgba.data(), W, H)) fprintf(stderr, "cannot write %s.png\n", out.c_str());
   }
   render.destroy();
   return 0;

@@ -41,6 +41,9 @@ struct GltfLight {  // KHR_lights_punctual
   int type = 1;  // LightType_Point (host_device.h:252-254)
 };
 struct GltfCamera { V3 eye{0, 0, 1}, center{0, 0, 0}, up{0, 1, 0}; float yfovDeg = 45.f; };
+// host/png_writer.cpp: the displayed frame (RT_BUF_LDR, R first) as an 8-bit PNG
+bool encodePng(const uint8_t* rgba, int width, int height, bool keepAlpha, std::vector<uint8_t>& out);
+bool writePng(const std::string& path, const uint8_t* rgba, int width, int height, bool keepAlpha = false);
 struct TextureImage { int width = 1, height = 1; std::vector<uint8_t> bgra; int wrapS = RT_WRAP_REPEAT, wrapT = RT_WRAP_REPEAT, magFilter = RT_FILTER_LINEAR; };
 
 // nvh::GltfScene stand-in: flattened arrays shared by all primitive meshes

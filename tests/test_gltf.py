@@ -236,3 +236,31 @@ def test_gltf_with_16bit_png_texture(tmp_path):
     d = dump(_load(tmp_path / "p16.gltf"))
     assert (d["textures"][3]["width"], d["textures"][3]["height"]) == (w, h)
     assert np.array_equal(d["texels"][3][:, [2, 1, 0]], (v >> 8).astype(np.uint8).reshape(-1, 3)) and (d["texels"][3][:, 3] == 255).all()
+
+
+def test_png_writer_round_trip(tmp_path):
+    """host/png_writer.cpp (the displayed frame) read back by the loader's own PNG reader and by an independent zlib parse"""
+    import struct, zlib
+    rng = np.random.default_rng(5)
+    for (h, w, alpha) in [(1, 1, False), (7, 13, True), (64, 48, False)]:
+        img = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+        p = str(tmp_path / f"t{h}x{w}.png")
+        host.write_png(p, img, keep_alpha=alpha)
+        data = open(p, "rb").read()
+        assert data[:8] == b"\x89PNG\r\n\x1a\n"
+        # independent parse: chunks + CRCs + inflate + filter 0
+        pos, idat, ihdr = 8, b"", None
+        while pos < len(data):
+            n, typ = struct.unpack(">I4s", data[pos:pos + 8])
+            body = data[pos + 8:pos + 8 + n]
+            assert struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(typ + body)
+            if typ == b"IHDR": ihdr = struct.unpack(">IIBBBBB", body)
+            if typ == b"IDAT": idat += body
+            pos += 12 + n
+        ch = 4 if alpha else 3
+        assert ihdr == (w, h, 8, 6 if alpha else 2, 0, 0, 0)
+        raw = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(h, 1 + w * ch)
+        assert (raw[:, 0] == 0).all() and np.array_equal(raw[:, 1:].reshape(h, w, ch), img[..., :ch])
+        back = host.decode_png(data)                       # BGRA
+        assert back is not None and np.array_equal(back[..., [2, 1, 0]], img[..., :3])
+        if alpha: assert np.array_equal(back[..., 3], img[..., 3])
