@@ -80,6 +80,7 @@ struct DevFrame {
   float4* geomN; float4* geomP; float4* geomNh; float4* geomPh;
   rt_direct_reservoir* tempDirectResv;  // RT_BUF_DIRECT_RESV_TEMP: cacheTempReservoir target of the spatial reuse (direct_stage.comp:127-129)
   double* postRowSums; float* postMean;  // rt_tonemap: per-row colour sums [2][H][3], image means [2][4]
+  float4* postMipD; float4* postMipI;    // rt_tonemap: mip levels 1..7 of the two result images (toneLocalExposure)
   uint32_t* tileOrder;              // 8 per-XCD lists of half-res tile ids, longest (multi-bounce) first
   int32_t W, H;
   // rows of the LAST-frame buffers that are valid on this GPU (row-tiled multi-GPU: own band + received halos).  A temporal

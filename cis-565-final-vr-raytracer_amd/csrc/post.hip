@@ -1,9 +1,12 @@
 // post.hip — the display pass: shaders/post.frag:103-175 + tonemapping.glsl:25-105 as compute kernels writing RGBA8.
 //   k_post_rowsum / k_post_mean  image mean for auto-exposure (stands in for textureLod(.., 20) on the mip pyramid that
 //                                RenderOutput::genMipmap builds, render_output.cpp:243-254)
+//   k_post_mip                   one level of the mip pyramid RenderOutput::genMipmap blits (linear filter), levels 1..7 of both result images:
+//                                toneLocalExposure (post.frag:70-101, autoExposure bit 1) samples them
 //   k_tonemap                    one thread per output pixel
 // Arithmetic follows include/rt_detmath.h (rt_pow for every pow) and the left-to-right evaluation rule, like every other stage.
 #include "stage_common.h"
+#include <algorithm>
 
 namespace rt {
 
@@ -34,6 +37,35 @@ __global__ void k_post_mean(const double* rowSums, int W, int H, float* mean /* 
   mean[img * 4 + ch] = float(t / (double(W) * double(H)));
 }
 
+// vkCmdBlitImage with VK_FILTER_LINEAR from a (sw x sh) level to a (dw x dh) level, as nvvk::cmdGenerateMipmaps records it
+// (render_output.cpp:243-254): the destination texel centre maps to the source coordinate (x + 0.5) * sw / dw, which is then sampled with
+// a clamped bilinear filter.  For even sizes this is the 2 x 2 box average.  The arithmetic order is fixed.
+struct MipLevels { const float4* img[8]; int w[8], h[8]; };   // level 0 = the result image itself
+RT_DEV float4 bilinearClamp(const float4* src, int sw, int sh, float fx, float fy)
+{
+  const float x0f = rt_floor(fx), y0f = rt_floor(fy);
+  const float ax = fx - x0f, ay = fy - y0f;
+  const int x0 = rt_ftoi(x0f), y0 = rt_ftoi(y0f);
+  const int xa = min(max(x0, 0), sw - 1), xb = min(max(x0 + 1, 0), sw - 1), ya = min(max(y0, 0), sh - 1), yb = min(max(y0 + 1, 0), sh - 1);
+  const float4 a = src[size_t(ya) * sw + xa], b = src[size_t(ya) * sw + xb], c = src[size_t(yb) * sw + xa], d = src[size_t(yb) * sw + xb];
+  auto mx = [](float p, float q, float t) { return p * (1.0f - t) + q * t; };
+  return make_float4(mx(mx(a.x, b.x, ax), mx(c.x, d.x, ax), ay), mx(mx(a.y, b.y, ax), mx(c.y, d.y, ax), ay), mx(mx(a.z, b.z, ax), mx(c.z, d.z, ax), ay),
+                     mx(mx(a.w, b.w, ax), mx(c.w, d.w, ax), ay));
+}
+__global__ __launch_bounds__(256) void k_post_mip(const float4* src, int sw, int sh, float4* dst, int dw, int dh)
+{
+  const int x = int(blockIdx.x * 64 + (threadIdx.x & 63)), y = int(blockIdx.y * 4 + (threadIdx.x >> 6));
+  if(x >= dw || y >= dh) return;
+  const float fx = (float(x) + 0.5f) * (float(sw) / float(dw)) - 0.5f, fy = (float(y) + 0.5f) * (float(sh) / float(dh)) - 0.5f;
+  dst[size_t(y) * dw + x] = bilinearClamp(src, sw, sh, fx, fy);
+}
+// texture(img, uv, bias = level): the level's bilinear sample at the fragment's uv (the display is 1:1, so the implicit LOD is 0)
+RT_DEV f3 sampleLevel(const MipLevels& M, int level, float u, float v)
+{
+  const float4 t = bilinearClamp(M.img[level], M.w[level], M.h[level], u * float(M.w[level]) - 0.5f, v * float(M.h[level]) - 0.5f);
+  return mk3(t.x, t.y, t.z);
+}
+
 RT_DEV f3 pow3(f3 c, float e) { return mk3(rt_pow(c.x, e), rt_pow(c.y, e), rt_pow(c.z, e)); }
 RT_DEV f3 linearTosRGB(f3 c) { return pow3(c, 1.0f / 2.2f); }  // tonemapping.glsl:25-33
 RT_DEV f3 sRGBToLinear(f3 c) { return pow3(c, 2.2f); }         // :37-40
@@ -56,6 +88,29 @@ RT_DEV f3 toneExposure(const rt_tonemapper& tm, f3 RGB, float logAvgLum)        
   const float Yd = (Y * (1.0f + Y / (tm.Ywhite * tm.Ywhite))) / (1.0f + Y);
   return RGB / XYZy * Yd;
 }
+// toneLocalExposure, post.frag:70-101.  v1 / v2 are the luminances of two consecutive pyramid levels at the fragment.  In the default view the
+// reference's `v2 == luminance(...)` (a comparison, :91) leaves v2 undefined; undefined values are 0 here, so the
+// adaptation luminance is the first v1 that clears the threshold, else 0.  The two single-image views assign v2 properly.
+RT_DEV f3 toneLocalExposure(const rt_tonemapper& tm, int dbg, const MipLevels& MD, const MipLevels& MI, float u, float v, f3 RGB, float logAvgLum)
+{
+  const float XYZy = (0.3575761f * RGB.x + 0.7151522f * RGB.y) + 0.1191920f * RGB.z;
+  const float Y = (tm.key / logAvgLum) * XYZy;
+  const float factor = tm.key / logAvgLum;
+  const float epsilon = 0.05f, phi = 2.0f;
+  float La = 0.0f;
+  float scale = 1.0f;
+  for(int i = 0; i < 7; ++i) {
+    float v1, v2 = 0.0f;
+    if(dbg == RT_DBG_DIRECT_STAGE) { v1 = postLuminance(sampleLevel(MD, i, u, v)) * factor; v2 = postLuminance(sampleLevel(MD, i + 1, u, v)) * factor; }
+    else if(dbg == RT_DBG_INDIRECT_STAGE) { v1 = postLuminance(sampleLevel(MI, i, u, v)) * factor; v2 = postLuminance(sampleLevel(MI, i + 1, u, v)) * factor; }
+    else v1 = postLuminance(sampleLevel(MD, i, u, v) + sampleLevel(MI, i, u, v)) * factor;
+    if(rt_abs(v1 - v2) / ((tm.key * rt_pow(2.0f, phi) / (scale * scale)) + v1) > epsilon) { La = v1; break; }
+    La = v2;
+    scale = scale * 2.0f;
+  }
+  const float Yd = Y / (1.0f + La);
+  return RGB / XYZy * Yd;
+}
 RT_DEV f3 ditherColor(f3 linear, f3 noise, float quant)  // post.frag:50-55
 {
   const f3 s = linearTosRGB(linear) / quant;
@@ -67,7 +122,8 @@ RT_DEV f3 ditherColor(f3 linear, f3 noise, float quant)  // post.frag:50-55
 }
 RT_DEV uint32_t toUnorm8(float c) { return rt_ftou(rt_floor(rt_clamp(c, 0.0f, 1.0f) * 255.0f + 0.5f)); }
 
-__global__ __launch_bounds__(256) void k_tonemap(const float4* direct, const float4* indirect, const float* mean, rt_tonemapper tm, int dbg, int W, int H, uint32_t* ldr)
+__global__ __launch_bounds__(256) void k_tonemap(const float4* direct, const float4* indirect, const float* mean, rt_tonemapper tm, int dbg, int W, int H, uint32_t* ldr,
+                                                 MipLevels MD, MipLevels MI)
 {
   const int x = int(blockIdx.x * 64 + (threadIdx.x & 63)), y = int(blockIdx.y * 4 + (threadIdx.x >> 6));
   if(x >= W || y >= H) return;
@@ -89,7 +145,8 @@ __global__ __launch_bounds__(256) void k_tonemap(const float4* direct, const flo
     if(tm.autoExposure & 1) {  // :133-153
       const f3 aD = mk3(mean[0], mean[1], mean[2]), aI = mk3(mean[4], mean[5], mean[6]);
       const f3 avg = (dbg == RT_DBG_DIRECT_STAGE) ? aD : (dbg == RT_DBG_INDIRECT_STAGE) ? aI : aD + aI;
-      hdr = toneExposure(tm, hdr, postLuminance(avg));
+      const float avgLum2 = postLuminance(avg);
+      hdr = (tm.autoExposure & 2) ? toneLocalExposure(tm, dbg, MD, MI, u * tm.zoom, v * tm.zoom, hdr, avgLum2) : toneExposure(tm, hdr, avgLum2);
     }
     color = toneMapUncharted(hdr * tm.avgLum);  // toneMap(), tonemapping.glsl:89-105 with TONEMAP_UNCHARTED
     uint32_t rx = uint32_t(x) * 1664525u + 1013904223u, ry = uint32_t(y) * 1664525u + 1013904223u, rz = 1013904223u;  // pcg3d, random.glsl:81-92
@@ -147,13 +204,29 @@ hipError_t launchPick(hipStream_t stream, const DevScene& S, const rt_mat4& view
 }
 
 hipError_t launchTonemap(hipStream_t stream, const float4* direct, const float4* indirect, double* rowSums, float* mean, const rt_tonemapper& tm, int dbg, int W, int H,
-                         uint32_t* ldr)
+                         uint32_t* ldr, float4* mipD, float4* mipI)
 {
   if(tm.autoExposure & 1) {
     hipLaunchKernelGGL(k_post_rowsum, dim3(unsigned(2 * H)), dim3(64), 0, stream, direct, indirect, W, H, rowSums);
     hipLaunchKernelGGL(k_post_mean, dim3(1), dim3(64), 0, stream, (const double*)rowSums, W, H, mean);
   }
-  hipLaunchKernelGGL(k_tonemap, dim3(unsigned((W + 63) / 64), unsigned((H + 3) / 4)), dim3(256), 0, stream, direct, indirect, (const float*)mean, tm, dbg, W, H, ldr);
+  MipLevels MD{}, MI{};
+  MD.img[0] = direct; MI.img[0] = indirect; MD.w[0] = MI.w[0] = W; MD.h[0] = MI.h[0] = H;
+  if((tm.autoExposure & 3) == 3 && mipD && mipI) {   // RenderOutput::genMipmap: levels 1..7 of both images, each from the one above
+    float4* pd = mipD; float4* pi = mipI;
+    for(int l = 1; l < 8; l++) {
+      const int w = std::max(1, MD.w[l - 1] / 2), h = std::max(1, MD.h[l - 1] / 2);
+      MD.w[l] = MI.w[l] = w; MD.h[l] = MI.h[l] = h;
+      const dim3 g(unsigned((w + 63) / 64), unsigned((h + 3) / 4));
+      hipLaunchKernelGGL(k_post_mip, g, dim3(256), 0, stream, MD.img[l - 1], MD.w[l - 1], MD.h[l - 1], pd, w, h);
+      hipLaunchKernelGGL(k_post_mip, g, dim3(256), 0, stream, MI.img[l - 1], MI.w[l - 1], MI.h[l - 1], pi, w, h);
+      MD.img[l] = pd; MI.img[l] = pi;
+      pd += size_t(w) * h; pi += size_t(w) * h;
+    }
+  } else {
+    for(int l = 1; l < 8; l++) { MD.img[l] = direct; MI.img[l] = indirect; MD.w[l] = MI.w[l] = W; MD.h[l] = MI.h[l] = H; }
+  }
+  hipLaunchKernelGGL(k_tonemap, dim3(unsigned((W + 63) / 64), unsigned((H + 3) / 4)), dim3(256), 0, stream, direct, indirect, (const float*)mean, tm, dbg, W, H, ldr, MD, MI);
   return hipGetLastError();
 }
 

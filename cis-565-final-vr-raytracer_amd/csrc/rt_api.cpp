@@ -494,6 +494,7 @@ int rt_resize(rt_ctx* c, int w, int h)
   RT_SCRATCH(qC[0], nh, uint32_t); RT_SCRATCH(qC[1], nh, uint32_t); RT_SCRATCH(qA, nh, uint32_t); RT_SCRATCH(qcount, 256, uint32_t);
   RT_SCRATCH(geomN, n, float4); RT_SCRATCH(geomP, n, float4); RT_SCRATCH(geomNh, nh, float4); RT_SCRATCH(geomPh, nh, float4);
   RT_SCRATCH(postRowSums, size_t(h) * 6, double); RT_SCRATCH(postMean, 8, float);
+  RT_SCRATCH(postMipD, n + 64, float4); RT_SCRATCH(postMipI, n + 64, float4);   // levels 1..7 (n/3 texels; up to n for one-pixel-wide images)
   RT_SCRATCH(tileOrder, (size_t(w / 2 + 7) / 8) * (size_t(h / 2 + 7) / 8 + 16 * 2) + 64, uint32_t);
 #undef RT_SCRATCH
   RT_HIP(c, hipDeviceSynchronize());  // memsets above ran on the null stream; the ctx stream does not wait for it implicitly
@@ -826,7 +827,8 @@ int rt_tonemap(rt_ctx* c, const rt_tonemapper* tm, int debugging_mode, int frame
   RT_HIP(c, joinInFlight(c));  // the result images of `frames` are complete once compose (side stream) is done
   const int cur = frames & 1;
   RT_HIP(c, launchTonemap(c->stream, static_cast<const float4*>(c->bufs[RT_BUF_DIRECT_RESULT0 + cur]), static_cast<const float4*>(c->bufs[RT_BUF_INDIRECT_RESULT0 + cur]),
-                          c->scratch.postRowSums, c->scratch.postMean, *tm, debugging_mode, c->W, c->H, static_cast<uint32_t*>(c->bufs[RT_BUF_LDR])));
+                          c->scratch.postRowSums, c->scratch.postMean, *tm, debugging_mode, c->W, c->H, static_cast<uint32_t*>(c->bufs[RT_BUF_LDR]),
+                          c->scratch.postMipD, c->scratch.postMipI));
   return RT_OK;
 }
 

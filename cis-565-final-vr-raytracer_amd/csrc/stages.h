@@ -26,5 +26,5 @@ hipError_t launchPick(hipStream_t stream, const DevScene& S, const rt_mat4& view
 // csrc/microbench.hip
 hipError_t measureValuIssue(hipStream_t stream, int variant, int wavesPerSimd, double* waveInstPerSec, double* seconds);
 hipError_t launchTonemap(hipStream_t stream, const float4* direct, const float4* indirect, double* rowSums, float* mean, const rt_tonemapper& tm, int dbg, int W, int H,
-                         uint32_t* ldr);
+                         uint32_t* ldr, float4* mipD, float4* mipI);
 }

@@ -372,8 +372,10 @@ int rt_rotate_buffers(rt_ctx* ctx, int frames);
  * mean, post.frag:133-153), the Uncharted-2 tone curve (tonemapping.glsl:48-66), dithering (post.frag:50-55), contrast /
  * brightness / saturation / vignette (post.frag:163-171) or the debug views (post.frag:106-118) and writes RT_BUF_LDR.
  * Differences from the fragment shader, all documented in DESIGN.md: the image mean replaces the driver-generated mip
- * pyramid's top level; tm.zoom samples the nearest texel; the "local" auto-exposure bit (autoExposure & 2, which reads an
- * uninitialised variable in the reference, post.frag:92) uses the global operator. */
+ * pyramid's top level; tm.zoom samples the nearest texel.  The "local" auto-exposure bit (autoExposure & 2, toneLocalExposure,
+ * post.frag:70-101) samples mip levels 0..7 of the two result images: the pyramid is built level by level with the linear-blit
+ * formula of RenderOutput::genMipmap (render_output.cpp:243-254; 2x2 box for even sizes) and sampled bilinearly at the fragment;
+ * the variable the reference leaves uninitialised in the default view (`v2 ==` at post.frag:91) is 0. */
 int rt_tonemap(rt_ctx* ctx, const rt_tonemapper* tm, int debugging_mode, int frames);
 int rt_set_pipeline(rt_ctx* ctx, int pipeline);
 /* SampleExample::screenPicking (sample_example.cpp:456-497): nvvk::RayPickerKHR — one camera ray through the normalised

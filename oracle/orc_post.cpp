@@ -5,8 +5,8 @@
 //   src/render_output.cpp      :224-254 RenderOutput::run / genMipmap
 // PARITY UNPINNED for this file: the reference draws this pass with a fragment shader into a swapchain (needs a Vulkan
 // device + glslang); no golden image exists.  Restated choices that the reference leaves to the driver are listed in
-// include/rt_abi.h at rt_tonemap (image mean for the top mip level, nearest texel for tm.zoom, global operator for the
-// "local" bit).  The pass's pure helpers ARE pinned by vectors minted from the GLSL itself (tests/test_kat_float.py): pcg3d,
+// include/rt_abi.h at rt_tonemap (image mean for the top mip level, nearest texel for tm.zoom, the blit formula of the
+// mip levels the "local" auto-exposure bit samples).  The pass's pure helpers ARE pinned by vectors minted from the GLSL itself (tests/test_kat_float.py): pcg3d,
 // toneExposure and the dither step bit-exactly, toneMapUncharted to 1 ulp; main()'s sequence is restated.
 #include "orc_stages.h"
 
@@ -81,6 +81,59 @@ static vec3 imageMean(const std::vector<float>& img, int W, int H)
   return {float(tot[0] / n), float(tot[1] / n), float(tot[2] / n)};
 }
 
+// RenderOutput::genMipmap (render_output.cpp:243-254): vkCmdBlitImage with VK_FILTER_LINEAR level by level — the destination texel centre
+// maps to (x + 0.5) * sw / dw in the source, sampled with a clamped bilinear filter (2 x 2 box average for even sizes)
+struct Mip { std::vector<float> img; int w = 0, h = 0; };
+static vec4 bilinearClamp(const float* src, int sw, int sh, float fx, float fy)
+{
+  const float x0f = rt_floor(fx), y0f = rt_floor(fy);
+  const float ax = fx - x0f, ay = fy - y0f;
+  const int x0 = rt_ftoi(x0f), y0 = rt_ftoi(y0f);
+  const int xa = std::min(std::max(x0, 0), sw - 1), xb = std::min(std::max(x0 + 1, 0), sw - 1), ya = std::min(std::max(y0, 0), sh - 1), yb = std::min(std::max(y0 + 1, 0), sh - 1);
+  auto px = [&](int x, int y) { const float* p = src + (size_t(y) * sw + x) * 4; return vec4{p[0], p[1], p[2], p[3]}; };
+  return mix(mix(px(xa, ya), px(xb, ya), ax), mix(px(xa, yb), px(xb, yb), ax), ay);
+}
+static void buildMips(const std::vector<float>& img, int W, int H, Mip (&M)[8])
+{
+  M[0].w = W; M[0].h = H;   // level 0 is read from `img` directly
+  for(int l = 1; l < 8; l++) {
+    const int sw = M[l - 1].w, sh = M[l - 1].h, w = std::max(1, sw / 2), h = std::max(1, sh / 2);
+    const float* src = l == 1 ? img.data() : M[l - 1].img.data();
+    M[l].w = w; M[l].h = h; M[l].img.resize(size_t(w) * h * 4);
+    for(int y = 0; y < h; y++)
+      for(int x = 0; x < w; x++) {
+        const vec4 t = bilinearClamp(src, sw, sh, (float(x) + 0.5f) * (float(sw) / float(w)) - 0.5f, (float(y) + 0.5f) * (float(sh) / float(h)) - 0.5f);
+        float* o = &M[l].img[(size_t(y) * w + x) * 4]; o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+      }
+  }
+}
+static vec3 sampleLevel(const std::vector<float>& img, const Mip (&M)[8], int level, float u, float v)
+{
+  const float* src = level == 0 ? img.data() : M[level].img.data();
+  return xyz(bilinearClamp(src, M[level].w, M[level].h, u * float(M[level].w) - 0.5f, v * float(M[level].h) - 0.5f));
+}
+// toneLocalExposure, post.frag:70-101 (v2 of the default view is undefined in the reference — `==` instead of `=` at :91 — and 0 here)
+static vec3 toneLocalExposure(const rt_tonemapper& tm, int dbg, const std::vector<float>& D, const Mip (&MD)[8], const std::vector<float>& I, const Mip (&MI)[8], float u, float v,
+                              vec3 RGB, float logAvgLum)
+{
+  const float XYZy = (0.3575761f * RGB.x + 0.7151522f * RGB.y) + 0.1191920f * RGB.z;
+  const float Y = (tm.key / logAvgLum) * XYZy;
+  const float factor = tm.key / logAvgLum;
+  const float epsilon = 0.05f, phi = 2.0f;
+  float La = 0.0f, scale = 1.0f;
+  for(int i = 0; i < 7; ++i) {
+    float v1, v2 = 0.0f;
+    if(dbg == RT_DBG_DIRECT_STAGE) { v1 = lumPost(sampleLevel(D, MD, i, u, v)) * factor; v2 = lumPost(sampleLevel(D, MD, i + 1, u, v)) * factor; }
+    else if(dbg == RT_DBG_INDIRECT_STAGE) { v1 = lumPost(sampleLevel(I, MI, i, u, v)) * factor; v2 = lumPost(sampleLevel(I, MI, i + 1, u, v)) * factor; }
+    else v1 = lumPost(sampleLevel(D, MD, i, u, v) + sampleLevel(I, MI, i, u, v)) * factor;
+    if(rt_abs(v1 - v2) / ((tm.key * rt_pow(2.0f, phi) / (scale * scale)) + v1) > epsilon) { La = v1; break; }
+    La = v2;
+    scale = scale * 2.0f;
+  }
+  const float Yd = Y / (1.0f + La);
+  return (RGB / XYZy) * Yd;
+}
+
 static inline uint32_t unorm8(float c) { return rt_ftou(rt_floor(rt_clamp(c, 0.0f, 1.0f) * 255.0f + 0.5f)); }
 
 void Frame::tonemap(const rt_tonemapper& tm, int dbg, int frames)
@@ -90,6 +143,9 @@ void Frame::tonemap(const rt_tonemapper& tm, int dbg, int frames)
   const std::vector<float>& I = indirectResult[cur];
   vec3 avgD{0, 0, 0}, avgI{0, 0, 0};
   if(tm.autoExposure & 1) { avgD = imageMean(D, W, H); avgI = imageMean(I, W, H); }
+  Mip MD[8], MI[8];
+  const bool local = (tm.autoExposure & 3) == 3;
+  if(local) { buildMips(D, W, H, MD); buildMips(I, W, H, MI); }
   parallelRows(H, 0, 0, [&](int y) {
     for(int x = 0; x < W; x++) {
       const float u = (float(x) + 0.5f) / float(W), v = (float(y) + 0.5f) / float(H);  // passthrough.vert: uv at the fragment centre
@@ -110,7 +166,7 @@ void Frame::tonemap(const rt_tonemapper& tm, int dbg, int frames)
         vec3 hdr = dbg == RT_DBG_DIRECT_STAGE ? xyz(d) : (dbg == RT_DBG_INDIRECT_STAGE ? xyz(in) : xyz(d) + xyz(in));
         if(tm.autoExposure & 1) {
           vec3 avg = dbg == RT_DBG_DIRECT_STAGE ? avgD : (dbg == RT_DBG_INDIRECT_STAGE ? avgI : avgD + avgI);
-          hdr = toneExposure(tm, hdr, lumPost(avg));
+          hdr = local ? toneLocalExposure(tm, dbg, D, MD, I, MI, u * tm.zoom, v * tm.zoom, hdr, lumPost(avg)) : toneExposure(tm, hdr, lumPost(avg));
         }
         color = toneMapUncharted(hdr * tm.avgLum);
         uint32_t r[3] = {uint32_t(x), uint32_t(y), 0u};  // uvec3(gl_FragCoord.xy, 0): x+0.5 truncates to x

@@ -16,6 +16,49 @@ def _pcg3d(x, y):
     return [((c >> np.uint64(9)).astype(np.uint32) | np.uint32(0x3f800000)).view(np.float32).astype(np.float64) - 1.0 for c in v]
 
 
+def _bilinear(img, fx, fy):
+    h, w = img.shape[:2]
+    x0, y0 = np.floor(fx), np.floor(fy)
+    ax, ay = (fx - x0)[..., None], (fy - y0)[..., None]
+    xa, xb = np.clip(x0, 0, w - 1).astype(int), np.clip(x0 + 1, 0, w - 1).astype(int)
+    ya, yb = np.clip(y0, 0, h - 1).astype(int), np.clip(y0 + 1, 0, h - 1).astype(int)
+    top = img[ya, xa] * (1 - ax) + img[ya, xb] * ax
+    bot = img[yb, xa] * (1 - ax) + img[yb, xb] * ax
+    return top * (1 - ay) + bot * ay
+
+
+def _mips(img):
+    """vkCmdBlitImage, linear filter, level by level (render_output.cpp:243-254)"""
+    levels = [img[..., :3].astype(np.float64)]
+    for _ in range(7):
+        src = levels[-1]
+        sh, sw = src.shape[:2]
+        w, h = max(1, sw // 2), max(1, sh // 2)
+        ys, xs = np.mgrid[0:h, 0:w]
+        levels.append(_bilinear(src, (xs + 0.5) * (sw / w) - 0.5, (ys + 0.5) * (sh / h) - 0.5))
+    return levels
+
+
+def _local_adaptation(D, I, tm, dbg, factor):
+    H, W, _ = D.shape
+    ys, xs = np.mgrid[0:H, 0:W]
+    u, v = (xs + 0.5) / W * tm.zoom, (ys + 0.5) / H * tm.zoom
+    MD, MI = _mips(D), _mips(I)
+    lw = np.array([0.2126, 0.7152, 0.0722])
+    def lum(levels, i):
+        h, w = levels[i].shape[:2]
+        return _bilinear(levels[i], u * w - 0.5, v * h - 0.5) @ lw
+    La = np.zeros((H, W)); done = np.zeros((H, W), bool)
+    for i in range(7):
+        if dbg == 1: v1, v2 = lum(MD, i) * factor, lum(MD, i + 1) * factor
+        elif dbg == 2: v1, v2 = lum(MI, i) * factor, lum(MI, i + 1) * factor
+        else: v1, v2 = (lum(MD, i) + lum(MI, i)) * factor, np.zeros((H, W))   # `v2 ==` at post.frag:91: undefined, 0 in this build
+        hit = (np.abs(v1 - v2) / (tm.key * 4.0 / (2.0 ** i) ** 2 + v1) > 0.05) & ~done
+        La = np.where(hit, v1, np.where(done, La, v2))
+        done |= hit
+    return La
+
+
 def reference_tonemap(D, I, tm, dbg=0):
     """float64 numpy restatement written from the GLSL, not from the oracle."""
     H, W, _ = D.shape
@@ -25,7 +68,10 @@ def reference_tonemap(D, I, tm, dbg=0):
         lum = avg @ np.array([0.2126, 0.7152, 0.0722])
         Yxyz = hdr @ np.array([0.3575761, 0.7151522, 0.1191920])
         Y = tm.key / lum * Yxyz
-        Yd = Y * (1 + Y / (tm.Ywhite * tm.Ywhite)) / (1 + Y)
+        if tm.autoExposure & 2:      # toneLocalExposure (post.frag:70-101) over the blitted mip pyramid
+            Yd = Y / (1 + _local_adaptation(D, I, tm, dbg, tm.key / lum))
+        else:
+            Yd = Y * (1 + Y / (tm.Ywhite * tm.Ywhite)) / (1 + Y)
         with np.errstate(divide="ignore", invalid="ignore"):
             hdr = hdr / Yxyz[..., None] * Yd[..., None]
     def impl(c):
