@@ -1,4 +1,4 @@
-"""Full-size parity of ALL 12 dispatches against the oracle, warm history, BASELINE configs 3 and 4.
+"""Full-size parity of ALL 12 dispatches against the oracle, warm history, BASELINE configs 3, 4 and 5.
 
 The oracle cannot render 1080p frames of a multi-million-triangle scene in seconds, but it can render row ranges
 (`run_stage(..., rowBegin, rowEnd)`).  For a 16-row band of frame f the test feeds the oracle what the frame consumes —
@@ -20,7 +20,6 @@ import pytest
 from helpers import abi, host, make_scene
 
 pytestmark = pytest.mark.gpu
-W, H = 1920, 1080
 BAND = 16
 
 
@@ -28,7 +27,7 @@ def _clip(a, b, n):
     return max(0, a), min(n, b)
 
 
-def oracle_band(o, st, f, y0, y1):
+def oracle_band(o, st, f, y0, y1, W, H):
     """run on the oracle every row range the 16-row band [y0, y1) of frame f depends on (see module docstring)"""
     Hh = H // 2
     h0, h1 = y0 // 2, (y1 + 1) // 2
@@ -47,7 +46,7 @@ def oracle_band(o, st, f, y0, y1):
     return h0, h1
 
 
-def compare_band(got, o, f, y0, y1, h0, h1):
+def compare_band(got, o, f, y0, y1, h0, h1, W, H):
     cur = f & 1
     full = [(abi.BUF_GBUFFER0 + cur, 16), (abi.BUF_MOTION, 4), (abi.BUF_DIRECT_RESV0 + cur, 36), (abi.BUF_LIGHT_ID0 + cur, 4),
             (abi.BUF_DIRECT_RESULT0 + cur, 16), (abi.BUF_INDIRECT_RESULT0 + cur, 16), (abi.BUF_DENOISE_DIR_A, 16)]
@@ -65,7 +64,7 @@ def compare_band(got, o, f, y0, y1, h0, h1):
     assert np.array_equal(g, r), f"frame {f} half rows {h0}..{h1} filtered indirect colour"
 
 
-def run_config(kind, scale, env_size, tweak, nframes, moving, bands_seed, tri_range):
+def run_config(kind, scale, env_size, tweak, nframes, moving, bands_seed, tri_range, W=1920, H=1080, orbit_deg=0.0):
     from restir_amd.renderer import Renderer
     from oracle.binding import Oracle
     sc, env = make_scene(kind, scale, 1, env_size)
@@ -75,8 +74,13 @@ def run_config(kind, scale, env_size, tweak, nframes, moving, bands_seed, tri_ra
     eye, center, up, fov = sc.cameraPose()
     cams = []
     sc.updateCamera(W, H)
+    rel = eye - center
     for f in range(nframes):
-        if moving:
+        if orbit_deg:      # the camera orbits its centre of interest
+            a = np.deg2rad(orbit_deg * (f + 1))
+            rot = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], dtype=np.float32)
+            sc.setCamera(center + rot @ rel, center, up, fov)
+        elif moving:
             sc.setCamera(eye + np.array([0.06 * f, 0.015 * f, -0.05 * f], dtype=np.float32), center, up, fov)
         sc.updateCamera(W, H); cams.append(sc.getCamera())
     prev = os.environ.get("RESTIR_OVERLAP")
@@ -101,7 +105,7 @@ def run_config(kind, scale, env_size, tweak, nframes, moving, bands_seed, tri_ra
     r.destroy()
     img = got[abi.BUF_DIRECT_RESULT0 + cur].view(np.float32)
     assert np.isfinite(img).all() and img.max() > 0.01
-    if moving:
+    if moving or orbit_deg:
         mv = got[abi.BUF_MOTION].view(np.int16).reshape(H, W, 2)
         assert (mv[..., 0] != np.arange(W)[None, :]).mean() > 0.2       # reprojection is not the identity
     o = Oracle(0); o.upload_scene(desc); o.resize(W, H)
@@ -112,8 +116,8 @@ def run_config(kind, scale, env_size, tweak, nframes, moving, bands_seed, tri_ra
     bands = sorted(int(2 * rng.integers(0, (H - BAND) // 2)) for _ in range(3))
     warm = 0
     for y0 in bands:
-        h0, h1 = oracle_band(o, st, f_last, y0, y0 + BAND)
-        compare_band(got, o, f_last, y0, y0 + BAND, h0, h1)
+        h0, h1 = oracle_band(o, st, f_last, y0, y0 + BAND, W, H)
+        compare_band(got, o, f_last, y0, y0 + BAND, h0, h1, W, H)
         resv = got[abi.BUF_DIRECT_RESV0 + cur].view(np.uint32).reshape(H, W, 9)[y0:y0 + BAND]
         warm += int((resv[..., 7] > st.RISSampleNum).sum())             # M above one frame's candidates => history was merged
     assert f_last == 0 or warm > 0, "no pixel of the compared bands reused history"
@@ -132,3 +136,9 @@ def test_config4_bistro_exterior_class_1080p_all_stages_moving_camera():
     """BASELINE config 4 (single-GPU leg): Bistro-Exterior-class ~2.8 M triangles with alpha-masked foliage + HDR env, 1920x1080,
     defaults (maxDepth 4, MIS, denoise), frame 3 under a moving camera (temporal reuse through real reprojection)."""
     run_config(abi.PROC_BISTRO_EXT, 1.0, (2048, 1024), lambda st: None, nframes=4, moving=True, bands_seed=4, tri_range=(2.6e6, 3.0e6))
+
+
+def test_config5_bistro_interior_class_4k_all_stages_orbiting_camera():
+    """BASELINE config 5 (single-GPU leg): Bistro-Interior-class ~1.0 M triangles with ~2 k emissive triangles, 3840x2160, DI + GI with
+    temporal reuse under a camera orbiting 0.5 degrees per frame; frame 3, three bands, all 12 dispatches."""
+    run_config(abi.PROC_BISTRO_INT, 1.0, (512, 256), lambda st: None, nframes=4, moving=False, bands_seed=5, tri_range=(0.8e6, 1.3e6), W=3840, H=2160, orbit_deg=0.5)
