@@ -45,7 +45,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-run", action="store_true", help="only the warm-up + K timed frames + the counting pass (for rocprofv3 --pmc / --kernel-trace runs)")
     ap.add_argument("--emulate-world", type=int, default=0, help="(1 GPU) N ranks of the native row-tiled frame (rt_mgpu_*) on this device, taking turns: per-rank stage times of a chip to itself")
-    ap.add_argument("--equal-bands", action="store_true", help="with --emulate-world: equal-height bands instead of cost-weighted ones")
+    ap.add_argument("--equal-bands", action="store_true", help="N > 1 (and --emulate-world): equal-height row bands instead of cost-weighted ones")
+    ap.add_argument("--band-rounds", type=int, default=8, help="N > 1: planning rounds of the cost-weighted band heights before the warm-up")
     ap.add_argument("--cpu-rows", type=int, default=256, help="height of the row band the CPU baseline renders")
     args = ap.parse_args()
 
@@ -114,6 +115,28 @@ def main():
             torch.cuda.synchronize()
 
     f = 0
+    band_plan = None
+    if world > 1 and not args.equal_bands:
+        # Cost-weighted band heights (SURVEY 8(e) "expected scaling limit"), planned before the warm-up: a few rounds of {two real
+        # frames, every rank times its band's two traced stages launched alone, the times are gathered, the boundaries move}.  The
+        # partition is then fixed: nothing of this runs in the warm-up or in the timed region.
+        tstream = torch.cuda.Stream()
+        for _ in range(args.band_rounds):
+            for _k in range(2):
+                step(f); f += 1
+            fence()
+            r.set_stream(tstream.cuda_stream)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            st.time = 1000 + f - 1
+            r.run_stage(st, f - 1, abi.STAGE_DIRECT, 0, frame.y0, frame.y1); r.run_stage(st, f - 1, abi.STAGE_INDIRECT, 0, frame.h0, frame.h1)   # warm
+            e0.record(tstream)
+            for _k in range(2):
+                r.run_stage(st, f - 1, abi.STAGE_DIRECT, 0, frame.y0, frame.y1); r.run_stage(st, f - 1, abi.STAGE_INDIRECT, 0, frame.h0, frame.h1)
+            e1.record(tstream); torch.cuda.synchronize()
+            r.history_miss()                                   # the re-runs may have raised the flag again: clear it
+            r.set_stream(stream.cuda_stream)
+            band_plan = frame.rebalance(e0.elapsed_time(e1) / 2.0, smoothing=0.6, max_move=6)
+        fence()
     for _ in range(args.warmup):
         step(f); f += 1
     fence()
@@ -170,7 +193,7 @@ def main():
             "config": {"workload": f"bistro-exterior-class procedural scene, {scene.getStat()['instancedTriangles']} triangles, {W}x{H}, "
                                    "ReSTIR DI (temporal, M=4) + GI (maxDepth 4, MIS) + A-Trous 4+5 levels + compose, static camera, "
                                    "2048x1024 synthetic HDR sky", "width": W, "height": H, "scene_scale": args.scale,
-                       "parallelism": ("single GPU" if frame is None else f"ONE rank of an emulated {args.emulate_world}-way row tiling, communication stubbed (not a benchmark result)") if world == 1 else f"row-tiled x{world}: frames in flight on 3 streams per rank, neighbour halo exchanges over RCCL (restir_amd/tiled.py PipelinedTiledFrame)",
+                       "parallelism": ("single GPU" if frame is None else f"ONE rank of an emulated {args.emulate_world}-way row tiling, communication stubbed (not a benchmark result)") if world == 1 else f"row-tiled x{world}: frames in flight on 3 streams per rank, halo exchanges over RCCL (restir_amd/tiled.py PipelinedTiledFrame), " + ("equal-height bands" if band_plan is None else f"cost-weighted bands {band_plan}"),
                        "rays_per_frame": round(rays_per_frame), "fps": round(1e3 / ms_per_step, 2), "bvh8_build_s": round(build_s, 2),
                        "accel": r.accel_stats()},
         }

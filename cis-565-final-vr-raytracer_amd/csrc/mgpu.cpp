@@ -160,6 +160,11 @@ void frameOnRank(rt_mgpu& M, Rank& R)
   if(multi && M.haveHistory) {
     for(int buf : {RT_BUF_GBUFFER0 + last, RT_BUF_DIRECT_RESV0 + last, RT_BUF_LIGHT_ID0 + last}) pullRows(M, R, buf, y0 - HIST_HALO, y1 + HIST_HALO, M.prevBands);
     pullRows(M, R, RT_BUF_INDIRECT_RESV0 + last, h0 - HIST_HALO / 2, h1 + HIST_HALO / 2, M.prevBands);
+    // rows that changed owner also bring the OTHER parity of the reservoir buffers along: pixels that return early (miss, emitter,
+    // debug view) leave their slot untouched (reference quirk), so a slot of this frame's buffer can keep the value of
+    // two frames ago.  Nothing is copied while the partition stands still (pullRows only copies rows other ranks owned).
+    for(int buf : {RT_BUF_DIRECT_RESV0 + cur, RT_BUF_LIGHT_ID0 + cur}) pullRows(M, R, buf, y0, y1, M.prevBands);
+    pullRows(M, R, RT_BUF_INDIRECT_RESV0 + cur, h0, h1, M.prevBands);
   }
   MG_CHECK(rt_set_history_rows(R.ctx, multi ? std::max(0, y0 - HIST_HALO) : 0, multi ? std::min(H, y1 + HIST_HALO) : H), "rt_set_history_rows");
   // ---- 2. ray-traced stages ----

@@ -50,13 +50,57 @@ def band_rows(H, world, rank):
     return min(rank * B, H), min((rank + 1) * B, H)
 
 
+def equal_partition(H, world):
+    """row boundaries [b_0 = 0, ..., b_world = H] of the equal-height partition (multiples of 16)"""
+    return [min(r * band_height(H, world), H) for r in range(world)] + [H]
+
+
+def half_partition(part, H):
+    """the same partition on the half-resolution grid"""
+    Hh = H // 2
+    return [min(p // 2, Hh) for p in part[:-1]] + [Hh]
+
+
+def plan_bands(H, world, stripe_cost, prev=None, max_move=None):
+    """Cost-weighted band boundaries: equalise the summed per-stripe cost (a stripe = 16 rows), every rank keeps >= 1 stripe; with
+    `prev` a boundary moves at most max_move stripes.  Same rule as csrc/mgpu.cpp rebalance()."""
+    stripes = (H + 15) // 16
+    cost = [max(1e-9, float(c)) for c in stripe_cost]
+    assert len(cost) == stripes and stripes >= world
+    total = sum(cost)
+    nb, acc, r = [0] * (world + 1), 0.0, 1
+    for s_ in range(stripes):
+        acc += cost[s_]
+        while r < world and acc >= total * r / world:
+            nb[r] = s_ + 1; r += 1
+    for k in range(r, world):
+        nb[k] = stripes
+    nb[world] = stripes
+    for k in range(1, world):
+        v = nb[k]
+        if prev is not None and max_move is not None:
+            old = prev[k] // 16
+            v = max(old - max_move, min(old + max_move, v))
+        v = max(v, nb[k - 1] + 1)
+        v = min(v, stripes - (world - k))
+        nb[k] = v
+    return [min(H, b * 16) for b in nb[:-1]] + [H]
+
+
+def _need(part, r, halo, limit):
+    """row segments rank r needs around its band: [(lo, hi)] above and below, clipped"""
+    y0, y1 = part[r], part[r + 1]
+    return [(max(0, y0 - halo), y0), (y1, min(limit, y1 + halo))]
+
+
 class LocalComm:
     """world == 1: every exchange is a no-op."""
     rank, world = 0, 1
-    def all_gather_rows(self, tensor, chunk_bytes, async_op=False): return None
+    def all_gather_rows(self, tensor, pitch, part, async_op=False): return None
     def halo_exchange(self, items, async_op=False): return []
-    def gather_rows_to(self, tensor, chunk_bytes, dst=0, async_op=False): return None
+    def gather_rows_to(self, tensor, pitch, part, dst=0, async_op=False): return None
     def any_flag(self, flag): return bool(flag)
+    def all_gather_floats(self, values): return [list(values)]
     def wait(self, work): pass
     def barrier(self): pass
 
@@ -73,41 +117,12 @@ class TorchComm:
         self._flag = torch.zeros(1, dtype=torch.int32, device="cuda" if self.nccl else "cpu")
         self._done = {}
 
-    def all_gather_rows(self, tensor, chunk_bytes, async_op=False):
-        out = tensor[: self.world * chunk_bytes]
-        mine = out[self.rank * chunk_bytes:(self.rank + 1) * chunk_bytes]
-        if self.nccl:  # in place: input is the rank-th chunk of the output
-            return self.dist.all_gather_into_tensor(out, mine, group=self.group, async_op=async_op)
-        chunks = [out[i * chunk_bytes:(i + 1) * chunk_bytes] for i in range(self.world)]
-        return self.dist.all_gather(chunks, mine.clone(), group=self.group, async_op=async_op)
-
-    def halo_exchange(self, items, async_op=False):
-        """items: [(tensor, pitch, y0, y1, halo, H, B)].  For every item fill rows [y0-halo, y0) and [y1, y1+halo) (clipped
-        to [0,H)) from the neighbouring bands, all items in ONE batched send/recv.  Items whose halo does not fit in a single
-        neighbour band fall back to an all-gather.  Returns the list of pending works."""
-        works, ops = [], []
-        P2P = self.dist.P2POp
-        for (tensor, pitch, y0, y1, halo, H, B) in items:
-            if halo <= 0:
-                continue
-            if halo > B:                                 # a halo would span more than one neighbour band
-                works.append(self.all_gather_rows(tensor, B * pitch, async_op=async_op))
-                continue
-            if y1 <= y0:
-                continue
-            # every band except the last non-empty one is B >= halo rows tall; only the last may be shorter, and it has no
-            # neighbour below, so "send min(halo, own height) rows" always matches what the receiver expects
-            ns = min(halo, y1 - y0)
-            up, down = self.rank - 1, self.rank + 1
-            if up >= 0 and y0 > 0:
-                ops.append(P2P(self.dist.isend, tensor[y0 * pitch:(y0 + ns) * pitch], up, group=self.group))
-                ops.append(P2P(self.dist.irecv, tensor[(y0 - halo) * pitch:y0 * pitch], up, group=self.group))
-            if down < self.world and y1 < H:
-                n = min(halo, H - y1)
-                ops.append(P2P(self.dist.isend, tensor[(y1 - ns) * pitch:y1 * pitch], down, group=self.group))
-                ops.append(P2P(self.dist.irecv, tensor[y1 * pitch:(y1 + n) * pitch], down, group=self.group))
-        if ops:
-            works += self.dist.batch_isend_irecv(ops)
+    # Every exchange is expressed on an arbitrary row partition `part` (world + 1 boundaries): rank q owns rows [part[q], part[q+1]).
+    # A rank receives the rows it needs from whoever owns them and sends the rows others need from its own band — one batched
+    # send/recv; both sides enumerate the segments of a pair in the same order (the receiver's need list), which is what NCCL's
+    # in-order matching of a group requires.  Bands may be narrower than a halo (a halo then spans several ranks).
+    def _batch(self, ops, async_op):
+        works = self.dist.batch_isend_irecv(ops) if ops else []
         works = [w for w in works if w is not None]
         if not async_op:
             for w in works:
@@ -115,19 +130,49 @@ class TorchComm:
             return []
         return works
 
-    def gather_rows_to(self, tensor, chunk_bytes, dst=0, async_op=False):
+    def _pair_ops(self, ops, tensor, pitch, part, need_of, limit):
+        P2P, me = self.dist.P2POp, self.rank
+        for q in range(self.world):
+            if q == me:
+                continue
+            for (lo, hi) in need_of(me):                     # what I receive from q
+                a, b = max(lo, part[q]), min(hi, part[q + 1], limit)
+                if b > a:
+                    ops.append(P2P(self.dist.irecv, tensor[a * pitch:b * pitch], q, group=self.group))
+            for (lo, hi) in need_of(q):                      # what q receives from me
+                a, b = max(lo, part[me]), min(hi, part[me + 1], limit)
+                if b > a:
+                    ops.append(P2P(self.dist.isend, tensor[a * pitch:b * pitch], q, group=self.group))
+
+    def all_gather_rows(self, tensor, pitch, part, async_op=False):
+        ops = []
+        self._pair_ops(ops, tensor, pitch, part, lambda r: [(0, part[-1])], part[-1])
+        w = self._batch(ops, async_op)
+        return w if async_op else None
+
+    def halo_exchange(self, items, async_op=False):
+        """items: [(tensor, pitch, part, halo, limit)].  For every item fill the `halo` rows above and below this rank's band (clipped to
+        [0, limit)) from the ranks that own them, all items in ONE batched send/recv.  Returns the list of pending works."""
+        ops = []
+        for (tensor, pitch, part, halo, limit) in items:
+            if halo <= 0:
+                continue
+            self._pair_ops(ops, tensor, pitch, part, lambda r, part=part, halo=halo, limit=limit: _need(part, r, halo, limit), limit)
+        return self._batch(ops, async_op)
+
+    def gather_rows_to(self, tensor, pitch, part, dst=0, async_op=False):
         # NCCL has no in-place gather primitive; grouped send/recv to dst: only dst's links carry the traffic
-        P2P = self.dist.P2POp
-        if self.rank == dst:
-            ops = [P2P(self.dist.irecv, tensor[r * chunk_bytes:(r + 1) * chunk_bytes], r, group=self.group) for r in range(self.world) if r != dst]
-        else:
-            ops = [P2P(self.dist.isend, tensor[self.rank * chunk_bytes:(self.rank + 1) * chunk_bytes], dst, group=self.group)]
-        works = self.dist.batch_isend_irecv(ops) if ops else []
-        if not async_op:
-            for w in works:
-                w.wait()
-            return None
-        return works
+        ops = []
+        self._pair_ops(ops, tensor, pitch, part, lambda r: [(0, part[-1])] if r == dst else [], part[-1])
+        w = self._batch(ops, async_op)
+        return w if async_op else None
+
+    def all_gather_floats(self, values):
+        """every rank's list of floats, by rank (host side; used outside the timed region to plan the band heights)"""
+        t = self.torch.tensor([float(v) for v in values], dtype=self.torch.float64, device="cuda" if self.nccl else "cpu")
+        out = [self.torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t, group=self.group)
+        return [[float(x) for x in o.cpu()] for o in out]
 
     def any_flag(self, flag):
         self._flag.fill_(1 if flag else 0)
@@ -160,17 +205,64 @@ class TiledFrame:
     backend needs: run_stage(state, frames, stage, level, row_begin, row_end), tensor(buf) -> (flat uint8 torch tensor over the
     whole allocation, row pitch in bytes), set_history_rows(r0, r1), history_miss() -> bool (synchronising)."""
 
-    def __init__(self, backend, comm, width, height):
+    def __init__(self, backend, comm, width, height, part=None):
         self.b, self.comm, self.W, self.H = backend, comm, width, height
-        self.B = band_height(height, comm.world)
-        if comm.world * self.B - height > 128:
-            raise ValueError("buffer slack rows (128) do not cover this world size")
-        self.y0, self.y1 = band_rows(height, comm.world, comm.rank)
-        self.Hh, self.Bh = height // 2, self.B // 2
-        self.h0, self.h1 = min(comm.rank * self.Bh, self.Hh), min((comm.rank + 1) * self.Bh, self.Hh)
+        self.Hh = height // 2
         self._pending = []          # history halos in flight (sent at the end of the previous frame)
         self._result_pending = []
         self.history_fallbacks = 0  # frames that needed the full history (statistics)
+        self._last_frames = None    # frame index of the last render_frame (set_partition redistributes its history)
+        self._apply_partition(part if part is not None else equal_partition(height, comm.world))
+
+    def _apply_partition(self, part):
+        part = [int(p) for p in part]
+        if len(part) != self.comm.world + 1 or part[0] != 0 or part[-1] != self.H or any(p % 16 and p != self.H for p in part) or \
+           any(part[i + 1] < part[i] for i in range(self.comm.world)):
+            raise ValueError(f"bad row partition {part}: needs world+1 non-decreasing boundaries from 0 to H, multiples of 16 (trailing bands may be empty)")
+        self.part, self.parth = part, half_partition(part, self.H)
+        r = self.comm.rank
+        self.y0, self.y1 = self.part[r], self.part[r + 1]
+        self.h0, self.h1 = self.parth[r], self.parth[r + 1]
+
+    def set_partition(self, part):
+        """Switch to another row partition (e.g. cost-weighted band heights from plan_bands).  Everything in flight is finished and the
+        history of the last frame is all-gathered under the OLD partition, so every rank holds the rows its new band + halo needs."""
+        self.finish()
+        if self.comm.world > 1 and self._last_frames is not None:
+            cur = self._last_frames & 1
+            # Both parities of the reservoir buffers: pixels that return early (miss, emitter, debug view) leave their reservoir slot
+            # untouched (reference quirk, DESIGN.md 6.7), so a slot can hold the value of two frames ago — rows that change owner
+            # must bring that along to stay bit-identical with the single-GPU frame.
+            for buf, pt in ((abi.BUF_GBUFFER0 + cur, self.part), (abi.BUF_DIRECT_RESV0 + cur, self.part), (abi.BUF_LIGHT_ID0 + cur, self.part),
+                            (abi.BUF_INDIRECT_RESV0 + cur, self.parth), (abi.BUF_DIRECT_RESV0 + (cur ^ 1), self.part),
+                            (abi.BUF_LIGHT_ID0 + (cur ^ 1), self.part), (abi.BUF_INDIRECT_RESV0 + (cur ^ 1), self.parth)):
+                t, p = self._t(buf)
+                self.comm.all_gather_rows(t, p, pt)
+            fn = getattr(self.b, "sync_all", None)
+            if fn:
+                fn()
+        self._apply_partition(part)
+
+    def rebalance(self, my_ms, smoothing=0.5, max_move=4):
+        """One step of cost-weighted band planning (outside the timed region): `my_ms` is what this rank measured for its band (e.g. its
+        direct + indirect stage launched alone); every rank contributes its number, the times are spread over the ranks' 16-row stripes
+        into a smoothed per-stripe cost, plan_bands equalises the summed cost and set_partition moves the history.  Returns the new
+        partition (identical on every rank: it is computed from the same gathered numbers)."""
+        stripes = (self.H + 15) // 16
+        if getattr(self, "_stripe_cost", None) is None or len(self._stripe_cost) != stripes:
+            self._stripe_cost = [1.0] * stripes
+        allms = self.comm.all_gather_floats([float(my_ms)])
+        for q in range(self.comm.world):
+            a, b = self.part[q] // 16, (self.part[q + 1] + 15) // 16
+            if b <= a:
+                continue
+            per = max(1e-6, allms[q][0]) / (b - a)
+            for s_ in range(a, b):
+                self._stripe_cost[s_] = (1.0 - smoothing) * self._stripe_cost[s_] + smoothing * per
+        new = plan_bands(self.H, self.comm.world, self._stripe_cost, prev=self.part, max_move=max_move)
+        if new != self.part:
+            self.set_partition(new)
+        return new
 
     def _t(self, buf):
         return self.b.tensor(buf)
@@ -188,6 +280,7 @@ class TiledFrame:
         c, b = self.comm, self.b
         cur, last = frames & 1, (frames + 1) & 1
         single = c.world == 1
+        self._last_frames = frames
         if not single and state.ReSTIRState in (abi.RESTIR_SPATIAL, abi.RESTIR_SPATIOTEMPORAL):
             # the spatial reuse step reads the cached reservoirs of the rows above / below the band (direct_stage.comp:86-107);
             # that buffer is not part of the halo exchange
@@ -201,10 +294,10 @@ class TiledFrame:
         self._traced_stages(state, frames)
         if not single and c.any_flag(b.history_miss()):
             self.history_fallbacks += 1
-            for buf, chunk in ((abi.BUF_GBUFFER0 + last, self.B), (abi.BUF_DIRECT_RESV0 + last, self.B), (abi.BUF_LIGHT_ID0 + last, self.B),
-                               (abi.BUF_INDIRECT_RESV0 + last, self.Bh)):
+            for buf, pt in ((abi.BUF_GBUFFER0 + last, self.part), (abi.BUF_DIRECT_RESV0 + last, self.part), (abi.BUF_LIGHT_ID0 + last, self.part),
+                            (abi.BUF_INDIRECT_RESV0 + last, self.parth)):
                 t, p = self._t(buf)
-                c.all_gather_rows(t, chunk * p)
+                c.all_gather_rows(t, p, pt)
             b.set_history_rows(0, self.H)
             self._traced_stages(state, frames)
             b.history_miss()  # clear
@@ -215,9 +308,9 @@ class TiledFrame:
             g, gp = self._t(abi.BUF_GBUFFER0 + cur)
             dcol, _ = self._t(abi.BUF_DIRECT_RESULT0 + cur)
             icol, _ = self._t(abi.BUF_DENOISE_IND_A)
-            c.halo_exchange([(g, gp, self.y0, self.y1, HALO_GBUFFER, self.H, self.B),
-                             (dcol, pitch, self.y0, self.y1, HALO_DIRECT_COLOR, self.H, self.B),
-                             (icol, pitch, self.h0, self.h1, HALO_INDIRECT_COLOR, self.Hh, self.Bh)])
+            c.halo_exchange([(g, gp, self.part, HALO_GBUFFER, self.H),
+                             (dcol, pitch, self.part, HALO_DIRECT_COLOR, self.H),
+                             (icol, pitch, self.parth, HALO_INDIRECT_COLOR, self.Hh)])
         if state.denoise > 0:
             for l in range(4):
                 g_ = 0 if single else DIRECT_GROW[l]
@@ -232,15 +325,15 @@ class TiledFrame:
             items = []
             for buf in (abi.BUF_GBUFFER0 + cur, abi.BUF_DIRECT_RESV0 + cur, abi.BUF_LIGHT_ID0 + cur):
                 t, p = self._t(buf)
-                items.append((t, p, self.y0, self.y1, HIST_HALO, self.H, self.B))
+                items.append((t, p, self.part, HIST_HALO, self.H))
             t, p = self._t(abi.BUF_INDIRECT_RESV0 + cur)
-            items.append((t, p, self.h0, self.h1, HIST_HALO // 2, self.Hh, self.Bh))
+            items.append((t, p, self.parth, HIST_HALO // 2, self.Hh))
             self._pending = c.halo_exchange(items, async_op=True)
             c.wait(self._result_pending)
             self._result_pending = []
             for buf in (abi.BUF_DIRECT_RESULT0 + cur, abi.BUF_INDIRECT_RESULT0 + cur):
                 t, p = self._t(buf)
-                w = c.gather_rows_to(t, self.B * p, dst=0, async_op=True)
+                w = c.gather_rows_to(t, p, self.part, dst=0, async_op=True)
                 if w:
                     self._result_pending += list(w)
 
@@ -273,8 +366,8 @@ class PipelinedTiledFrame(TiledFrame):
     reads G(f) and G(f-1) while direct(f+1) writes; the history-miss flags are per stage kind (history_miss_stage); a miss
     drains everything and re-runs that stage with the all-gathered history, exactly like TiledFrame."""
 
-    def __init__(self, backend, comm, width, height):
-        super().__init__(backend, comm, width, height)
+    def __init__(self, backend, comm, width, height, part=None):
+        super().__init__(backend, comm, width, height, part)
         self._wD = []            # X_D of the latest direct stage
         self._wD_prev = []       # ... and of the one before (history rows the indirect stage reads)
         self._rotated = None
@@ -330,6 +423,7 @@ class PipelinedTiledFrame(TiledFrame):
         if state.ReSTIRState in (abi.RESTIR_SPATIAL, abi.RESTIR_SPATIOTEMPORAL):
             raise NotImplementedError("ReSTIRState eSpatial / eSpatiotemporal is single-GPU only in this build")
         f, cur, last = frames, frames & 1, (frames + 1) & 1
+        self._last_frames = frames
         self._rotate(f)
         # ---- 1. direct(f) on the main stream ---------------------------------------------------------------------------------
         with self._stream("main"):
@@ -346,19 +440,19 @@ class PipelinedTiledFrame(TiledFrame):
                 self._drain()
                 for buf in (abi.BUF_GBUFFER0 + last, abi.BUF_DIRECT_RESV0 + last, abi.BUF_LIGHT_ID0 + last):
                     t, p = self._t(buf)
-                    c.all_gather_rows(t, self.B * p)
+                    c.all_gather_rows(t, p, self.part)
                 b.set_history_rows(0, self.H)
                 self._run(state, f, abi.STAGE_DIRECT, 0, self.y0, self.y1, self.H)
                 self._miss(abi.STAGE_DIRECT)  # clear
             items = []
             g, gp = self._t(abi.BUF_GBUFFER0 + cur)
-            items.append((g, gp, self.y0, self.y1, HALO_GBUFFER if state.denoise > 0 else HIST_HALO, self.H, self.B))
+            items.append((g, gp, self.part, HALO_GBUFFER if state.denoise > 0 else HIST_HALO, self.H))
             for buf in (abi.BUF_DIRECT_RESV0 + cur, abi.BUF_LIGHT_ID0 + cur):
                 t, p = self._t(buf)
-                items.append((t, p, self.y0, self.y1, HIST_HALO, self.H, self.B))
+                items.append((t, p, self.part, HIST_HALO, self.H))
             if state.denoise > 0:
                 dcol, _ = self._t(abi.BUF_DIRECT_RESULT0 + cur)
-                items.append((dcol, self.W * _COLOR_BYTES, self.y0, self.y1, HALO_DIRECT_COLOR, self.H, self.B))
+                items.append((dcol, self.W * _COLOR_BYTES, self.part, HALO_DIRECT_COLOR, self.H))
             self._wD_prev = self._wD
             self._wD = c.halo_exchange(items, async_op=True)
             self._record(("D", f))
@@ -397,10 +491,10 @@ class PipelinedTiledFrame(TiledFrame):
                 self._validate_indirect(state, f)
             items = []
             t, p = self._t(abi.BUF_INDIRECT_RESV0 + cur)
-            items.append((t, p, self.h0, self.h1, HIST_HALO // 2, self.Hh, self.Bh))
+            items.append((t, p, self.parth, HIST_HALO // 2, self.Hh))
             if state.denoise > 0:
                 icol, _ = self._t(abi.BUF_DENOISE_IND_A)
-                items.append((icol, self.W * _COLOR_BYTES, self.h0, self.h1, HALO_INDIRECT_COLOR, self.Hh, self.Bh))
+                items.append((icol, self.W * _COLOR_BYTES, self.parth, HALO_INDIRECT_COLOR, self.Hh))
             self._wI = c.halo_exchange(items, async_op=True)
             self._record(("Ix", f))
         with self._stream("side"):
@@ -414,7 +508,7 @@ class PipelinedTiledFrame(TiledFrame):
             works = []
             for buf in (abi.BUF_DIRECT_RESULT0 + cur, abi.BUF_INDIRECT_RESULT0 + cur):
                 t, p = self._t(buf)
-                w = c.gather_rows_to(t, self.B * p, dst=0, async_op=True)
+                w = c.gather_rows_to(t, p, self.part, dst=0, async_op=True)
                 if w:
                     works += list(w)
             self._wR[cur] = works
@@ -433,9 +527,9 @@ class PipelinedTiledFrame(TiledFrame):
         newer = self._rotated
         if newer is not None and newer > f:
             self._rotate(newer)            # undo: the boundary ids point at frame f's G-buffers / motion vectors again
-        for buf, chunk in ((abi.BUF_GBUFFER0 + last, self.B), (abi.BUF_INDIRECT_RESV0 + last, self.Bh)):
+        for buf, pt in ((abi.BUF_GBUFFER0 + last, self.part), (abi.BUF_INDIRECT_RESV0 + last, self.parth)):
             t, p = self._t(buf)
-            c.all_gather_rows(t, chunk * p)
+            c.all_gather_rows(t, p, pt)
         b.set_history_rows(0, self.H)
         self._run(state, f, abi.STAGE_INDIRECT, 0, self.h0, self.h1, self.Hh)
         self._miss(abi.STAGE_INDIRECT)     # clear

@@ -89,29 +89,36 @@ class ThreadComm:
     def _sync(self):
         import torch
         self.s["renderers"][self.rank].sync(); torch.cuda.synchronize(); self.s["barrier"].wait()
-    def all_gather_rows(self, tensor, chunk_bytes, async_op=False):
+    def _copy_needed(self, tensor, pitch, part, need, limit):
+        """rows in `need` (list of (lo, hi)) that other ranks own, copied from their buffers (all ranks call with the same arguments)"""
         import torch
         self.s["slot"][self.rank] = tensor
         self._sync()
-        for p in range(self.world):
-            if p != self.rank:
-                tensor[p * chunk_bytes:(p + 1) * chunk_bytes].copy_(self.s["slot"][p][p * chunk_bytes:(p + 1) * chunk_bytes])
+        for (lo, hi) in need:
+            for p in range(self.world):
+                if p == self.rank:
+                    continue
+                a, b = max(lo, part[p]), min(hi, part[p + 1], limit)
+                if b > a:
+                    tensor[a * pitch:b * pitch].copy_(self.s["slot"][p][a * pitch:b * pitch])
         torch.cuda.synchronize(); self.s["barrier"].wait()
+    def all_gather_rows(self, tensor, pitch, part, async_op=False):
+        self._copy_needed(tensor, pitch, part, [(0, part[-1])], part[-1])
         return None
     def halo_exchange(self, items, async_op=False):
-        import torch
-        for (tensor, pitch, y0, y1, halo, H_, B) in items:   # every rank passes the same item list => barriers line up
+        from restir_amd import tiled
+        for (tensor, pitch, part, halo, limit) in items:   # every rank passes the same item list => barriers line up
             if halo <= 0:
                 continue
-            self.s["slot"][self.rank] = tensor
-            self._sync()
-            if y1 > y0:
-                for p, (a, b) in ((self.rank - 1, (max(0, y0 - halo), y0)), (self.rank + 1, (y1, min(H_, y1 + halo)))):
-                    if 0 <= p < self.world and b > a:
-                        tensor[a * pitch:b * pitch].copy_(self.s["slot"][p][a * pitch:b * pitch])
-            torch.cuda.synchronize(); self.s["barrier"].wait()
+            self._copy_needed(tensor, pitch, part, tiled._need(part, self.rank, halo, limit), limit)
         return []
-    def gather_rows_to(self, tensor, chunk_bytes, dst=0, async_op=False): return self.all_gather_rows(tensor, chunk_bytes)
+    def gather_rows_to(self, tensor, pitch, part, dst=0, async_op=False): return self.all_gather_rows(tensor, pitch, part)
+    def all_gather_floats(self, values):
+        self.s.setdefault("floats", [None] * self.world)[self.rank] = list(values)
+        self.s["barrier"].wait()
+        out = [list(v) for v in self.s["floats"]]
+        self.s["barrier"].wait()
+        return out
     def any_flag(self, flag):
         self.s["flags"][self.rank] = bool(flag)
         self.s["barrier"].wait()
@@ -122,13 +129,15 @@ class ThreadComm:
     def barrier(self): self.s["barrier"].wait()
 
 
-@pytest.mark.parametrize("mode", ["serial", "serial-fallbacks", "frames-in-flight", "frames-in-flight-fallbacks"])
+@pytest.mark.parametrize("mode", ["serial", "serial-fallbacks", "frames-in-flight", "frames-in-flight-fallbacks", "frames-in-flight-uneven", "frames-in-flight-rebalance"])
 def test_tiled_three_ranks_equals_untiled(bistro, mode, monkeypatch):
     import torch
     from restir_amd import tiled
     sc, env, st, cam = bistro
     world, frames = 3, (2 if mode == "serial" else 4)
     Frame = tiled.TiledFrame if mode.startswith("serial") else tiled.PipelinedTiledFrame
+    part0 = [0, 496, 560, H] if mode.endswith("uneven") else None    # a 64-row band at the horizon: every halo spans more than one rank
+    parts = [None] * world
     if mode.endswith("fallbacks"):
         monkeypatch.setattr(tiled, "HIST_HALO", 0)   # every cross-band reprojection misses: both exact fallbacks (incl. the un-rotate / re-rotate of the G-buffers) run
     ref = _renderer(sc, env)
@@ -146,12 +155,15 @@ def test_tiled_three_ranks_equals_untiled(bistro, mode, monkeypatch):
     def rank_main(rank):
         try:
             torch.cuda.set_device(0)
-            fr = Frame(tiled.RendererTensors(rs[rank]), ThreadComm(rank, world, shared), W, H)
+            fr = Frame(tiled.RendererTensors(rs[rank]), ThreadComm(rank, world, shared), W, H, part0)
             import copy
             st_r = copy.copy(st)
             for f in range(frames):
                 st_r.time = 500 + f; rs[rank].set_camera(cams[f]); fr.render_frame(st_r, f)
+                if mode.endswith("rebalance") and f == 1:      # cost feedback in the middle of the sequence: the street rows cost 5x the sky rows
+                    fr.rebalance(sum(5.0 if y >= 500 else 1.0 for y in range(fr.y0, fr.y1)), smoothing=1.0, max_move=8)
             fr.finish(); rs[rank].sync()
+            parts[rank] = list(fr.part)
             fallbacks[rank] = fr.history_fallbacks
         except Exception as e:  # pragma: no cover
             errors.append(e); shared["barrier"].abort()
@@ -167,13 +179,15 @@ def test_tiled_three_ranks_equals_untiled(bistro, mode, monkeypatch):
         got, want = rs[0].readback(b).reshape(H, -1), ref.readback(b).reshape(H, -1)
         bad = np.nonzero((got != want).any(axis=1))[0]
         assert bad.size == 0, (abi.BUFFER_NAMES[b], "rows", int(bad.min()), int(bad.max()), int(bad.size))
-    B = tiled.band_height(H, world)
+    part = parts[0]; parth = tiled.half_partition(part, H)
+    assert all(p == part for p in parts)
+    if mode.endswith("rebalance"): assert part != tiled.equal_partition(H, world)
     for b, elem, half in [(abi.BUF_GBUFFER0 + cur, 16, False), (abi.BUF_DIRECT_RESV0 + cur, 36, False), (abi.BUF_LIGHT_ID0 + cur, 4, False),
                           (abi.BUF_INDIRECT_RESV0 + cur, 76, True)]:
         want = ref.readback(b)
         for rank in range(world):   # the frame's history stays distributed: each rank owns its band
-            w, Bb, Hb = (W // 2, B // 2, H // 2) if half else (W, B, H)
-            a, e = min(rank * Bb, Hb), min((rank + 1) * Bb, Hb)
+            w = W // 2 if half else W
+            a, e = (parth[rank], parth[rank + 1]) if half else (part[rank], part[rank + 1])
             got = rs[rank].readback(b).reshape(-1, w * elem)[a:e]
             assert np.array_equal(got, want.reshape(-1, w * elem)[a:e]), (abi.BUFFER_NAMES[b], rank)
 

@@ -47,7 +47,7 @@ def _setup():
     return sc, env, st, o
 
 
-def _worker(rank, world, port, outdir, fast, pipelined=False):
+def _worker(rank, world, port, outdir, fast, pipelined=False, part=None, replan=False):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -55,11 +55,15 @@ def _worker(rank, world, port, outdir, fast, pipelined=False):
     if fast:
         tiled.HIST_HALO = 0   # no history halo: the first cross-band reprojection must trigger the exact fallback
     sc, env, st, o = _setup()
-    frame = (tiled.PipelinedTiledFrame if pipelined else tiled.TiledFrame)(OracleTensors(o), tiled.TorchComm(), W, H)
+    frame = (tiled.PipelinedTiledFrame if pipelined else tiled.TiledFrame)(OracleTensors(o), tiled.TorchComm(), W, H, part)
     sc.updateCamera(W, H)
     for f in range(FRAMES):
         st.time = 900 + f; _camera(sc, f, fast); sc.updateCamera(W, H); o.set_camera(sc.getCamera())
         frame.render_frame(st, f)
+        if replan == 1 and f == 1:     # switch to another partition in the middle of the sequence: history must follow
+            frame.set_partition(REPLAN[world])
+        if replan == 2:                # cost feedback: a synthetic cost of 1 per row, 9 per row below row 128 => bands shrink at the bottom
+            frame.rebalance(sum(9.0 if y >= 128 else 1.0 for y in range(frame.y0, frame.y1)), smoothing=1.0, max_move=3)
     frame.finish()
     cur = (FRAMES - 1) & 1
     if rank == 0:   # both parities: the last frame and the one before it (whose second half was issued one call later)
@@ -77,6 +81,11 @@ def _result_buffers(cur):
 
 def _history_buffers(cur):
     return [abi.BUF_GBUFFER0 + cur, abi.BUF_DIRECT_RESV0 + cur, abi.BUF_LIGHT_ID0 + cur, abi.BUF_INDIRECT_RESV0 + cur]
+
+
+# uneven partitions: bands narrower than the 32-row history halo and the 144-row G-buffer halo (a halo spans several ranks)
+UNEVEN = {2: [0, 48, 208], 3: [0, 16, 176, 208]}
+REPLAN = {2: [0, 160, 208], 3: [0, 96, 112, 208]}
 
 
 _ELEM = {"gbuffer": 16, "direct_resv": 36, "light_id": 4, "indirect_resv": 76}
@@ -110,11 +119,64 @@ def test_tiled_equals_untiled(world, fast, pipelined, tmp_path):
     assert (int(got["fallbacks"][0]) > 0) == fast
 
 
+@pytest.mark.parametrize("pipelined", [False, True], ids=["serial", "frames-in-flight"])
+@pytest.mark.parametrize("mode", ["uneven", "replan", "feedback"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_uneven_partitions_equal_untiled(world, mode, pipelined, tmp_path):
+    """cost-weighted band heights: a fixed uneven partition, and a switch of partition in the middle of a temporal sequence"""
+    part = UNEVEN[world] if mode == "uneven" else None
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), False, pipelined, part, {"uneven": 0, "replan": 1, "feedback": 2}[mode]), nprocs=world, join=True)
+    got = np.load(os.path.join(tmp_path, f"tiled_{world}.npz"))
+    sc, env, st, o = _setup()
+    sc.updateCamera(W, H)
+    for f in range(FRAMES):
+        st.time = 900 + f; _camera(sc, f, False); sc.updateCamera(W, H); o.set_camera(sc.getCamera()); o.render_frame(st, f)
+    cur = (FRAMES - 1) & 1
+    for b in _result_buffers(cur):
+        assert np.array_equal(got[abi.BUFFER_NAMES[b]], o.readback(b)), abi.BUFFER_NAMES[b]
+    want_rows = {"uneven": UNEVEN[world], "replan": REPLAN[world]}.get(mode)
+    ends = []
+    for rank in range(world):
+        band = np.load(os.path.join(tmp_path, f"band_{world}_{rank}.npz"))
+        y0, y1, h0, h1 = (int(v) for v in band["rows"])
+        ends.append(y1)
+        if want_rows:
+            assert (y0, y1) == (want_rows[rank], want_rows[rank + 1])
+        for b in _history_buffers(cur):
+            name = abi.BUFFER_NAMES[b]
+            half = name.startswith("indirect")
+            w, a, e = (W // 2, h0, h1) if half else (W, y0, y1)
+            elem = _ELEM[name[:-1]]
+            assert np.array_equal(band[name].reshape(-1, w * elem)[a:e], o.readback(b).reshape(-1, w * elem)[a:e]), (name, rank)
+    if mode == "feedback":   # the expensive bottom rows ended up in a shorter band than the equal split's
+        from restir_amd import tiled
+        eq = tiled.equal_partition(H, world)
+        assert ends[-1] == H and (ends[-1] - ends[-2]) < (eq[-1] - eq[-2])
+
+
 def test_band_partition():
     from restir_amd import tiled
     for Hh, world in [(1080, 8), (1080, 4), (1080, 2), (2160, 8), (80, 3), (40, 8)]:
-        B = tiled.band_height(Hh, world)
-        assert B % 16 == 0 and world * B >= Hh and world * B - Hh <= 128
-        rows = [tiled.band_rows(Hh, world, r) for r in range(world)]
-        assert rows[0][0] == 0 and max(r[1] for r in rows) == Hh
-        assert all(rows[i][1] == rows[i + 1][0] or rows[i + 1][0] == Hh for i in range(world - 1))
+        part = tiled.equal_partition(Hh, world)
+        assert part[0] == 0 and part[-1] == Hh and all(p % 16 == 0 or p == Hh for p in part) and all(part[i] <= part[i + 1] for i in range(world))
+        assert tiled.half_partition(part, Hh)[-1] == Hh // 2
+
+
+def test_plan_bands_balances_cost():
+    from restir_amd import tiled
+    H, world = 1080, 8
+    stripes = (H + 15) // 16
+    cost = [1.0] * stripes
+    for s_ in range(30, 38):
+        cost[s_] = 12.0                       # an expensive horizon
+    part = tiled.plan_bands(H, world, cost)
+    assert part[0] == 0 and part[-1] == H and all(p % 16 == 0 for p in part[:-1]) and all(part[i + 1] > part[i] for i in range(world))
+    sums = [sum(cost[part[r] // 16:(part[r + 1] + 15) // 16]) for r in range(world)]
+    eq = tiled.equal_partition(H, world)
+    sums_eq = [sum(cost[eq[r] // 16:(eq[r + 1] + 15) // 16]) for r in range(world)]
+    assert max(sums) < 0.7 * max(sums_eq)      # the heaviest band got lighter
+    assert min(part[r + 1] - part[r] for r in range(world)) < 64 < max(part[r + 1] - part[r] for r in range(world))
+    moved = tiled.plan_bands(H, world, cost, prev=eq, max_move=2)
+    assert all(abs(moved[k] - eq[k]) <= 32 for k in range(world + 1))
+    with pytest.raises(AssertionError):
+        tiled.plan_bands(32, 4, [1.0, 1.0])    # fewer stripes than ranks
