@@ -116,7 +116,7 @@ def main():
 
     f = 0
     band_plan = None
-    if world > 1 and not args.equal_bands:
+    if world > 1 and not args.equal_bands and os.environ.get("RESTIR_EQUAL_BANDS", "0") != "1":
         # Cost-weighted band heights (SURVEY 8(e) "expected scaling limit"), planned before the warm-up: a few rounds of {two real
         # frames, every rank times its band's two traced stages launched alone, the times are gathered, the boundaries move}.  The
         # partition is then fixed: nothing of this runs in the warm-up or in the timed region.
