@@ -142,9 +142,22 @@ void runStage(rt_mgpu& M, Rank& R, int stage, int level, int r0, int r1, int lim
   if(r1 > r0) MG_CHECK(rt_run_stage(R.ctx, &M.st, M.frames, stage, level, r0, r1), "rt_run_stage");
 }
 
+// direct stage on the band, indirect stage on its half-res rows.  With spatial reuse the direct stage runs in two halves around an
+// exchange: every pixel caches its reservoir (level 1), the ranks pull the rows next to their band from RT_BUF_DIRECT_RESV_TEMP — the
+// neighbour picks of direct_stage.comp:86-107 reach one pixel up / down — and then merge and shade (level 2).  Contains one barrier in
+// the spatial modes (uniform over ranks: the mode comes from the shared RtxState).
 void tracedStages(rt_mgpu& M, Rank& R, int y0, int y1, int h0, int h1)
 {
-  runStage(M, R, RT_STAGE_DIRECT, 0, y0, y1, M.H);
+  const bool spatial = M.n > 1 && (M.st.ReSTIRState == RT_RESTIR_SPATIAL || M.st.ReSTIRState == RT_RESTIR_SPATIOTEMPORAL);
+  if(!spatial) runStage(M, R, RT_STAGE_DIRECT, 0, y0, y1, M.H);
+  else {
+    runStage(M, R, RT_STAGE_DIRECT, 1, y0, y1, M.H);
+    MG_HIP(hipStreamSynchronize(R.stream), "sync");
+    M.step.wait();
+    pullRows(M, R, RT_BUF_DIRECT_RESV_TEMP, y0 - 2, y0, M.bands);
+    pullRows(M, R, RT_BUF_DIRECT_RESV_TEMP, y1, y1 + 2, M.bands);
+    runStage(M, R, RT_STAGE_DIRECT, 2, y0, y1, M.H);
+  }
   runStage(M, R, RT_STAGE_INDIRECT, 0, h0, h1, M.H / 2);
 }
 
@@ -163,14 +176,15 @@ void frameOnRank(rt_mgpu& M, Rank& R)
     // rows that changed owner also bring the OTHER parity of the reservoir buffers along: pixels that return early (miss, emitter,
     // debug view) leave their slot untouched (reference quirk), so a slot of this frame's buffer can keep the value of
     // two frames ago.  Nothing is copied while the partition stands still (pullRows only copies rows other ranks owned).
-    for(int buf : {RT_BUF_DIRECT_RESV0 + cur, RT_BUF_LIGHT_ID0 + cur}) pullRows(M, R, buf, y0, y1, M.prevBands);
+    for(int buf : {RT_BUF_DIRECT_RESV0 + cur, RT_BUF_LIGHT_ID0 + cur, int(RT_BUF_DIRECT_RESV_TEMP)}) pullRows(M, R, buf, y0, y1, M.prevBands);
     pullRows(M, R, RT_BUF_INDIRECT_RESV0 + cur, h0, h1, M.prevBands);
   }
   MG_CHECK(rt_set_history_rows(R.ctx, multi ? std::max(0, y0 - HIST_HALO) : 0, multi ? std::min(H, y1 + HIST_HALO) : H), "rt_set_history_rows");
   // ---- 2. ray-traced stages ----
   {
+    const bool spatialSplit = multi && (M.st.ReSTIRState == RT_RESTIR_SPATIAL || M.st.ReSTIRState == RT_RESTIR_SPATIOTEMPORAL);
     std::unique_lock<std::mutex> turn(M.turn, std::defer_lock);
-    if(M.serialize) { turn.lock(); MG_HIP(hipStreamSynchronize(R.stream), "sync"); }
+    if(M.serialize && !spatialSplit) { turn.lock(); MG_HIP(hipStreamSynchronize(R.stream), "sync"); }   // (the split stage has a barrier inside: ranks cannot take turns)
     MG_HIP(hipEventRecord(R.ev[0], R.stream), "hipEventRecord");
     tracedStages(M, R, y0, y1, h0, h1);
     MG_HIP(hipEventRecord(R.ev[1], R.stream), "hipEventRecord");
@@ -186,8 +200,9 @@ void frameOnRank(rt_mgpu& M, Rank& R)
     for(int buf : {RT_BUF_GBUFFER0 + last, RT_BUF_DIRECT_RESV0 + last, RT_BUF_LIGHT_ID0 + last}) pullRows(M, R, buf, 0, H, M.prevBands);
     pullRows(M, R, RT_BUF_INDIRECT_RESV0 + last, 0, Hh, M.prevBands);
     MG_CHECK(rt_set_history_rows(R.ctx, 0, H), "rt_set_history_rows");
+    const bool spatialSplit = M.st.ReSTIRState == RT_RESTIR_SPATIAL || M.st.ReSTIRState == RT_RESTIR_SPATIOTEMPORAL;
     std::unique_lock<std::mutex> turn(M.turn, std::defer_lock);
-    if(M.serialize) turn.lock();
+    if(M.serialize && !spatialSplit) turn.lock();
     tracedStages(M, R, y0, y1, h0, h1);
     int miss = 0;
     MG_CHECK(rt_history_miss(R.ctx, &miss), "rt_history_miss");   // clears the flag, waits for the stream
@@ -385,11 +400,6 @@ int rt_mgpu_render_frame(rt_mgpu* M, const rt_state* st, int frames)
 {
   if(!M || !st) return RT_ERR_INVALID_ARG;
   if(M->W == 0) { M->err = "rt_mgpu_render_frame: rt_mgpu_resize has not been called"; return RT_ERR_NO_TARGET; }
-  if(M->n > 1 && (st->ReSTIRState == RT_RESTIR_SPATIAL || st->ReSTIRState == RT_RESTIR_SPATIOTEMPORAL)) {
-    // the spatial reuse step reads the cached reservoirs of the rows above / below the band (direct_stage.comp:86-107); that
-    // buffer is not part of the halo exchange
-    M->err = "rt_mgpu_render_frame: ReSTIRState eSpatial / eSpatiotemporal is single-GPU only"; return RT_ERR_INVALID_ARG;
-  }
   M->st = *st; M->frames = frames;
   const int rc = dispatch(M, rt_mgpu::FRAME);
   // statistics of this frame, then the partition of the next one

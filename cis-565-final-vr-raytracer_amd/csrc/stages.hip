@@ -955,8 +955,10 @@ hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F,
       // (a K-tiles-per-wave variant of this kernel — primary and shadow rays through the LDS ray pool, pixel state in the scratch
       //  records between the traces — was measured: 1.77 -> 2.6 ms; the coherent primary rays gain nothing from the pool and the
       //  split shading costs more than the shorter tail saves.  The single-bounce indirect tiles are where pooling pays.)
-      hipLaunchKernelGGL(k_direct_stage, grid, block, lds, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY);
-      if(st.ReSTIRState == RT_RESTIR_SPATIAL || st.ReSTIRState == RT_RESTIR_SPATIOTEMPORAL)
+      // `level` selects the halves of the stage for hosts that must exchange the cached reservoirs of neighbouring rows in between
+      // (row-tiled multi-GPU frames with spatial reuse): 0 = the whole stage, 1 = k_direct_stage only, 2 = k_direct_spatial only
+      if(level != 2) hipLaunchKernelGGL(k_direct_stage, grid, block, lds, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY);
+      if(level != 1 && (st.ReSTIRState == RT_RESTIR_SPATIAL || st.ReSTIRState == RT_RESTIR_SPATIOTEMPORAL))
         hipLaunchKernelGGL(k_direct_spatial, grid, block, 0, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY);
       break;
     case RT_STAGE_DIRECT_GEN: hipLaunchKernelGGL(k_direct_gen, grid, block, lds, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY); break;

@@ -235,7 +235,8 @@ class TiledFrame:
             # must bring that along to stay bit-identical with the single-GPU frame.
             for buf, pt in ((abi.BUF_GBUFFER0 + cur, self.part), (abi.BUF_DIRECT_RESV0 + cur, self.part), (abi.BUF_LIGHT_ID0 + cur, self.part),
                             (abi.BUF_INDIRECT_RESV0 + cur, self.parth), (abi.BUF_DIRECT_RESV0 + (cur ^ 1), self.part),
-                            (abi.BUF_LIGHT_ID0 + (cur ^ 1), self.part), (abi.BUF_INDIRECT_RESV0 + (cur ^ 1), self.parth)):
+                            (abi.BUF_LIGHT_ID0 + (cur ^ 1), self.part), (abi.BUF_INDIRECT_RESV0 + (cur ^ 1), self.parth),
+                            (abi.BUF_DIRECT_RESV_TEMP, self.part)):
                 t, p = self._t(buf)
                 self.comm.all_gather_rows(t, p, pt)
             fn = getattr(self.b, "sync_all", None)
@@ -272,8 +273,19 @@ class TiledFrame:
         if r1 > r0:
             self.b.run_stage(state, frames, stage, level, r0, r1)
 
+    def _direct(self, state, frames):
+        """the direct stage on the band; with spatial reuse in two halves around an exchange of the cached reservoirs' boundary rows (the
+        neighbour picks of direct_stage.comp:86-107 reach one pixel up / down): rt_run_stage levels 1 and 2"""
+        if self.comm.world > 1 and state.ReSTIRState in (abi.RESTIR_SPATIAL, abi.RESTIR_SPATIOTEMPORAL):
+            self._run(state, frames, abi.STAGE_DIRECT, 1, self.y0, self.y1, self.H)
+            t, p = self._t(abi.BUF_DIRECT_RESV_TEMP)
+            self.comm.halo_exchange([(t, p, self.part, 2, self.H)])
+            self._run(state, frames, abi.STAGE_DIRECT, 2, self.y0, self.y1, self.H)
+        else:
+            self._run(state, frames, abi.STAGE_DIRECT, 0, self.y0, self.y1, self.H)
+
     def _traced_stages(self, state, frames):
-        self._run(state, frames, abi.STAGE_DIRECT, 0, self.y0, self.y1, self.H)
+        self._direct(state, frames)
         self._run(state, frames, abi.STAGE_INDIRECT, 0, self.h0, self.h1, self.Hh)
 
     def render_frame(self, state, frames):
@@ -281,10 +293,6 @@ class TiledFrame:
         cur, last = frames & 1, (frames + 1) & 1
         single = c.world == 1
         self._last_frames = frames
-        if not single and state.ReSTIRState in (abi.RESTIR_SPATIAL, abi.RESTIR_SPATIOTEMPORAL):
-            # the spatial reuse step reads the cached reservoirs of the rows above / below the band (direct_stage.comp:86-107);
-            # that buffer is not part of the halo exchange
-            raise NotImplementedError("ReSTIRState eSpatial / eSpatiotemporal is single-GPU only in this build")
         c.wait(self._pending)
         self._pending = []
 
@@ -420,8 +428,6 @@ class PipelinedTiledFrame(TiledFrame):
         c, b = self.comm, self.b
         if c.world == 1:
             return super().render_frame(state, frames)
-        if state.ReSTIRState in (abi.RESTIR_SPATIAL, abi.RESTIR_SPATIOTEMPORAL):
-            raise NotImplementedError("ReSTIRState eSpatial / eSpatiotemporal is single-GPU only in this build")
         f, cur, last = frames, frames & 1, (frames + 1) & 1
         self._last_frames = frames
         self._rotate(f)
@@ -431,7 +437,7 @@ class PipelinedTiledFrame(TiledFrame):
             c.wait(self._wR.pop(cur, None))                                   # ... and the result band of f-2 has left
             c.wait(self._wD)                                                  # neighbours' history rows of f-1
             b.set_history_rows(max(0, self.y0 - HIST_HALO), min(self.H, self.y1 + HIST_HALO))
-            self._run(state, f, abi.STAGE_DIRECT, 0, self.y0, self.y1, self.H)
+            self._direct(state, f)
             # ---- 2. second half of frame f-1, issued while direct(f) runs: the host's wait for indirect(f-1)'s flag overlaps
             #         with direct(f) instead of following it
             self._finish_prev()
@@ -442,7 +448,7 @@ class PipelinedTiledFrame(TiledFrame):
                     t, p = self._t(buf)
                     c.all_gather_rows(t, p, self.part)
                 b.set_history_rows(0, self.H)
-                self._run(state, f, abi.STAGE_DIRECT, 0, self.y0, self.y1, self.H)
+                self._direct(state, f)
                 self._miss(abi.STAGE_DIRECT)  # clear
             items = []
             g, gp = self._t(abi.BUF_GBUFFER0 + cur)

@@ -267,7 +267,7 @@ typedef enum {
 
 /* per-frame stage selector for rt_run_stage — the dispatch list of renderer.cpp:163-205 */
 typedef enum {
-  RT_STAGE_DIRECT = 0,           /* direct_stage.comp  (live)                    */
+  RT_STAGE_DIRECT = 0,           /* direct_stage.comp  (live); rt_run_stage level 1 / 2: only the first / second half of the spatial-reuse modes (see rt_run_stage) */
   RT_STAGE_INDIRECT = 1,         /* indirect_stage.comp, half resolution         */
   RT_STAGE_DENOISE_DIRECT = 2,   /* denoise_direct.comp, level 0..3              */
   RT_STAGE_DENOISE_INDIRECT = 3, /* denoise_indirect.comp, level 0..4            */
@@ -331,7 +331,10 @@ int rt_set_camera(rt_ctx* ctx, const rt_scene_camera* cam);
 int rt_render_frame(rt_ctx* ctx, const rt_state* state, int frames);
 /* One dispatch of the list above, restricted to pixel rows [rowBegin,rowEnd) of the stage's own grid
  * (full-res rows for direct/denoise_direct/compose, half-res rows for indirect/denoise_indirect).
- * rowEnd <= 0 means "all rows".  Used for row-tiled multi-GPU frames. */
+ * rowEnd <= 0 means "all rows".  Used for row-tiled multi-GPU frames.
+ * `level`: the a-trous level for the two denoise stages.  For RT_STAGE_DIRECT with ReSTIRState eSpatial / eSpatiotemporal it selects
+ * the half of the stage: 0 = both, 1 = everything up to cacheTempReservoir (direct_stage.comp:224-235), 2 = the neighbour merges and
+ * the shading (:236-262) — a row-tiled host runs 1, exchanges the neighbouring rows of RT_BUF_DIRECT_RESV_TEMP, then runs 2. */
 int rt_run_stage(rt_ctx* ctx, const rt_state* state, int frames, int stage, int level, int rowBegin, int rowEnd);
 /* Copy a screen-space buffer to / from host memory in the reference element layout. Synchronous. */
 int rt_readback(rt_ctx* ctx, int buffer, void* dst, size_t bytes);
@@ -410,7 +413,8 @@ int rt_set_overlap(rt_ctx* ctx, int mode);
  *     rt_mgpu_create -> rt_mgpu_upload_scene (upload + BVH8 build on every device) -> rt_mgpu_resize
  *     per frame: rt_mgpu_set_camera, rt_mgpu_render_frame (returns when the frame is complete on every device)
  *     rt_mgpu_readback assembles a buffer of the last frame from the ranks that own its rows (same layout as rt_readback).
- * Every output is bit-identical to the single-GPU frame.  `devices` may name the same device more than once (used by the
+ * Every output is bit-identical to the single-GPU frame, in every ReSTIRState (the spatial-reuse modes run the direct stage in two
+ * halves around an exchange of the cached reservoirs' boundary rows).  `devices` may name the same device more than once (used by the
  * tests on a one-GPU machine).  The caller's thread discipline is the reference's: one thread issues the calls.
  * (One-process-per-GPU hosts use restir_amd/tiled.py over torch.distributed / RCCL instead.)
  * ---------------------------------------------------------------------------------------------------------------- */

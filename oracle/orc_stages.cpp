@@ -140,28 +140,32 @@ bool Frame::findTemporalNeighborDirect(const rt_state& st, int last, vec3 norm, 
 // ------------------------------------------------------------------------------------------------------------
 // direct_stage.comp  (the live direct pass)
 // ------------------------------------------------------------------------------------------------------------
-void Frame::directStage(const rt_state& st, int frames, int rowBegin, int rowEnd)
+void Frame::directStage(const rt_state& st, int frames, int rowBegin, int rowEnd, int phase)
 {
   const int cur = frames & 1, last = (frames + 1) & 1;
   // The reference does the spatial reuse inside the same dispatch, between barrier()s that only order one workgroup, reading
   // neighbours' tempDirectResv entries that other workgroups may or may not have written yet (a data race).  The race-free
-  // reading restated here: every pixel caches its reservoir first (pass 1), then every pixel merges (pass 2).
+  // reading restated here: every pixel caches its reservoir first (pass 1), then every pixel merges (pass 2).  `phase` 1 / 2
+  // runs one pass only (row-tiled hosts exchange the neighbouring rows of the cache in between); the parked pixels live in the Frame.
   const bool spatial = st.ReSTIRState == RT_RESTIR_SPATIAL || st.ReSTIRState == RT_RESTIR_SPATIOTEMPORAL;
-  std::vector<SpatialPending> pend(spatial ? size_t(st.size.x) * st.size.y : 0);
-  parallelRows(st.size.y, rowBegin, rowEnd, [&](int y) {
-    for(int x = 0; x < st.size.x; x++) {
-      Shader sh(*scene, st, cam);
-      sh.imageCoords = ivec2{x, y};
-      sh.seed = tea(uint32_t(st.size.x) * uint32_t(y) + uint32_t(x), st.time);  // :279
-      Ray ray = sh.raySpawn(sh.imageCoords, ivec2{st.size.x, st.size.y});
-      SpatialPending* P = spatial ? &pend[size_t(y) * st.size.x + x] : nullptr;
-      vec3 radiance = ReSTIRDirect(sh, ray, cur, last, P);
-      if(P && P->active) continue;
-      vec3 pixelColor = sh.clampRadiance(radiance);
-      storeImg(directResult[cur], sh.imageCoords, V4(pixelColor, 1.0f));  // :286
-    }
-  });
-  if(!spatial) return;
+  std::vector<SpatialPending>& pend = spatialPend;
+  if(spatial && pend.size() != size_t(st.size.x) * st.size.y) pend.assign(size_t(st.size.x) * st.size.y, SpatialPending());
+  if(phase != 2)
+    parallelRows(st.size.y, rowBegin, rowEnd, [&](int y) {
+      for(int x = 0; x < st.size.x; x++) {
+        Shader sh(*scene, st, cam);
+        sh.imageCoords = ivec2{x, y};
+        sh.seed = tea(uint32_t(st.size.x) * uint32_t(y) + uint32_t(x), st.time);  // :279
+        Ray ray = sh.raySpawn(sh.imageCoords, ivec2{st.size.x, st.size.y});
+        SpatialPending* P = spatial ? &pend[size_t(y) * st.size.x + x] : nullptr;
+        if(P) P->active = false;
+        vec3 radiance = ReSTIRDirect(sh, ray, cur, last, P);
+        if(P && P->active) continue;
+        vec3 pixelColor = sh.clampRadiance(radiance);
+        storeImg(directResult[cur], sh.imageCoords, V4(pixelColor, 1.0f));  // :286
+      }
+    });
+  if(!spatial || phase == 1) return;
   parallelRows(st.size.y, rowBegin, rowEnd, [&](int y) {
     for(int x = 0; x < st.size.x; x++) {
       const SpatialPending& P = pend[size_t(y) * st.size.x + x];
@@ -729,7 +733,7 @@ void Frame::compose(const rt_state& st, int frames, int rowBegin, int rowEnd)
 void Frame::runStage(const rt_state& st, int frames, int stage, int level, int rowBegin, int rowEnd)
 {
   switch(stage) {
-    case RT_STAGE_DIRECT: directStage(st, frames, rowBegin, rowEnd); break;
+    case RT_STAGE_DIRECT: directStage(st, frames, rowBegin, rowEnd, level); break;
     case RT_STAGE_INDIRECT: indirectStage(st, frames, rowBegin, rowEnd); break;
     case RT_STAGE_DENOISE_DIRECT: denoiseDirect(st, frames, level, rowBegin, rowEnd); break;
     case RT_STAGE_DENOISE_INDIRECT: denoiseIndirect(st, frames, level, rowBegin, rowEnd); break;

@@ -36,7 +36,7 @@ struct Frame {
   void renderFrame(const rt_state& st, int frames);
   void runStage(const rt_state& st, int frames, int stage, int level, int rowBegin, int rowEnd);
 
-  void directStage(const rt_state& st, int frames, int rowBegin, int rowEnd);
+  void directStage(const rt_state& st, int frames, int rowBegin, int rowEnd, int phase = 0);  // phase: rt_run_stage's `level` (0 both halves, 1 / 2 one)
   void directGen(const rt_state& st, int frames, int rowBegin, int rowEnd);
   void directReuse(const rt_state& st, int frames, int rowBegin, int rowEnd);
   void indirectStage(const rt_state& st, int frames, int rowBegin, int rowEnd);
@@ -61,6 +61,7 @@ struct Frame {
   // spatial / spatiotemporal reuse (direct_stage.comp:224-255): a pixel that reaches the reuse step parks what the rest of
   // ReSTIRDirect needs and finishes after every pixel of the frame has cached its reservoir (SpatialPending / finishSpatial)
   struct SpatialPending { bool active = false; State state; vec3 wo; float hitT = 0; uint32_t seed = 0; rt_direct_reservoir resv; };
+  std::vector<SpatialPending> spatialPend;   // parked pixels of the first half (kept between the two rt_run_stage calls of a split stage)
   vec3 ReSTIRDirect(Shader& sh, const Ray& r, int cur, int last, SpatialPending* pending);
   vec3 finishSpatial(Shader& sh, const SpatialPending& P, int cur);
   vec3 ReSTIRIndirect(Shader& sh, float dist, float primSamplePdf, vec3 primWo, State primState, rt_gi_sample gi, int cur, int last);

@@ -29,13 +29,14 @@ def _cams(sc, W, H, n, speed):
     return cams
 
 
-@pytest.mark.parametrize("world,balance,speed", [(3, True, 0.04), (4, False, 0.04), (8, True, 0.04), (3, True, 1.5)],
-                         ids=["3-balanced", "4-equal", "8-balanced", "3-fast-camera-fallback"])
-def test_mgpu_equals_single_gpu(world, balance, speed):
+@pytest.mark.parametrize("world,balance,speed,restir", [(3, True, 0.04, 3), (4, False, 0.04, 3), (8, True, 0.04, 3), (3, True, 1.5, 3), (3, True, 0.04, 4), (5, True, 0.04, 2)],
+                         ids=["3-balanced", "4-equal", "8-balanced", "3-fast-camera-fallback", "3-spatiotemporal", "5-spatial"])
+def test_mgpu_equals_single_gpu(world, balance, speed, restir):
     from restir_amd.renderer import Renderer, MultiGpuRenderer
     W, H, frames = 480, 272, 5
     sc, env = make_scene(abi.PROC_BISTRO_EXT, 0.02, 1, (256, 128))
     st = host.default_state(W, H, sc, env)
+    st.ReSTIRState = restir          # 3 = temporal (default), 2 / 4 = the spatial-reuse modes: direct stage in two halves around an exchange
     desc = sc.desc(env)
     cams = _cams(sc, W, H, frames, speed)
     ref = Renderer().setup(0); ref.load_scene(desc); ref.update(W, H)
@@ -50,7 +51,7 @@ def test_mgpu_equals_single_gpu(world, balance, speed):
         bands_seen.add(tuple(s.bandEnd[:world]))
         assert s.bandBegin[0] == 0 and s.bandEnd[world - 1] == H and all(s.bandEnd[r] == s.bandBegin[r + 1] for r in range(world - 1))
         assert all(s.bandEnd[r] > s.bandBegin[r] and s.bandBegin[r] % 16 == 0 for r in range(world))
-        for b in frame_buffers(f):
+        for b in frame_buffers(f) + ([abi.BUF_DIRECT_RESV_TEMP] if restir in (2, 4) else []):
             got, want = m.readback(b), ref.readback(b)
             if b in (abi.BUF_DENOISE_DIR_A, abi.BUF_DENOISE_DIR_B, abi.BUF_DENOISE_IND_A, abi.BUF_DENOISE_IND_B):
                 continue   # intermediates: valid on each rank's grown region only; the result images below depend on every level
@@ -80,7 +81,7 @@ def test_mgpu_single_rank_is_the_plain_frame():
         assert np.array_equal(m.readback(b), ref.readback(b)), abi.BUFFER_NAMES[b]
 
 
-def test_mgpu_refuses_spatial_reuse_and_bad_arguments():
+def test_mgpu_bad_arguments():
     from restir_amd.renderer import MultiGpuRenderer, RtError
     sc, env = make_scene(abi.PROC_CORNELL)
     st = host.default_state(64, 64, sc, None)
@@ -89,10 +90,6 @@ def test_mgpu_refuses_spatial_reuse_and_bad_arguments():
         m.run(st, 0)                                  # no target yet
     m.update(64, 64)
     sc.updateCamera(64, 64); m.set_camera(sc.getCamera())
-    st.ReSTIRState = abi.RESTIR_SPATIAL
-    with pytest.raises(RtError):
-        m.run(st, 0)
-    st.ReSTIRState = abi.RESTIR_TEMPORAL
     m.run(st, 0)
     with pytest.raises(RtError):
         MultiGpuRenderer().setup(_devices(2)).update(16, 16)   # fewer 16-row stripes than ranks

@@ -47,7 +47,7 @@ def _setup():
     return sc, env, st, o
 
 
-def _worker(rank, world, port, outdir, fast, pipelined=False, part=None, replan=False):
+def _worker(rank, world, port, outdir, fast, pipelined=False, part=None, replan=False, restir=None):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -55,6 +55,7 @@ def _worker(rank, world, port, outdir, fast, pipelined=False, part=None, replan=
     if fast:
         tiled.HIST_HALO = 0   # no history halo: the first cross-band reprojection must trigger the exact fallback
     sc, env, st, o = _setup()
+    if restir is not None: st.ReSTIRState = restir
     frame = (tiled.PipelinedTiledFrame if pipelined else tiled.TiledFrame)(OracleTensors(o), tiled.TorchComm(), W, H, part)
     sc.updateCamera(W, H)
     for f in range(FRAMES):
@@ -152,6 +153,33 @@ def test_uneven_partitions_equal_untiled(world, mode, pipelined, tmp_path):
         from restir_amd import tiled
         eq = tiled.equal_partition(H, world)
         assert ends[-1] == H and (ends[-1] - ends[-2]) < (eq[-1] - eq[-2])
+
+
+@pytest.mark.parametrize("pipelined", [False, True], ids=["serial", "frames-in-flight"])
+@pytest.mark.parametrize("restir", [abi.RESTIR_SPATIAL, abi.RESTIR_SPATIOTEMPORAL], ids=["spatial", "spatiotemporal"])
+def test_spatial_reuse_tiled_equals_untiled(restir, pipelined, tmp_path):
+    """the spatial-reuse modes across bands: direct stage in two halves (rt_run_stage levels 1 / 2) around an exchange of the cached
+    reservoirs' boundary rows; a 16-row band in the middle makes both of its neighbours' picks cross a boundary"""
+    world = 3
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), False, pipelined, UNEVEN[world], 0, restir), nprocs=world, join=True)
+    got = np.load(os.path.join(tmp_path, f"tiled_{world}.npz"))
+    sc, env, st, o = _setup()
+    st.ReSTIRState = restir
+    sc.updateCamera(W, H)
+    for f in range(FRAMES):
+        st.time = 900 + f; _camera(sc, f, False); sc.updateCamera(W, H); o.set_camera(sc.getCamera()); o.render_frame(st, f)
+    cur = (FRAMES - 1) & 1
+    for b in _result_buffers(cur) + _result_buffers(cur ^ 1):
+        assert np.array_equal(got[abi.BUFFER_NAMES[b]], o.readback(b)), abi.BUFFER_NAMES[b]
+    for rank in range(world):
+        band = np.load(os.path.join(tmp_path, f"band_{world}_{rank}.npz"))
+        y0, y1, h0, h1 = (int(v) for v in band["rows"])
+        for b in _history_buffers(cur):
+            name = abi.BUFFER_NAMES[b]
+            half = name.startswith("indirect")
+            w, a, e = (W // 2, h0, h1) if half else (W, y0, y1)
+            elem = _ELEM[name[:-1]]
+            assert np.array_equal(band[name].reshape(-1, w * elem)[a:e], o.readback(b).reshape(-1, w * elem)[a:e]), (name, rank)
 
 
 def test_band_partition():
