@@ -63,6 +63,8 @@ struct Rank {
 
 }  // namespace
 
+extern "C" int rt_mgpu_plan_bands(int height, int numRanks, const float* stripeCost, const int* prevBands, int maxMoveStripes, int* outBands);
+
 struct rt_mgpu {
   int n = 0;
   std::vector<Rank> ranks;
@@ -294,29 +296,41 @@ void rebalance(rt_mgpu* M)
     for(int s = a; s < b; s++) M->stripeCost[size_t(s)] = 0.5f * M->stripeCost[size_t(s)] + 0.5f * per;
   }
   if(!M->balance || n == 1) return;
-  double total = 0; for(float c : M->stripeCost) total += c;
   std::vector<int> nb(size_t(n) + 1, 0);
-  double acc = 0; int r = 1;
-  for(int s = 0; s < stripes && r < n; s++) {
-    acc += M->stripeCost[size_t(s)];
-    while(r < n && acc >= total * r / n) { nb[size_t(r)] = s + 1; r++; }
-  }
-  for(; r < n; r++) nb[size_t(r)] = stripes;
-  nb[size_t(n)] = stripes;
-  for(int k = 1; k < n; k++) {
-    const int old = M->bands[size_t(k)] / 16;
-    int v = std::max(old - 2, std::min(old + 2, nb[size_t(k)]));
-    v = std::max(v, nb[size_t(k) - 1] + 1);                 // every rank keeps at least one stripe
-    v = std::min(v, stripes - (n - k));
-    nb[size_t(k)] = v;
-  }
-  for(int k = 0; k <= n; k++) M->bands[size_t(k)] = std::min(M->H, nb[size_t(k)] * 16);
-  M->bands[size_t(n)] = M->H;
+  rt_mgpu_plan_bands(M->H, n, M->stripeCost.data(), M->bands.data(), 2, nb.data());
+  M->bands = nb;
 }
 
 }  // namespace
 
 extern "C" {
+
+// Band boundaries that equalise the summed per-stripe cost (a stripe = 16 rows): every rank keeps at least one stripe; with prevBands a
+// boundary moves at most maxMoveStripes stripes.  Pure host arithmetic (no device needed); the same rule as tiled.plan_bands.
+int rt_mgpu_plan_bands(int height, int numRanks, const float* stripeCost, const int* prevBands, int maxMoveStripes, int* outBands)
+{
+  const int stripes = (height + 15) / 16, n = numRanks;
+  if(height <= 0 || n < 1 || !stripeCost || !outBands || stripes < n) return RT_ERR_INVALID_ARG;
+  double total = 0; for(int s = 0; s < stripes; s++) total += std::max(1e-9, double(stripeCost[s]));
+  std::vector<int> nb(size_t(n) + 1, 0);
+  double acc = 0; int r = 1;
+  for(int s = 0; s < stripes && r < n; s++) {
+    acc += std::max(1e-9, double(stripeCost[s]));
+    while(r < n && acc >= total * r / n) { nb[size_t(r)] = s + 1; r++; }
+  }
+  for(; r < n; r++) nb[size_t(r)] = stripes;
+  nb[size_t(n)] = stripes;
+  for(int k = 1; k < n; k++) {
+    int v = nb[size_t(k)];
+    if(prevBands && maxMoveStripes >= 0) { const int old = prevBands[k] / 16; v = std::max(old - maxMoveStripes, std::min(old + maxMoveStripes, v)); }
+    v = std::max(v, nb[size_t(k) - 1] + 1);                 // every rank keeps at least one stripe
+    v = std::min(v, stripes - (n - k));
+    nb[size_t(k)] = v;
+  }
+  for(int k = 0; k <= n; k++) outBands[k] = std::min(height, nb[size_t(k)] * 16);
+  outBands[n] = height;
+  return RT_OK;
+}
 
 int rt_mgpu_create(rt_mgpu** out, int numRanks, const int* devices)
 {

@@ -17,7 +17,7 @@ ABI_SYMBOLS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "r
                "rt_render_frame", "rt_run_stage", "rt_readback", "rt_upload_history", "rt_buffer_bytes", "rt_device_ptr",
                "rt_set_counting", "rt_get_counters", "rt_sync", "rt_last_error", "rt_abi_version", "rt_set_pipeline", "rt_set_history_rows", "rt_history_miss", "rt_set_overlap", "rt_tonemap", "rt_set_sun_and_sky", "rt_pick", "rt_history_miss_stage", "rt_rotate_buffers", "rt_measure_valu_peak",
                "rt_mgpu_create", "rt_mgpu_destroy", "rt_mgpu_upload_scene", "rt_mgpu_resize", "rt_mgpu_set_camera", "rt_mgpu_render_frame", "rt_mgpu_readback",
-               "rt_mgpu_sync", "rt_mgpu_set_balance", "rt_mgpu_set_serialize", "rt_mgpu_get_stats", "rt_mgpu_last_error"]
+               "rt_mgpu_sync", "rt_mgpu_set_balance", "rt_mgpu_set_serialize", "rt_mgpu_get_stats", "rt_mgpu_last_error", "rt_mgpu_plan_bands"]
 
 
 def hip_lib():
@@ -75,6 +75,7 @@ def hip_lib():
         L.rt_mgpu_set_serialize.argtypes = [C.c_void_p, C.c_int]
         L.rt_mgpu_get_stats.argtypes = [C.c_void_p, C.c_void_p]
         L.rt_mgpu_last_error.argtypes = [C.c_void_p]; L.rt_mgpu_last_error.restype = C.c_char_p
+        L.rt_mgpu_plan_bands.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.rt_accel_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
         _lib = L
     return _lib

@@ -441,6 +441,9 @@ int rt_mgpu_sync(rt_mgpu* m);
 int rt_mgpu_set_balance(rt_mgpu* m, int mode);    /* 1 (default): cost-weighted band heights; 0: equal heights */
 int rt_mgpu_set_serialize(rt_mgpu* m, int on);    /* measurement aid when several ranks share ONE device: ranks take turns on the GPU */
 int rt_mgpu_get_stats(rt_mgpu* m, rt_mgpu_stats* out);
+/* The partition rule on its own (pure host arithmetic): boundaries (numRanks + 1 rows, multiples of 16) that equalise the summed cost of the
+ * 16-row stripes; with prevBands a boundary moves at most maxMoveStripes stripes (< 0: unlimited); every rank keeps >= one stripe. */
+int rt_mgpu_plan_bands(int height, int numRanks, const float* stripeCost, const int* prevBands, int maxMoveStripes, int* outBands);
 const char* rt_mgpu_last_error(rt_mgpu* m);
 
 /* Measured VALU issue ceiling of the device the ctx lives on (csrc/microbench.hip): wave-level VALU instructions per second of a

@@ -54,3 +54,25 @@ def test_header_is_valid_c_and_cpp(tmp_path):
     (tmp_path / "t.cpp").write_text('#include "rt_abi.h"\n#include "rt_detmath.h"\nint main() { rt_scene_desc d{}; (void)d; return rt_sin(0.0f) != 0.0f; }\n')
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", inc, str(tmp_path / "t.cpp"), "-o", str(tmp_path / "tcpp")])
     assert subprocess.call([str(tmp_path / "tcpp")]) == 0
+
+
+def test_mgpu_band_planner_matches_the_python_planner():
+    """rt_mgpu_plan_bands (csrc/mgpu.cpp, no GPU needed) and tiled.plan_bands implement one rule: same boundaries on random costs"""
+    import ctypes as C
+    import numpy as np
+    from restir_amd import renderer, tiled
+    lib = renderer.hip_lib()
+    rng = np.random.default_rng(9)
+    for _ in range(200):
+        H = int(rng.integers(64, 2200)); world = int(rng.integers(1, min(8, (H + 15) // 16) + 1))
+        stripes = (H + 15) // 16
+        cost = (rng.random(stripes) ** 3 * 10 + 0.01).astype(np.float32)
+        prev = np.array(tiled.equal_partition(H, world) if rng.integers(2) else tiled.plan_bands(H, world, rng.random(stripes) + 0.1), dtype=np.int32)
+        use_prev = bool(rng.integers(2)); mv = int(rng.integers(0, 5))
+        out = np.zeros(world + 1, dtype=np.int32)
+        rc = lib.rt_mgpu_plan_bands(H, world, cost.ctypes.data, prev.ctypes.data if use_prev else None, mv if use_prev else -1, out.ctypes.data)
+        assert rc == 0
+        want = tiled.plan_bands(H, world, [float(c) for c in cost], prev=[int(p) for p in prev] if use_prev else None, max_move=mv if use_prev else None)
+        assert list(out) == want, (H, world, list(out), want)
+        assert out[0] == 0 and out[-1] == H and all(b % 16 == 0 for b in out[:-1]) and all(out[i + 1] > out[i] for i in range(world))
+    assert lib.rt_mgpu_plan_bands(32, 4, cost.ctypes.data, None, -1, out.ctypes.data) != 0     # fewer stripes than ranks
