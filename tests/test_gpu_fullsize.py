@@ -129,11 +129,14 @@ class ThreadComm:
     def barrier(self): self.s["barrier"].wait()
 
 
-@pytest.mark.parametrize("mode", ["serial", "serial-fallbacks", "frames-in-flight", "frames-in-flight-fallbacks", "frames-in-flight-uneven", "frames-in-flight-rebalance"])
+@pytest.mark.parametrize("mode", ["serial", "serial-fallbacks", "frames-in-flight", "frames-in-flight-fallbacks", "frames-in-flight-uneven", "frames-in-flight-rebalance", "frames-in-flight-spatial", "serial-spatial"])
 def test_tiled_three_ranks_equals_untiled(bistro, mode, monkeypatch):
     import torch
     from restir_amd import tiled
     sc, env, st, cam = bistro
+    import copy
+    st = copy.copy(st)
+    if mode.endswith("spatial"): st.ReSTIRState = abi.RESTIR_SPATIOTEMPORAL   # direct stage in two halves around an exchange of the cache's boundary rows
     world, frames = 3, (2 if mode == "serial" else 4)
     Frame = tiled.TiledFrame if mode.startswith("serial") else tiled.PipelinedTiledFrame
     part0 = [0, 496, 560, H] if mode.endswith("uneven") else None    # a 64-row band at the horizon: every halo spans more than one rank
