@@ -10,25 +10,37 @@ struct TileCoord { int x, y; bool valid; };
 // XCD-aware tile order.  Workgroup L runs on XCD L % 8 (observed placement; used for speed only).  The screen is cut into
 // stripes of TILE_STRIPE tile rows; stripe s belongs to XCD s % 8, so every XCD's private L2 works on a few compact screen
 // regions (and the BVH subtrees under them) while expensive image regions (foliage rows vs sky rows) are spread over all XCDs.
-constexpr int TILE_STRIPE = 2;
+#ifndef RT_TILE_STRIPE
+#define RT_TILE_STRIPE 1
+#endif
+#ifndef RT_TILE_CHUNK
+#define RT_TILE_CHUNK 0      // > 0: chunks of this many tiles (row-major tile order) instead of stripes of whole tile rows
+#endif
+constexpr int TILE_STRIPE = RT_TILE_STRIPE;
+// tiles per chunk; chunk c (row-major tile order) belongs to XCD c % 8.  Measured on the 1080p bench scene (frames in flight, ms/frame):
+// stripes of 8 / 4 / 2 / 1 tile rows: 3.70 / 3.39 / 3.23 / 3.15 — the finer the interleave, the better the XCDs are balanced
+// (sky rows vs street rows); profiles/r02_tile_order_ab.txt has the chunked variants.
+__host__ __device__ inline int tileChunk(int tilesX) { return RT_TILE_CHUNK > 0 ? RT_TILE_CHUNK : TILE_STRIPE * tilesX; }
 RT_DEV TileCoord tileOfBlock(int L, int tilesX, int tilesY)
 {
   const int xcd = L & 7, k = L >> 3;                 // k-th workgroup of this XCD
-  const int perStripe = TILE_STRIPE * tilesX;
-  const int s = k / perStripe, off = k - s * perStripe;
-  TileCoord t;
-  t.y = (s * 8 + xcd) * TILE_STRIPE + off / tilesX;
-  t.x = off % tilesX;
-  t.valid = t.y < tilesY;
-  return t;
+  const int G = tileChunk(tilesX);
+  const int j = k / G, off = k - j * G;
+  const int t = (j * 8 + xcd) * G + off;             // row-major tile index
+  TileCoord tc;
+  tc.y = t / tilesX;
+  tc.x = t - tc.y * tilesX;
+  tc.valid = t < tilesX * tilesY;
+  return tc;
 }
 RT_DEV TileCoord tileOf(int tilesX, int tilesY) { return tileOfBlock(int(blockIdx.x), tilesX, tilesY); }
 // grid size (in workgroups) that covers tilesX x tilesY tiles with the mapping above
 inline unsigned tileGrid(int tilesX, int tilesY)
 {
-  const int stripes = (tilesY + TILE_STRIPE - 1) / TILE_STRIPE;
-  const int perXcd = (stripes + 7) / 8;
-  return unsigned(8 * perXcd * TILE_STRIPE * tilesX);
+  const int G = tileChunk(tilesX);
+  const int chunks = (tilesX * tilesY + G - 1) / G;
+  const int perXcd = (chunks + 7) / 8;
+  return unsigned(8 * perXcd * G);
 }
 
 #ifndef RT_COUNT

@@ -39,8 +39,10 @@ namespace RT_VARIANT {
 // ------------------------------------------------------------------------------------------------------------
 // direct_stage.comp
 // ------------------------------------------------------------------------------------------------------------
+// launch bounds of the two traced kernels, re-measured in round 2 under the final schedule (frames in flight, ms/frame, same box):
+// (direct, indirect) waves per SIMD = (5,5) 3.155, (4,5) 3.121, (4,4) 3.29, (5,4) 3.59, (3,5) 3.16, (4,6) 3.15  =>  (4, 5)
 #ifndef RT_DIRECT_LB
-#define RT_DIRECT_LB 5
+#define RT_DIRECT_LB 4
 #endif
 __global__ __launch_bounds__(64, RT_DIRECT_LB) void k_direct_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY)
 {
@@ -272,11 +274,13 @@ __global__ __launch_bounds__(256) void k_ind_tile_order(rt_state st, int rowBegi
   __syncthreads();
   uint32_t* list = lists + size_t(xcd) * cap;
   const int indW = st.size.x / 2;
-  const int stripes = (tilesY + TILE_STRIPE - 1) / TILE_STRIPE;
-  for(int s = xcd; s < stripes; s += 8) {
-    for(int i = int(threadIdx.x); i < TILE_STRIPE * tilesX; i += int(blockDim.x)) {
-      const int ty = s * TILE_STRIPE + i / tilesX, tx = i % tilesX;
-      if(ty >= tilesY) continue;
+  const int G = tileChunk(tilesX), nTiles = tilesX * tilesY;
+  const int chunks = (nTiles + G - 1) / G;
+  for(int s = xcd; s < chunks; s += 8) {
+    for(int i = int(threadIdx.x); i < G; i += int(blockDim.x)) {
+      const int ti = s * G + i;
+      if(ti >= nTiles) continue;
+      const int ty = ti / tilesX, tx = ti - ty * tilesX;
       uint32_t seed = tea(uint32_t(indW) * uint32_t(rowBegin + ty * 8) + uint32_t(tx * 8), st.time);
       const bool mb = rnd(seed) < 0.25f;
       const uint32_t t = uint32_t(ty * tilesX + tx);
