@@ -90,6 +90,8 @@ struct DevFrame {
   uint32_t* histMiss;
   // highest a-trous level that runs on the LDS-tile filter kernel (k_denoise_tile), -1 = none: chosen per launch by rt_api.cpp
   int32_t denoiseTileMax;
+  // highest a-trous level of the DIRECT filter that runs on the one-wave LDS-staged kernel (k_denoise_lds), -1 = none; takes precedence over the tile kernel
+  int32_t denoiseLdsMax;
 };
 
 }  // namespace rt

@@ -519,6 +519,8 @@ static DevFrame makeFrame(rt_ctx* c, int frames)
   // the frames-in-flight schedule keeps the per-pixel gather.  RESTIR_DENOISE_TILE=<max level | -1> overrides.
   static const int tileEnv = getenv("RESTIR_DENOISE_TILE") ? atoi(getenv("RESTIR_DENOISE_TILE")) : -2;
   F.denoiseTileMax = tileEnv != -2 ? tileEnv : (c->overlap == 2 ? -1 : 1);
+  static const int ldsEnv = getenv("RESTIR_DENOISE_LDS") ? atoi(getenv("RESTIR_DENOISE_LDS")) : -2;
+  F.denoiseLdsMax = ldsEnv != -2 ? ldsEnv : (c->overlap == 2 ? -1 : 3);
   F.thisG = static_cast<uint4*>(c->bufs[RT_BUF_GBUFFER0 + cur]); F.lastG = static_cast<const uint4*>(c->bufs[RT_BUF_GBUFFER0 + last]);
   F.motion = static_cast<short2*>(c->bufs[RT_BUF_MOTION]);
   F.thisDirectResv = static_cast<rt_direct_reservoir*>(c->bufs[RT_BUF_DIRECT_RESV0 + cur]);

@@ -934,6 +934,86 @@ __global__ __launch_bounds__(256) void k_denoise_tile(DevFrame F, rt_state st, c
   }
 }
 
+// The same filter with the inputs of ONE wave staged in LDS: a 64-thread workgroup takes an 8 x 8 tile of one a-trous sub-lattice, stages
+// colour (+ luminance), normal + material hash and position of the tile and its 2-pixel ring (12 x 12 lattice pixels, 6.9 KB) and every lane
+// reads its 25 taps from there: 7 global loads per lane instead of 75.  The gather kernel keeps the texture-address path 66-82 % busy when it
+// runs alone (TA_BUSY, profiles/r02_denoise_lds_ab.txt) and shares that path with the traversal kernels when frames are in flight; this one
+// needs a tenth of it, and — unlike k_denoise_tile — its one-wave workgroups fit into any free wave slot.  No weight sharing: every tap is
+// evaluated as in k_denoise, in the same order, with the same expressions.
+constexpr int DL_T = 8, DL_S = DL_T + 4;
+template <bool IND, bool FAST>
+__global__ __launch_bounds__(64) void k_denoise_lds(DevFrame F, rt_state st, const float4* src, float4* dst, int level, int rowBegin, int rowEnd, int tilesX, int tilesY,
+                                                    float yL, float yN, float yD)
+{
+  __shared__ float4 sC[DL_S * DL_S];
+  __shared__ float4 sN[DL_S * DL_S];
+  __shared__ float4 sP[DL_S * DL_S];
+  const int step = 1 << level;
+  const int total = tilesX * tilesY * step * step, perXcd = (total + 7) / 8;
+  const int local = int(blockIdx.x >> 3);
+  const int work = int(blockIdx.x & 7u) * perXcd + local;      // consecutive work items (the sub-lattices of one region share cache lines) on one XCD
+  if(local >= perXcd || work >= total) return;
+  const int sub = work % (step * step), tileIdx = work / (step * step);
+  const int a = sub % step, b = sub / step;
+  const int X0 = (tileIdx % tilesX) * DL_T, Y0 = (tileIdx / tilesX) * DL_T;
+  const i2 bound = IND ? i2{st.size.x / 2, st.size.y / 2} : i2{st.size.x, st.size.y};
+  const float sigLumin = IND ? st.sigLuminIndirect : st.sigLuminDirect;
+  const float sigNormal = IND ? st.sigNormalIndirect : st.sigNormalDirect;
+  const float sigDepth = IND ? st.sigDepthIndirect : st.sigDepthDirect;
+  const int last = IND ? 4 : 3;
+  const float4* gN = IND ? F.geomNh : F.geomN;
+  const float4* gP = IND ? F.geomPh : F.geomP;
+  const int lane = int(threadIdx.x);
+#pragma unroll
+  for(int it = 0; it < 3; it++) {
+    const int idx = lane + 64 * it;
+    if(idx < DL_S * DL_S) {
+      const int lx = idx % DL_S, ly = idx / DL_S;
+      const int px = a + step * (X0 - 2 + lx), py = rowBegin + b + step * (Y0 - 2 + ly);
+      float4 c = make_float4(0.f, 0.f, 0.f, 0.f), n = make_float4(0.f, 0.f, 0.f, rt_u2f(RT_INVALID_MAT_ID)), q = make_float4(0.f, 0.f, 0.f, 0.f);
+      if(px >= 0 && py >= 0 && px < bound.x && py < bound.y) {
+        const size_t gi = size_t(py) * bound.x + px;
+        n = gN[gi]; q = gP[gi];
+        c = src[size_t(py) * F.W + px];
+        c.w = IND ? 0.0f : luminance(mk3(c.x, c.y, c.z));
+      }
+      sC[idx] = c; sN[idx] = n; sP[idx] = q;
+    }
+  }
+  __syncthreads();
+  const int ux = lane & 7, uy = lane >> 3;
+  const i2 coord{a + step * (X0 + ux), rowBegin + b + step * (Y0 + uy)};
+  if(coord.x >= bound.x || coord.y >= bound.y || coord.y >= rowEnd) return;
+  const int cidx = (uy + 2) * DL_S + (ux + 2);
+  const float4 cN = sN[cidx];
+  const uint32_t hash = rt_f2u(cN.w);
+  f3 res = mk3(0.0f);
+  if(hash != RT_INVALID_MAT_ID) {
+    const float4 cC = sC[cidx], cP = sP[cidx];
+    const f3 color = mk3(cC.x, cC.y, cC.z), norm = mk3(cN.x, cN.y, cN.z), pos = mk3(cP.x, cP.y, cP.z);
+    f3 sum = mk3(0.0f);
+    float sumWeight = 0.0f;
+#pragma unroll
+    for(int j = -2; j <= 2; j++)
+#pragma unroll
+      for(int i = -2; i <= 2; i++) {
+        const int qidx = cidx + j * DL_S + i;
+        const float4 qN = sN[qidx];
+        if(rt_f2u(qN.w) == hash) {
+          const float4 qP = sP[qidx], qC = sC[qidx];
+          const float w = denoisePairWeight<IND, FAST>(color, cC.w, norm, pos, mk3(qC.x, qC.y, qC.z), qC.w, mk3(qN.x, qN.y, qN.z), mk3(qP.x, qP.y, qP.z), kGauss[i + 2][j + 2],
+                                                       sigLumin, sigNormal, sigDepth, yL, yN, yD);
+          sum += mk3(qC.x, qC.y, qC.z) * w;
+          sumWeight += w;
+        }
+      }
+    res = (sumWeight < 1e-5f) ? mk3(0.0f) : sum / sumWeight;
+    if(hasNan(res) || res.x < 0 || res.y < 0 || res.z < 0 || res.x > 1e8f || res.y > 1e8f || res.z > 1e8f) res = mk3(0.0f);
+  }
+  if(level == last) res = LDRToHDR(res);
+  storeImg(dst, F, coord, mk4(res, 1.0f));
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // compose.comp:23-43
 // ------------------------------------------------------------------------------------------------------------
@@ -964,6 +1044,8 @@ __global__ __launch_bounds__(64) void k_compose(DevFrame F, rt_state st, int row
 static bool uniformDivOk(float s) { return s >= 1e-6f && s <= 1e6f; }
 // RESTIR_DENOISE_WGS: upper bound of resident k_denoise_tile workgroups (multiple of 8; each holds 36.5 KB of LDS); default: one per work item
 static unsigned denoiseTileGridCap() { static const unsigned v = getenv("RESTIR_DENOISE_WGS") ? (unsigned(atoi(getenv("RESTIR_DENOISE_WGS"))) + 7u) / 8u * 8u : 1u << 30; return std::max(8u, v); }
+// RESTIR_DENOISE_LDS_IND: highest level of the INDIRECT filter on k_denoise_lds (measurement only; default none: the tile / gather pair is faster there)
+static int denoiseLdsMaxIndirect() { static const int v = getenv("RESTIR_DENOISE_LDS_IND") ? atoi(getenv("RESTIR_DENOISE_LDS_IND")) : -1; return v; }
 // RESTIR_DENOISE_TILE=0 selects the per-pixel gather kernels (k_denoise) for A/B runs; results are bit-identical
 
 hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F, const rt_state& st, const rt_scene_camera& cam, int stage, int level,
@@ -1019,6 +1101,16 @@ hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F,
         const int gty = (g1 - g0 + 7) / 8;
         hipLaunchKernelGGL(k_denoise_geom<false>, dim3(tileGrid(tilesX, gty)), block, 0, stream, F, st, cam, g0, g1, tilesX, gty);
       }
+      if(level <= F.denoiseLdsMax) {
+        const int stp = 1 << level, ltx = ((gw + stp - 1) / stp + DL_T - 1) / DL_T, lty = ((rowEnd - rowBegin + stp - 1) / stp + DL_T - 1) / DL_T;
+        const unsigned nwg = 8u * unsigned((ltx * lty * stp * stp + 7) / 8);
+        if(uniformDivOk(st.sigLuminDirect) && uniformDivOk(st.sigNormalDirect) && uniformDivOk(st.sigDepthDirect))
+          hipLaunchKernelGGL((k_denoise_lds<false, true>), dim3(nwg), dim3(64), 0, stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, ltx, lty,
+                             1.0f / st.sigLuminDirect, 1.0f / st.sigNormalDirect, 1.0f / st.sigDepthDirect);
+        else
+          hipLaunchKernelGGL((k_denoise_lds<false, false>), dim3(nwg), dim3(64), 0, stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, ltx, lty, 0.f, 0.f, 0.f);
+        break;
+      }
       if(level <= F.denoiseTileMax) {
         const int stp = 1 << level, ltx = ((gw + stp - 1) / stp + DT_T - 1) / DT_T, lty = ((rowEnd - rowBegin + stp - 1) / stp + DT_T - 1) / DT_T;
         const unsigned nwg = std::min(8u * unsigned((ltx * lty * stp * stp + 7) / 8), denoiseTileGridCap());
@@ -1055,6 +1147,16 @@ hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F,
                              1.0f / st.sigLuminIndirect, 1.0f / st.sigNormalIndirect, 1.0f / st.sigDepthIndirect);
         else
           hipLaunchKernelGGL((k_denoise_tile<true, false>), dim3(nwg), dim3(256), 0, stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, ltx, lty, 0.f, 0.f, 0.f);
+        break;
+      }
+      if(level <= denoiseLdsMaxIndirect()) {
+        const int stp = 1 << level, ltx = ((gw + stp - 1) / stp + DL_T - 1) / DL_T, lty = ((rowEnd - rowBegin + stp - 1) / stp + DL_T - 1) / DL_T;
+        const unsigned nwg = 8u * unsigned((ltx * lty * stp * stp + 7) / 8);
+        if(uniformDivOk(st.sigLuminIndirect) && uniformDivOk(st.sigNormalIndirect) && uniformDivOk(st.sigDepthIndirect))
+          hipLaunchKernelGGL((k_denoise_lds<true, true>), dim3(nwg), dim3(64), 0, stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, ltx, lty,
+                             1.0f / st.sigLuminIndirect, 1.0f / st.sigNormalIndirect, 1.0f / st.sigDepthIndirect);
+        else
+          hipLaunchKernelGGL((k_denoise_lds<true, false>), dim3(nwg), dim3(64), 0, stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, ltx, lty, 0.f, 0.f, 0.f);
         break;
       }
       if(uniformDivOk(st.sigLuminIndirect) && uniformDivOk(st.sigNormalIndirect) && uniformDivOk(st.sigDepthIndirect))
