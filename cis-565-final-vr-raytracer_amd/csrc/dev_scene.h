@@ -39,10 +39,14 @@ struct DevScene {
   int32_t envW, envH;
   uint32_t numTris, numNodes;
   const struct SkyPre* sky;         // != nullptr: procedural sun & sky replaces the HDR map (_sunAndSky.in_use == 1)
-  int32_t stackEntries;             // LDS traversal stack entries per lane for this tree (multiple of 4, >= max depth)
+  int32_t stackEntries;             // traversal stack entries per lane held in LDS (8 B each); entries beyond that live in stackOvf
   int32_t coopLive;                 // traversal: cooperative triangle steps when at most this many rays of a wave are live (0 = off)
   float triPad;                     // box padding of the build (2e-5 x largest |coordinate|): an accepted hit point lies inside its triangle's padded box
-  int32_t pad2;
+  int32_t stackTotal;               // stack entries a ray of this tree can need (multiple of 4, > max depth); stackTotal - stackEntries per thread sit in HBM
+  // overflow part of the traversal stacks: (stackTotal - stackEntries) entries per thread of a launch, thread = blockIdx.x * blockDim.x + threadIdx.x.
+  // Two areas, because a direct-kind and an indirect-kind kernel can be in flight together; the launchers point stackOvf at the one of their stage.
+  uint2* stackOvf; uint2* stackOvfInd;
+  uint32_t stackOvfThreads; uint32_t pad3;
 };
 
 // wavefront scratch records (internal; never cross the ABI)
@@ -92,6 +96,8 @@ struct DevFrame {
   int32_t denoiseTileMax;
   // highest a-trous level of the DIRECT filter that runs on the one-wave LDS-staged kernel (k_denoise_lds), -1 = none; takes precedence over the tile kernel
   int32_t denoiseLdsMax;
+  int32_t stackLds;                 // traversal stack entries per lane kept in LDS by this frame's traced launches (0 = the whole stack); the rest sits in DevScene::stackOvf
+  int32_t denoiseLdsMaxInd;         // the same for the INDIRECT filter, after the tile kernel's levels
 };
 
 }  // namespace rt

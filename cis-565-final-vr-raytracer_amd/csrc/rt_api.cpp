@@ -38,7 +38,7 @@ struct rt_ctx {
   std::vector<rt_material> materials; std::vector<DevTexture> devTextures;
   std::vector<std::vector<uint8_t>> hostAlpha;  // alpha channel of every texture (opacity micro-map build)
   // device allocations of the scene
-  std::vector<void*> sceneAllocs, accelAllocs;
+  std::vector<void*> sceneAllocs, accelAllocs, ovfAllocs;
   DevScene ds{};
   bool haveScene = false, haveAccel = false;
   int maxDepth = 0; size_t numNodes = 0, numTris = 0;
@@ -187,6 +187,9 @@ template <class T> static int upload(rt_ctx* c, std::vector<void*>& pool, const 
   return RT_OK;
 }
 static void freePool(std::vector<void*>& pool) { for(void* p : pool) (void)hipFree(p); pool.clear(); }
+static int ensureStackOverflow(rt_ctx* c);
+static int stackLdsEnv() { static const int v = getenv("RESTIR_STACK_LDS") ? std::max(2, atoi(getenv("RESTIR_STACK_LDS"))) : 0; return v; }
+static int stackLdsMin() { return stackLdsEnv() ? stackLdsEnv() : 6; }   // the shortest LDS stack any schedule uses: sizes the overflow areas
 
 static size_t elemBytes(int id)
 {
@@ -258,7 +261,7 @@ int rt_destroy(rt_ctx* c)
   if(!c) return RT_ERR_INVALID_ARG;
   (void)hipSetDevice(c->device);
   (void)syncAll(c);
-  freePool(c->sceneAllocs); freePool(c->accelAllocs); freePool(c->scratchAllocs);
+  freePool(c->sceneAllocs); freePool(c->accelAllocs); freePool(c->scratchAllocs); freePool(c->ovfAllocs);
   for(int i = 0; i < RT_BUF_COUNT; i++) if(c->bufs[i]) (void)hipFree(c->bufs[i]);
   if(c->spareG) (void)hipFree(c->spareG);
   if(c->spareMotion) (void)hipFree(c->spareMotion);
@@ -443,13 +446,17 @@ int rt_build_accel(rt_ctx* c)
   if((rc = upload(c, c->accelAllocs, bo.triRef.data(), bo.triRef.size(), &c->ds.triRef))) return rc;
   if((rc = upload(c, c->accelAllocs, bo.instances.data(), bo.instances.size(), &c->ds.instances))) return rc;
   c->ds.numNodes = uint32_t(bo.nodes.size()); c->ds.numTris = uint32_t(bo.tris.size());
-  c->ds.stackEntries = std::max(8, ((bo.maxDepth + 1 + 3) / 4) * 4);
+  // traversal stack: what a ray of this tree can need.  How much of it each lane keeps in LDS is a per-launch choice (stackLdsEntries below): with frames
+  // in flight 6 entries = 3 KB per wave (measured, profiles/r02_short_stack_ab.txt), deeper entries in a per-thread area in HBM (ensureStackOverflow);
+  // serial schedules have the LDS to themselves and keep the whole stack there.  RESTIR_STACK_LDS=<n> forces n entries in every schedule.
+  c->ds.stackTotal = std::max(8, ((bo.maxDepth + 1 + 3) / 4) * 4);
+  c->ds.stackEntries = c->ds.stackTotal;   // the launchers shorten it per launch (DevFrame::stackLds)
   c->ds.triPad = bo.pad;
   { const char* e = getenv("RESTIR_COOP"); c->ds.coopLive = e ? std::max(0, std::min(64, atoi(e))) : 4; }
   c->numNodes = bo.nodes.size(); c->numTris = bo.tris.size(); c->maxDepth = bo.maxDepth;
   RT_HIP(c, hipDeviceSynchronize());
   c->haveAccel = true;
-  return RT_OK;
+  return ensureStackOverflow(c);
 }
 
 int rt_resize(rt_ctx* c, int w, int h)
@@ -499,6 +506,23 @@ int rt_resize(rt_ctx* c, int w, int h)
 #undef RT_SCRATCH
   RT_HIP(c, hipDeviceSynchronize());  // memsets above ran on the null stream; the ctx stream does not wait for it implicitly
   c->W = w; c->H = h;
+  return ensureStackOverflow(c);
+}
+
+// Overflow part of the traversal stacks (DevScene::stackOvf): (stackTotal - stackEntries) entries for every thread of the largest traced launch of
+// this frame size, one area per stage kind.  (Re)allocated when the tree or the frame size changes; touched only by rays that go deeper than the LDS part.
+static int ensureStackOverflow(rt_ctx* c)
+{
+  freePool(c->ovfAllocs);
+  c->ds.stackOvf = c->ds.stackOvfInd = nullptr; c->ds.stackOvfThreads = 0;
+  if(!c->haveAccel || c->W <= 0 || c->ds.stackTotal <= stackLdsMin()) return RT_OK;
+  const size_t tilesX = size_t(c->W + 7) / 8, tilesY = size_t(c->H + 7) / 8;
+  const size_t blocks = std::max<size_t>(16384, tilesX * tilesY + 8 * tilesX + 1024);   // >= any traced grid: tileGrid() of the full frame; 4 waves per half-res tile; persistent launches
+  const size_t bytes = blocks * 64 * size_t(c->ds.stackTotal - stackLdsMin()) * sizeof(uint2);
+  void* p[2] = {nullptr, nullptr};
+  for(int i = 0; i < 2; i++) { RT_HIP(c, hipMalloc(&p[i], bytes)); c->ovfAllocs.push_back(p[i]); }
+  c->ds.stackOvf = static_cast<uint2*>(p[0]); c->ds.stackOvfInd = static_cast<uint2*>(p[1]);
+  c->ds.stackOvfThreads = uint32_t(blocks * 64);
   return RT_OK;
 }
 
@@ -513,14 +537,17 @@ static DevFrame makeFrame(rt_ctx* c, int frames)
 {
   const int cur = frames & 1, last = (frames + 1) & 1;  // m_descSet[(frames+1)%2]: this = [!i] (renderer.cpp:157, 346-356)
   DevFrame F{};
-  // A-Trous kernel choice (bit-identical results): the LDS-tile kernel computes every pair weight once and wins on levels 0-1 when
-  // the launch has the chip to itself (-17 % / -29 % direct / indirect), but its 256-thread / 36 KB workgroups fit badly between
-  // the traversal waves of the frames in flight (+5 % frame time, profiles/r02_denoise_tile_ab.txt): serial schedules use it,
-  // the frames-in-flight schedule keeps the per-pixel gather.  RESTIR_DENOISE_TILE=<max level | -1> overrides.
+  // A-Trous kernel choice (bit-identical results; profiles/r02_denoise_tile_ab.txt, r02_denoise_lds_ab.txt, r02_short_stack_ab.txt).  Direct filter:
+  // the one-wave LDS-staged kernel on every level, in every schedule.  Indirect filter: serial schedules run levels 0-1 on the 256-thread tile kernel
+  // (every pair weight once) and the rest on the gather; with frames in flight the tile kernel's 36 KB workgroups fit badly between the traversal
+  // waves, so levels 0-1 take the one-wave LDS kernel instead.  RESTIR_DENOISE_TILE / _LDS / _LDS_IND = <max level | -1> override.
   static const int tileEnv = getenv("RESTIR_DENOISE_TILE") ? atoi(getenv("RESTIR_DENOISE_TILE")) : -2;
   F.denoiseTileMax = tileEnv != -2 ? tileEnv : (c->overlap == 2 ? -1 : 1);
   static const int ldsEnv = getenv("RESTIR_DENOISE_LDS") ? atoi(getenv("RESTIR_DENOISE_LDS")) : -2;
-  F.denoiseLdsMax = ldsEnv != -2 ? ldsEnv : (c->overlap == 2 ? -1 : 3);
+  F.denoiseLdsMax = ldsEnv != -2 ? ldsEnv : 3;
+  F.stackLds = stackLdsEnv() ? stackLdsEnv() : (c->overlap == 2 ? 6 : 0);
+  static const int ldsIndEnv = getenv("RESTIR_DENOISE_LDS_IND") ? atoi(getenv("RESTIR_DENOISE_LDS_IND")) : -2;
+  F.denoiseLdsMaxInd = ldsIndEnv != -2 ? ldsIndEnv : (c->overlap == 2 ? 1 : -1);
   F.thisG = static_cast<uint4*>(c->bufs[RT_BUF_GBUFFER0 + cur]); F.lastG = static_cast<const uint4*>(c->bufs[RT_BUF_GBUFFER0 + last]);
   F.motion = static_cast<short2*>(c->bufs[RT_BUF_MOTION]);
   F.thisDirectResv = static_cast<rt_direct_reservoir*>(c->bufs[RT_BUF_DIRECT_RESV0 + cur]);

@@ -1044,13 +1044,15 @@ __global__ __launch_bounds__(64) void k_compose(DevFrame F, rt_state st, int row
 static bool uniformDivOk(float s) { return s >= 1e-6f && s <= 1e6f; }
 // RESTIR_DENOISE_WGS: upper bound of resident k_denoise_tile workgroups (multiple of 8; each holds 36.5 KB of LDS); default: one per work item
 static unsigned denoiseTileGridCap() { static const unsigned v = getenv("RESTIR_DENOISE_WGS") ? (unsigned(atoi(getenv("RESTIR_DENOISE_WGS"))) + 7u) / 8u * 8u : 1u << 30; return std::max(8u, v); }
-// RESTIR_DENOISE_LDS_IND: highest level of the INDIRECT filter on k_denoise_lds (measurement only; default none: the tile / gather pair is faster there)
-static int denoiseLdsMaxIndirect() { static const int v = getenv("RESTIR_DENOISE_LDS_IND") ? atoi(getenv("RESTIR_DENOISE_LDS_IND")) : -1; return v; }
 // RESTIR_DENOISE_TILE=0 selects the per-pixel gather kernels (k_denoise) for A/B runs; results are bit-identical
 
-hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F, const rt_state& st, const rt_scene_camera& cam, int stage, int level,
+hipError_t launchStage(hipStream_t stream, const DevScene& Sin, const DevFrame& F, const rt_state& st, const rt_scene_camera& cam, int stage, int level,
                        int rowBegin, int rowEnd)
 {
+  DevScene S = Sin;
+  S.stackEntries = F.stackLds > 0 ? std::min(F.stackLds, S.stackTotal) : S.stackTotal;   // LDS part of the traversal stack for this launch
+  if(stage == RT_STAGE_INDIRECT) S.stackOvf = Sin.stackOvfInd;   // a direct-kind kernel of the next frame can be in flight beside it
+  const bool needOvf = S.stackTotal > S.stackEntries;
   const bool half = (stage == RT_STAGE_INDIRECT || stage == RT_STAGE_DENOISE_INDIRECT);
   const int gw = half ? st.size.x / 2 : st.size.x, gh = half ? st.size.y / 2 : st.size.y;
   if(rowEnd <= 0 || rowEnd > gh) rowEnd = gh;
@@ -1066,11 +1068,15 @@ hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F,
       //  split shading costs more than the shorter tail saves.  The single-bounce indirect tiles are where pooling pays.)
       // `level` selects the halves of the stage for hosts that must exchange the cached reservoirs of neighbouring rows in between
       // (row-tiled multi-GPU frames with spatial reuse): 0 = the whole stage, 1 = k_direct_stage only, 2 = k_direct_spatial only
+      if(needOvf && grid.x * 64u > S.stackOvfThreads) return hipErrorInvalidValue;
       if(level != 2) hipLaunchKernelGGL(k_direct_stage, grid, block, lds, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY);
       if(level != 1 && (st.ReSTIRState == RT_RESTIR_SPATIAL || st.ReSTIRState == RT_RESTIR_SPATIOTEMPORAL))
         hipLaunchKernelGGL(k_direct_spatial, grid, block, 0, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY);
       break;
-    case RT_STAGE_DIRECT_GEN: hipLaunchKernelGGL(k_direct_gen, grid, block, lds, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY); break;
+    case RT_STAGE_DIRECT_GEN:
+      if(needOvf && grid.x * 64u > S.stackOvfThreads) return hipErrorInvalidValue;
+      hipLaunchKernelGGL(k_direct_gen, grid, block, lds, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY);
+      break;
     case RT_STAGE_DIRECT_REUSE: hipLaunchKernelGGL(k_direct_reuse, grid, block, 0, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY); break;
     case RT_STAGE_INDIRECT: {
       // per-XCD tile lists: capacity = the tiles one XCD can own under the striped mapping
@@ -1087,6 +1093,7 @@ hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F,
       const unsigned genericBlocks = grid.x << subShift;
       const unsigned sbBlocks = sbK > 0 ? 8u * unsigned((cap + sbK - 1) / sbK) : 0u;
       const size_t poolBytes = std::max<size_t>(POOL_BYTES, size_t(sbK) * 64 * 33);
+      if(needOvf && (genericBlocks + sbBlocks) * 64u > S.stackOvfThreads) return hipErrorInvalidValue;
       hipLaunchKernelGGL(k_indirect_stage, dim3(genericBlocks + sbBlocks), block, lds + poolBytes, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY, cap,
                          (const uint32_t*)F.tileOrder, (const uint32_t*)(F.qcount + 192), subShift, sbK, int(genericBlocks));
       break;
@@ -1149,7 +1156,7 @@ hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F,
           hipLaunchKernelGGL((k_denoise_tile<true, false>), dim3(nwg), dim3(256), 0, stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, ltx, lty, 0.f, 0.f, 0.f);
         break;
       }
-      if(level <= denoiseLdsMaxIndirect()) {
+      if(level <= F.denoiseLdsMaxInd) {
         const int stp = 1 << level, ltx = ((gw + stp - 1) / stp + DL_T - 1) / DL_T, lty = ((rowEnd - rowBegin + stp - 1) / stp + DL_T - 1) / DL_T;
         const unsigned nwg = 8u * unsigned((ltx * lty * stp * stp + 7) / 8);
         if(uniformDivOk(st.sigLuminIndirect) && uniformDivOk(st.sigNormalIndirect) && uniformDivOk(st.sigDepthIndirect))

@@ -225,18 +225,39 @@ RT_DEV bool travInit(Trav& T, f3 o, f3 d, float tmax, uint32_t raySeed)
   return true;
 }
 
+// The traversal stack of a lane: the first S.stackEntries entries live in LDS (most rays never go deeper), the rest of the S.stackTotal entries a
+// ray of this tree can need in HBM, one small area per thread of the launch.  The short LDS stack is what lets LDS-staged filter kernels run beside
+// the traversal kernels of the neighbouring frames in flight (profiles/r02_short_stack_ab.txt; a ring of the TOP entries in LDS was measured too:
+// it needs a power-of-two size, and 4 KB per wave loses more to LDS pressure than the rarer HBM accesses gain).
+RT_DEV uint2& stackOverflowSlot(const DevScene& S, int sp)
+{
+  const size_t thread = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  return S.stackOvf[thread * size_t(S.stackTotal - S.stackEntries) + size_t(sp - S.stackEntries)];
+}
+RT_DEV uint2 stackPop(const DevScene& S, Trav& T, uint2* stack)
+{
+  --T.sp;
+  if(T.sp < S.stackEntries) return stack[T.sp * 64];
+  return stackOverflowSlot(S, T.sp);
+}
+RT_DEV void stackPush(const DevScene& S, Trav& T, uint2* stack, uint2 g)
+{
+  if(T.sp < S.stackEntries) stack[(T.sp++) * 64] = g;
+  else if(T.sp < S.stackTotal) { stackOverflowSlot(S, T.sp) = g; T.sp++; }   // (deeper than the tree: cannot happen, rt_build_accel sizes stackTotal)
+}
+
 // Node step (precondition: no pending triangles, travHasNodes).  `stack` = this lane's LDS column (stride 64 entries).
 RT_DEV void travNode(const DevScene& S, Trav& T, uint2* stack, TravCounters& tc)
 {
   uint2 ngroup = T.ngroup;
-  if(ngroup.y <= 0x00FFFFFFu) ngroup = stack[(--T.sp) * 64];
+  if(ngroup.y <= 0x00FFFFFFu) ngroup = stackPop(S, T, stack);
   const bool nx = T.d.x < 0.0f, ny = T.d.y < 0.0f, nz = T.d.z < 0.0f;
   const uint32_t octinv = T.octinv;
   const uint32_t octinv4 = octinv * 0x01010101u;
   const uint32_t hits = ngroup.y;
   const uint32_t bit = 31u - uint32_t(__clz(int(hits)));
   ngroup.y &= ~(1u << bit);
-  if(ngroup.y > 0x00FFFFFFu) { if(T.sp < S.stackEntries) stack[(T.sp++) * 64] = ngroup; }
+  if(ngroup.y > 0x00FFFFFFu) stackPush(S, T, stack, ngroup);
   const uint32_t slot = (bit - 24u) ^ octinv;
   const uint32_t rel = uint32_t(__popc(hits & ~(0xFFFFFFFFu << slot) & 0xFFu));
   const uint4* np = reinterpret_cast<const uint4*>(S.nodes + (ngroup.x + rel));

@@ -459,11 +459,14 @@ __global__ __launch_bounds__(64) void k_ind_finish(DevScene S, DevFrame F, rt_st
 // ================================================================================================================
 // host-side sequencing
 // ================================================================================================================
-hipError_t launchStageWavefront(hipStream_t stream, const DevScene& S, const DevFrame& F, const rt_state& st, const rt_scene_camera& cam, int stage, int level,
+hipError_t launchStageWavefront(hipStream_t stream, const DevScene& Sin, const DevFrame& F, const rt_state& st, const rt_scene_camera& cam, int stage, int level,
                                 int rowBegin, int rowEnd)
 {
   const bool isDirect = stage == RT_STAGE_DIRECT || stage == RT_STAGE_DIRECT_GEN;
-  if(!isDirect && stage != RT_STAGE_INDIRECT) return launchStage(stream, S, F, st, cam, stage, level, rowBegin, rowEnd);
+  if(!isDirect && stage != RT_STAGE_INDIRECT) return launchStage(stream, Sin, F, st, cam, stage, level, rowBegin, rowEnd);
+  DevScene S = Sin;
+  S.stackEntries = F.stackLds > 0 ? std::min(F.stackLds, S.stackTotal) : S.stackTotal;   // LDS part of the traversal stack for this launch
+  if(stage == RT_STAGE_INDIRECT) S.stackOvf = Sin.stackOvfInd;
   // the spatial reuse modes exist in the fused organisation only (k_direct_stage + k_direct_spatial)
   if(stage == RT_STAGE_DIRECT && (st.ReSTIRState == RT_RESTIR_SPATIAL || st.ReSTIRState == RT_RESTIR_SPATIOTEMPORAL))
     return launchStage(stream, S, F, st, cam, stage, level, rowBegin, rowEnd);
@@ -480,6 +483,7 @@ hipError_t launchStageWavefront(hipStream_t stream, const DevScene& S, const Dev
   static const int persistent = getenv("RESTIR_PERSISTENT") ? atoi(getenv("RESTIR_PERSISTENT")) : 1;
   static const int wavesPerCU = getenv("RESTIR_WAVES_PER_CU") ? atoi(getenv("RESTIR_WAVES_PER_CU")) : 16;
   const dim3 pgrid(unsigned(std::min<long long>(256ll * wavesPerCU, (long long)cap)));
+  if(S.stackTotal > S.stackEntries && std::max(grid.x, pgrid.x) * 64u > S.stackOvfThreads) return hipErrorInvalidValue;
   uint32_t* heads = F.qcount + 128;
   hipError_t e = hipMemsetAsync(F.qcount, 0, 192 * sizeof(uint32_t), stream);  // slots 192.. belong to the tile lists / history-miss flag
   if(e != hipSuccess) return e;
