@@ -98,14 +98,17 @@ def test_regression_sliver_triangle():
 
 
 KNOBS = ["RESTIR_IND_SUB=0 RESTIR_IND_SBK=3", "RESTIR_IND_SUB=0 RESTIR_IND_SBK=2", "RESTIR_IND_SUB=1 RESTIR_IND_SBK=0",
-         "RESTIR_IND_SUB=0 RESTIR_IND_SBK=0 RESTIR_COOP=64", "RESTIR_OVERLAP=0 RESTIR_COOP=0", "RESTIR_PIPELINE=wavefront RESTIR_OVERLAP=1"]
+         "RESTIR_IND_SUB=0 RESTIR_IND_SBK=0 RESTIR_COOP=64", "RESTIR_OVERLAP=0 RESTIR_COOP=0", "RESTIR_PIPELINE=wavefront RESTIR_OVERLAP=1",
+         # two LDS stack entries: nearly every ray keeps part of its traversal stack in the HBM overflow area; every filter level on each of the three filter kernels
+         "RESTIR_STACK_LDS=2 RESTIR_DENOISE_LDS=4 RESTIR_DENOISE_LDS_IND=4", "RESTIR_STACK_LDS=3 RESTIR_PIPELINE=wavefront",
+         "RESTIR_STACK_LDS=64 RESTIR_DENOISE_LDS=-1 RESTIR_DENOISE_LDS_IND=-1 RESTIR_DENOISE_TILE=4", "RESTIR_DENOISE_LDS=-1 RESTIR_DENOISE_LDS_IND=-1 RESTIR_DENOISE_TILE=-1"]
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("knobs", KNOBS)
 def test_launch_shape_knobs_do_not_change_the_bits(knobs):
     """The tuning switches of DESIGN.md §12 only change how the work is laid out over waves and streams (tiles per wave, waves per
-    tile, cooperative-tail threshold, stream overlap, kernel organisation).  Small images pick the small-launch shapes on their own,
+    tile, cooperative-tail threshold, stream overlap, kernel organisation, LDS / HBM split of the traversal stack, filter kernel per level).  Small images pick the small-launch shapes on their own,
     so the shapes of a full-size frame are forced here; the library reads some switches once per process, hence a subprocess."""
     import subprocess
     env = dict(os.environ)
