@@ -222,22 +222,24 @@ int rt_create(rt_ctx** out, int device)
   rt_ctx* c = new(std::nothrow) rt_ctx();
   if(!c) { g_createErr = "rt_create: out of host memory"; return RT_ERR_OOM; }
   c->device = device;
-  if(hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) != hipSuccess) { g_createErr = "rt_create: hipStreamCreate failed"; delete c; return RT_ERR_HIP; }
-  c->stream = c->ownStream;
   {
-    // older work first: the streams that finish frame f outrank the one that starts frame f+1 (RESTIR_PRIO=0 disables)
+    // stream priorities of the frames-in-flight schedule (RESTIR_PRIO): 0 none, 1 ind + side high, 2 ind high (default: measured 2 % faster than 1, round 2),
+    // 3 side high, 4 main (direct stage) high, 5 main + ind high, 6 main + side high, 7 main high / ind normal / side low
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     const char* pe = getenv("RESTIR_PRIO");
-    const int mode = pe ? atoi(pe) : 2;   // 0 none, 1 ind + side high, 2 ind high (default: measured 2 % faster than 1, round 2), 3 side high
+    const int mode = pe ? atoi(pe) : 2;
     const bool can = hi < lo;
     bool ok = true;
-    auto mk = [&](hipStream_t* s, bool high) {
-      if(can && high) ok = ok && hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi) == hipSuccess;
+    auto mk = [&](hipStream_t* s, int level) {   // level: 1 high, 0 default, -1 low
+      if(can && level != 0) ok = ok && hipStreamCreateWithPriority(s, hipStreamNonBlocking, level > 0 ? hi : lo) == hipSuccess;
       else ok = ok && hipStreamCreateWithFlags(s, hipStreamNonBlocking) == hipSuccess;
     };
-    mk(&c->sideStream, mode == 1 || mode == 3);
-    mk(&c->indStream, mode == 1 || mode == 2);
+    mk(&c->ownStream, (mode >= 4 && mode <= 7) ? 1 : 0);
+    if(!ok) { g_createErr = "rt_create: hipStreamCreate failed"; delete c; return RT_ERR_HIP; }
+    c->stream = c->ownStream;
+    mk(&c->sideStream, (mode == 1 || mode == 3 || mode == 6) ? 1 : (mode == 7 ? -1 : 0));
+    mk(&c->indStream, (mode == 1 || mode == 2 || mode == 5) ? 1 : 0);
     for(int i = 0; i < 4; i++) {
       ok = ok && hipEventCreateWithFlags(&c->evD[i], hipEventDisableTiming) == hipSuccess;
       ok = ok && hipEventCreateWithFlags(&c->evI[i], hipEventDisableTiming) == hipSuccess;
