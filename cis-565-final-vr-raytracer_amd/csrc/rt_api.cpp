@@ -539,17 +539,17 @@ static DevFrame makeFrame(rt_ctx* c, int frames)
 {
   const int cur = frames & 1, last = (frames + 1) & 1;  // m_descSet[(frames+1)%2]: this = [!i] (renderer.cpp:157, 346-356)
   DevFrame F{};
-  // A-Trous kernel choice (bit-identical results; profiles/r02_denoise_tile_ab.txt, r02_denoise_lds_ab.txt, r02_short_stack_ab.txt).  Direct filter:
-  // the one-wave LDS-staged kernel on every level, in every schedule.  Indirect filter: serial schedules run levels 0-1 on the 256-thread tile kernel
-  // (every pair weight once) and the rest on the gather; with frames in flight the tile kernel's 36 KB workgroups fit badly between the traversal
-  // waves, so levels 0-1 take the one-wave LDS kernel instead.  RESTIR_DENOISE_TILE / _LDS / _LDS_IND = <max level | -1> override.
-  static const int tileEnv = getenv("RESTIR_DENOISE_TILE") ? atoi(getenv("RESTIR_DENOISE_TILE")) : -2;
-  F.denoiseTileMax = tileEnv != -2 ? tileEnv : (c->overlap == 2 ? -1 : 1);
-  static const int ldsEnv = getenv("RESTIR_DENOISE_LDS") ? atoi(getenv("RESTIR_DENOISE_LDS")) : -2;
-  F.denoiseLdsMax = ldsEnv != -2 ? ldsEnv : 3;
+  // A-Trous kernel choice (bit-identical results; profiles/r02_denoise_tile_ab.txt, r02_denoise_lds_ab.txt, r02_short_stack_ab.txt): the one-wave
+  // LDS-staged kernel (k_denoise_lds) on every level of both filters, in every schedule.  The 256-thread tile kernel and the per-pixel gather stay for
+  // A/B runs: RESTIR_DENOISE_TILE / RESTIR_DENOISE_LDS / RESTIR_DENOISE_LDS_IND = <highest level on that kernel | -1>; direct filter: lds before tile,
+  // indirect filter: tile before lds, the gather takes what is left.
+  static const int tileEnv = getenv("RESTIR_DENOISE_TILE") ? atoi(getenv("RESTIR_DENOISE_TILE")) : -1;
+  F.denoiseTileMax = tileEnv;
+  static const int ldsEnv = getenv("RESTIR_DENOISE_LDS") ? atoi(getenv("RESTIR_DENOISE_LDS")) : 3;
+  F.denoiseLdsMax = ldsEnv;
+  static const int ldsIndEnv = getenv("RESTIR_DENOISE_LDS_IND") ? atoi(getenv("RESTIR_DENOISE_LDS_IND")) : 4;
+  F.denoiseLdsMaxInd = ldsIndEnv;
   F.stackLds = stackLdsEnv() ? stackLdsEnv() : (c->overlap == 2 ? 6 : 0);
-  static const int ldsIndEnv = getenv("RESTIR_DENOISE_LDS_IND") ? atoi(getenv("RESTIR_DENOISE_LDS_IND")) : -2;
-  F.denoiseLdsMaxInd = ldsIndEnv != -2 ? ldsIndEnv : (c->overlap == 2 ? 1 : -1);
   F.thisG = static_cast<uint4*>(c->bufs[RT_BUF_GBUFFER0 + cur]); F.lastG = static_cast<const uint4*>(c->bufs[RT_BUF_GBUFFER0 + last]);
   F.motion = static_cast<short2*>(c->bufs[RT_BUF_MOTION]);
   F.thisDirectResv = static_cast<rt_direct_reservoir*>(c->bufs[RT_BUF_DIRECT_RESV0 + cur]);

@@ -934,24 +934,59 @@ __global__ __launch_bounds__(256) void k_denoise_tile(DevFrame F, rt_state st, c
   }
 }
 
-// The same filter with the inputs of ONE wave staged in LDS: a 64-thread workgroup takes an 8 x 8 tile of one a-trous sub-lattice, stages
-// colour (+ luminance), normal + material hash and position of the tile and its 2-pixel ring (12 x 12 lattice pixels, 6.9 KB) and every lane
-// reads its 25 taps from there: 7 global loads per lane instead of 75.  The gather kernel keeps the texture-address path 66-82 % busy when it
-// runs alone (TA_BUSY, profiles/r02_denoise_lds_ab.txt) and shares that path with the traversal kernels when frames are in flight; this one
-// needs a tenth of it, and — unlike k_denoise_tile — its one-wave workgroups fit into any free wave slot.  No weight sharing: every tap is
-// evaluated as in k_denoise, in the same order, with the same expressions.
+// The same filter with the inputs of ONE wave staged in LDS (k_denoise_lds): a 64-thread workgroup takes an 8 x 8 tile of one a-trous sub-lattice,
+// stages colour (+ luminance), normal + material hash and position of the tile and its 2-pixel ring (12 x 12 lattice pixels, 6.9 KB) and every lane takes
+// its 25 taps from there: 7 global loads per lane instead of 75.  The gather kernel keeps the texture-address path 66-82 % busy when it runs alone
+// (TA_BUSY, profiles/r02_denoise_lds_ab.txt) and shares that path with the traversal kernels when frames are in flight; this one needs a tenth of it,
+// and — unlike k_denoise_tile — its one-wave workgroups fit into any free wave slot.
+// Every pair weight is evaluated once (the symmetry k_denoise_tile uses): a lane owns its pixel's 12 forward weights and the centre weight; a backward
+// tap takes the neighbour's forward weight when that neighbour is one of the tile's 64 pixels (71 % of the backward taps), the other 222 (pixel, offset)
+// pairs of a tile are the same for every tile — a compile-time list, fetched before the first barrier and worked off in four full-wave passes.  17 weight
+// evaluations per lane instead of 25 (-20 % executed VALU instructions); the weights travel through the LDS that held normals and positions, which are
+// dead by then.  Same expressions, same accumulation order as k_denoise: bit-identical.
 constexpr int DL_T = 8, DL_S = DL_T + 4;
+struct BwdPairs { uint32_t pair[256]; float gauss[256]; int16_t base[DT_NFWD + 1]; };
+constexpr float kGaussFwdC[DT_NFWD] = {.0983f, .0219f, .0133f, .0596f, .0983f, .0596f, .0133f, .0030f, .0133f, .0219f, .0133f, .0030f};
+constexpr BwdPairs makeBwdPairs()
+{
+  BwdPairs t{};
+  int n = 0;
+  for(int k = 0; k < DT_NFWD; k++) {
+    const int i = kFwdI[k], j = kFwdJ[k];
+    t.base[k] = int16_t(n);
+    for(int p = 0; p < 64; p++) {
+      const int qx = (p & 7) - i, qy = (p >> 3) - j;
+      if(qx < 0 || qx > 7 || qy < 0) {
+        const int pidx = ((p >> 3) + 2) * 12 + ((p & 7) + 2), qidx = pidx - j * 12 - i;
+        t.pair[n] = uint32_t(pidx | (qidx << 8)); t.gauss[n] = kGaussFwdC[k]; n++;
+      }
+    }
+  }
+  t.base[DT_NFWD] = int16_t(n);
+  return t;
+}
+__device__ constexpr BwdPairs kBwdPairs = makeBwdPairs();
+constexpr int DL_NBWD = makeBwdPairs().base[DT_NFWD];
+static_assert(DL_NBWD == 222, "backward pair list");
+RT_DEV int bwdSlot(int k, int i, int j, int x, int y)
+{
+  const int ai = i < 0 ? -i : i;
+  const int inRow = i > 0 ? x : x - (8 - ai);
+  const int r = y < j ? 8 * y + x : 8 * j + (y - j) * ai + inRow;
+  return kBwdPairs.base[k] + r;
+}
+
 template <bool IND, bool FAST>
 __global__ __launch_bounds__(64) void k_denoise_lds(DevFrame F, rt_state st, const float4* src, float4* dst, int level, int rowBegin, int rowEnd, int tilesX, int tilesY,
-                                                    float yL, float yN, float yD)
+                                                     float yL, float yN, float yD)
 {
   __shared__ float4 sC[DL_S * DL_S];
-  __shared__ float4 sN[DL_S * DL_S];
-  __shared__ float4 sP[DL_S * DL_S];
+  __shared__ float4 sNP[2 * DL_S * DL_S];
+  float4* sN = sNP; float4* sP = sNP + DL_S * DL_S;
   const int step = 1 << level;
   const int total = tilesX * tilesY * step * step, perXcd = (total + 7) / 8;
   const int local = int(blockIdx.x >> 3);
-  const int work = int(blockIdx.x & 7u) * perXcd + local;      // consecutive work items (the sub-lattices of one region share cache lines) on one XCD
+  const int work = int(blockIdx.x & 7u) * perXcd + local;
   if(local >= perXcd || work >= total) return;
   const int sub = work % (step * step), tileIdx = work / (step * step);
   const int a = sub % step, b = sub / step;
@@ -980,30 +1015,73 @@ __global__ __launch_bounds__(64) void k_denoise_lds(DevFrame F, rt_state st, con
       sC[idx] = c; sN[idx] = n; sP[idx] = q;
     }
   }
+  uint32_t pr[4]; float pg[4];
+#pragma unroll
+  for(int r = 0; r < 4; r++) { const int idx = min(r * 64 + lane, DL_NBWD - 1); pr[r] = kBwdPairs.pair[idx]; pg[r] = kBwdPairs.gauss[idx]; }
   __syncthreads();
   const int ux = lane & 7, uy = lane >> 3;
+  const int cidx = (uy + 2) * DL_S + (ux + 2);
+  const float4 cN = sN[cidx], cC = sC[cidx], cP = sP[cidx];
+  const uint32_t hash = rt_f2u(cN.w);
+  const f3 color = mk3(cC.x, cC.y, cC.z), norm = mk3(cN.x, cN.y, cN.z), pos = mk3(cP.x, cP.y, cP.z);
+  float wf[DT_NFWD];
+#pragma unroll
+  for(int k = 0; k < DT_NFWD; k++) {
+    const int qidx = cidx + kFwdJ[k] * DL_S + kFwdI[k];
+    const float4 qN = sN[qidx];
+    float w = -1.0f;
+    if(hash != RT_INVALID_MAT_ID && rt_f2u(qN.w) == hash) {
+      const float4 qP = sP[qidx], qC = sC[qidx];
+      w = denoisePairWeight<IND, FAST>(color, cC.w, norm, pos, mk3(qC.x, qC.y, qC.z), qC.w, mk3(qN.x, qN.y, qN.z), mk3(qP.x, qP.y, qP.z), kGauss[kFwdI[k] + 2][kFwdJ[k] + 2],
+                                       sigLumin, sigNormal, sigDepth, yL, yN, yD);
+    }
+    wf[k] = w;
+  }
+  float wb[4];
+#pragma unroll
+  for(int r = 0; r < 4; r++) {
+    float w = -1.0f;
+    if(r * 64 + lane < DL_NBWD) {
+      const int pidx = int(pr[r] & 0xffu), qidx = int(pr[r] >> 8);
+      const float4 pN = sN[pidx], qN = sN[qidx];
+      const uint32_t ph = rt_f2u(pN.w);
+      if(ph != RT_INVALID_MAT_ID && rt_f2u(qN.w) == ph) {
+        const float4 pC = sC[pidx], pP = sP[pidx], qC = sC[qidx], qP = sP[qidx];
+        w = denoisePairWeight<IND, FAST>(mk3(pC.x, pC.y, pC.z), pC.w, mk3(pN.x, pN.y, pN.z), mk3(pP.x, pP.y, pP.z), mk3(qC.x, qC.y, qC.z), qC.w, mk3(qN.x, qN.y, qN.z),
+                                         mk3(qP.x, qP.y, qP.z), pg[r], sigLumin, sigNormal, sigDepth, yL, yN, yD);
+      }
+    }
+    wb[r] = w;
+  }
+  __syncthreads();
+  float* sW = reinterpret_cast<float*>(sNP);
+#pragma unroll
+  for(int k = 0; k < DT_NFWD; k++) sW[k * 64 + lane] = wf[k];
+#pragma unroll
+  for(int r = 0; r < 4; r++) if(r * 64 + lane < DL_NBWD) sW[DT_NFWD * 64 + r * 64 + lane] = wb[r];
+  __syncthreads();
   const i2 coord{a + step * (X0 + ux), rowBegin + b + step * (Y0 + uy)};
   if(coord.x >= bound.x || coord.y >= bound.y || coord.y >= rowEnd) return;
-  const int cidx = (uy + 2) * DL_S + (ux + 2);
-  const float4 cN = sN[cidx];
-  const uint32_t hash = rt_f2u(cN.w);
   f3 res = mk3(0.0f);
   if(hash != RT_INVALID_MAT_ID) {
-    const float4 cC = sC[cidx], cP = sP[cidx];
-    const f3 color = mk3(cC.x, cC.y, cC.z), norm = mk3(cN.x, cN.y, cN.z), pos = mk3(cP.x, cP.y, cP.z);
     f3 sum = mk3(0.0f);
     float sumWeight = 0.0f;
 #pragma unroll
     for(int j = -2; j <= 2; j++)
 #pragma unroll
       for(int i = -2; i <= 2; i++) {
-        const int qidx = cidx + j * DL_S + i;
-        const float4 qN = sN[qidx];
-        if(rt_f2u(qN.w) == hash) {
-          const float4 qP = sP[qidx], qC = sC[qidx];
-          const float w = denoisePairWeight<IND, FAST>(color, cC.w, norm, pos, mk3(qC.x, qC.y, qC.z), qC.w, mk3(qN.x, qN.y, qN.z), mk3(qP.x, qP.y, qP.z), kGauss[i + 2][j + 2],
-                                                       sigLumin, sigNormal, sigDepth, yL, yN, yD);
-          sum += mk3(qC.x, qC.y, qC.z) * w;
+        float w;
+        if(i == 0 && j == 0)
+          w = denoisePairWeight<IND, FAST>(color, cC.w, norm, pos, color, cC.w, norm, pos, kGauss[2][2], sigLumin, sigNormal, sigDepth, yL, yN, yD);
+        else if(j > 0 || (j == 0 && i > 0)) w = wf[fwdIndex(i, j)];
+        else {
+          const int k = fwdIndex(-i, -j), qx = ux + i, qy = uy + j;
+          const bool inside = qx >= 0 && qx <= 7 && qy >= 0;
+          w = sW[inside ? k * 64 + qy * 8 + qx : DT_NFWD * 64 + bwdSlot(k, -i, -j, ux, uy)];
+        }
+        if(w != -1.0f) {
+          const float4 q = sC[cidx + j * DL_S + i];
+          sum += mk3(q.x, q.y, q.z) * w;
           sumWeight += w;
         }
       }
