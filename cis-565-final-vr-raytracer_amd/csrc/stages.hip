@@ -945,6 +945,8 @@ __global__ __launch_bounds__(256) void k_denoise_tile(DevFrame F, rt_state st, c
 // evaluations per lane instead of 25 (-20 % executed VALU instructions); the weights travel through the LDS that held normals and positions, which are
 // dead by then.  Same expressions, same accumulation order as k_denoise: bit-identical.
 constexpr int DL_T = 8, DL_S = DL_T + 4;
+// the (pixel p, forward offset k) pairs whose backward partner q = p - offset(k) lies outside the tile, offsets ascending, pixels ascending within an offset:
+// pair = LDS index of p | LDS index of q << 8 in the staged 12 x 12 block, gauss = the kernel factor of the offset, base[k] = first pair of offset k
 struct BwdPairs { uint32_t pair[256]; float gauss[256]; int16_t base[DT_NFWD + 1]; };
 constexpr float kGaussFwdC[DT_NFWD] = {.0983f, .0219f, .0133f, .0596f, .0983f, .0596f, .0133f, .0030f, .0133f, .0219f, .0133f, .0030f};
 constexpr BwdPairs makeBwdPairs()
@@ -968,6 +970,8 @@ constexpr BwdPairs makeBwdPairs()
 __device__ constexpr BwdPairs kBwdPairs = makeBwdPairs();
 constexpr int DL_NBWD = makeBwdPairs().base[DT_NFWD];
 static_assert(DL_NBWD == 222, "backward pair list");
+// slot of pixel (x, y)'s directly evaluated backward weight for forward offset k = (i, j): its rank in kBwdPairs.  Rows y < j lie outside with all 8 pixels,
+// the rows below with |i| pixels each (x < i for i > 0, x > 7 + i for i < 0)
 RT_DEV int bwdSlot(int k, int i, int j, int x, int y)
 {
   const int ai = i < 0 ? -i : i;
