@@ -308,6 +308,9 @@ GltfScene makeSponza(float scale, uint32_t seed)
 // ---- configs 4/5: "Bistro-class" street / interior ------------------------------------------------------------
 GltfScene makeBistro(bool interior, float scale, uint32_t seed)
 {
+  // RESTIR_SCENE_STRESS=1: a harder variant of the exterior scene for robustness measurements: rotated buildings, twice the foliage, wires.
+  // The benchmark scene (unset) is unchanged, down to the order of its random draws.
+  const bool stress = !interior && getenv("RESTIR_SCENE_STRESS") != nullptr;
   Builder B(seed);
   Palette P = interior ? makePalette(B, 30, 512, seed, 26.f, 22.f, 16.f) : makePalette(B, 40, 512, seed, 60.f, 48.f, 30.f);
   float s = std::sqrt(scale);
@@ -325,9 +328,13 @@ GltfScene makeBistro(bool interior, float scale, uint32_t seed)
     // buildings along both sides of the street: facade with window frames
     int nb = std::max(2, int(24 * scale + 0.5f));
     for(int b = 0; b < nb; b++) {
-      float bx = -X + 6.f + (b / 2) * (2 * X - 12.f) / std::max(1, nb / 2 - 1 + (nb / 2 == 1)), bz = (b & 1) ? 14.f : -14.f;
+      const float wbx = -X + 6.f + (b / 2) * (2 * X - 12.f) / std::max(1, nb / 2 - 1 + (nb / 2 == 1)), wbz = (b & 1) ? 14.f : -14.f;
       float hw = B.rng.range(3.5f, 4.8f), hh = B.rng.range(6.f, 11.f), hd = B.rng.range(4.f, 6.f);
-      B.beginMesh(mat(2 + b)); B.box({bx, hh, bz}, {hw, hh, hd}, 0.f, false, 4.f); B.addNode(B.endMesh());
+      // stress variant: every building (shell, window frames, glass) is modelled around its own origin and turned by a random angle, so the large
+      // facade triangles and the thousands of frame boxes are no longer axis aligned
+      const float bx = stress ? 0.f : wbx, bz = stress ? 0.f : wbz;
+      const M4 bm = stress ? translate({wbx, 0, wbz}) * rotateY(B.rng.range(-0.45f, 0.45f)) : translate({0, 0, 0});
+      B.beginMesh(mat(2 + b)); B.box({bx, hh, bz}, {hw, hh, hd}, 0.f, false, 4.f); B.addNode(B.endMesh(), bm);
       B.beginMesh(mat(7 + b));
       int floors = std::max(1, int(10 * s)), cols = std::max(1, int(12 * s));
       float face = (b & 1) ? bz - hd : bz + hd, dir = (b & 1) ? -1.f : 1.f;
@@ -339,17 +346,17 @@ GltfScene makeBistro(bool interior, float scale, uint32_t seed)
           B.box({wx, wy - wh, face + dir * 0.06f}, {ww, 0.04f, 0.08f});
           B.box({wx, wy + wh, face + dir * 0.06f}, {ww, 0.04f, 0.06f});
         }
-      B.addNode(B.endMesh());
+      B.addNode(B.endMesh(), bm);
       B.beginMesh(P.glass);
       for(int f = 0; f < floors; f++)
         for(int c = 0; c < cols; c++) {
           float wx = bx - hw + (c + 0.5f) * 2 * hw / cols, wy = (f + 0.6f) * 2 * hh / floors, ww = 0.7f * hw / cols, wh = 0.6f * hh / floors, z = face + dir * 0.02f;
           B.quad({wx - ww, wy - wh, z}, {wx + ww, wy - wh, z}, {wx + ww, wy + wh, z}, {wx - ww, wy + wh, z}, {0, 0, dir});
         }
-      B.addNode(B.endMesh());
+      B.addNode(B.endMesh(), bm);
     }
     // trees: 4 prim meshes (trunk + alpha-masked leaf quads), instanced — ~10 % of all triangles
-    int leafQuads = std::max(8, int(3000 * scale));
+    int leafQuads = std::max(8, int((stress ? 6000 : 3000) * scale));
     int treeMesh[4], trunkMesh;
     B.beginMesh(mat(3)); B.cylinder({0, 0, 0}, 0.22f, 3.2f, std::max(5, int(24 * s)), std::max(2, int(20 * s))); trunkMesh = B.endMesh();
     for(int t = 0; t < 4; t++) {
@@ -364,7 +371,7 @@ GltfScene makeBistro(bool interior, float scale, uint32_t seed)
       }
       treeMesh[t] = B.endMesh();
     }
-    int nt = std::max(2, int(40 * scale + 0.5f));
+    int nt = std::max(2, int((stress ? 80 : 40) * scale + 0.5f));
     for(int t = 0; t < nt; t++) {
       M4 m = translate({-X + 5.f + t * (2 * X - 10.f) / nt, 0, (t & 1) ? 7.5f : -7.5f}) * rotateY(B.rng.range(0, 6.28f)) * scaleM({1, B.rng.range(0.85f, 1.2f), 1});
       B.addNode(trunkMesh, m); B.addNode(treeMesh[t & 3], m);
@@ -377,6 +384,12 @@ GltfScene makeBistro(bool interior, float scale, uint32_t seed)
       float lx = -X + 3.f + (l + 0.5f) * (2 * X - 6.f) / nl, lz = interior ? ((l % 3) - 1) * 3.2f : ((l & 1) ? 5.2f : -5.2f), ly = interior ? 3.6f : 4.4f;
       B.beginMesh(P.lamp); B.sphere({lx, ly, lz}, {0.16f, 0.12f, 0.16f}, interior ? 8 : 6, 4); B.addNode(B.endMesh());
       if(!interior) { B.beginMesh(P.metal); B.cylinder({lx, 0, lz}, 0.05f, 4.3f, 8, 2); B.addNode(B.endMesh()); }
+      if(!interior && stress && l + 1 < nl) {   // stress variant: thin diagonal wires from lamp to lamp across the street
+        const float nx2 = -X + 3.f + (l + 1.5f) * (2 * X - 6.f) / nl, nz2 = -lz;
+        const float dx = nx2 - lx, dz = nz2 - lz, len = std::sqrt(dx * dx + dz * dz);
+        B.beginMesh(P.metal); B.box({0, 0, 0}, {0.5f * len, 0.008f, 0.008f});
+        B.addNode(B.endMesh(), translate({0.5f * (lx + nx2), 4.25f, 0.5f * (lz + nz2)}) * rotateY(-std::atan2(dz, dx)));
+      }
     }
   }
   // props (chairs / bikes / crockery stand-ins): high-resolution blobs, the bulk of the triangle count
