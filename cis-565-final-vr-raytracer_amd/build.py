@@ -37,15 +37,19 @@ def _deps(d, exts):
     return out
 
 
-def build_hip(force=False, verbose=False):
+def build_hip(force=False, verbose=False, variant=None, extra_flags=()):
     """hipcc --offload-arch=gfx950: one object per translation unit, compiled in parallel (the stage kernels exist in four
-    variants, see csrc/stages.hip), then one link into csrc/librestir_hip.so.  Objects go to csrc/_obj (git-ignored)."""
+    variants, see csrc/stages.hip), then one link into csrc/librestir_hip.so.  Objects go to csrc/_obj (git-ignored).
+    `variant` + `extra_flags`: a measurement build (e.g. -DRT_WAVEPROF=1) into csrc/_ab/librestir_hip_<variant>.so, selected at run
+    time with RESTIR_HIP_LIB; never the product library."""
     d = os.path.join(_HERE, "csrc")
+    HIP_LIB = globals()["HIP_LIB"] if variant is None else os.path.join(d, "_ab", "librestir_hip_%s.so" % variant)
+    os.makedirs(os.path.dirname(HIP_LIB), exist_ok=True)
     if force or _stale(HIP_LIB, _deps(d, (".cpp", ".hip", ".h"))):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        objdir = os.path.join(d, "_obj")
+        objdir = os.path.join(d, "_obj" if variant is None else "_obj_" + variant)
         os.makedirs(objdir, exist_ok=True)
-        flags = [f for f in HIP_FLAGS if f != "-shared"] + os.environ.get("RESTIR_EXTRA_HIPFLAGS", "").split()   # experiments only
+        flags = [f for f in HIP_FLAGS if f != "-shared"] + list(extra_flags) + os.environ.get("RESTIR_EXTRA_HIPFLAGS", "").split()   # experiments only
         jobs = []
         for src in HIP_SRC:
             obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")

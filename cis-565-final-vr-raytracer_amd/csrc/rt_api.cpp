@@ -882,6 +882,21 @@ int rt_accel_stats(rt_ctx* c, uint64_t* numNodes, uint64_t* numTris, int* maxDep
   return RT_OK;
 }
 
+#if RT_WAVEPROF
+/* measurement builds only (scripts/wave_profile.py): read and clear the per-wave profile records kept in the hitRec scratch */
+int rt_debug_wave_profile(rt_ctx* c, void* dst, size_t bytes)
+{
+  if(!c || !dst || c->W == 0) return RT_ERR_INVALID_ARG;
+  RT_HIP(c, hipSetDevice(c->device));
+  RT_HIP(c, syncAll(c));
+  bytes = std::min(bytes, size_t(c->W) * c->H * 16);
+  RT_HIP(c, hipMemcpy(dst, c->scratch.hitRec, bytes, hipMemcpyDeviceToHost));
+  RT_HIP(c, hipMemset(c->scratch.hitRec, 0, bytes));
+  RT_HIP(c, hipDeviceSynchronize());
+  return RT_OK;
+}
+#endif
+
 int rt_measure_valu_peak(rt_ctx* c, int variant, int wavesPerSimd, double* waveInstPerSec)
 {
   if(!c || !waveInstPerSec || variant < 0 || variant > 1 || wavesPerSimd < 1 || wavesPerSimd > 8) return RT_ERR_INVALID_ARG;

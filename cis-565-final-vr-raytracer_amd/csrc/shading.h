@@ -259,8 +259,14 @@ struct Ctx {
   }
 
   // ------------------------------------------------------------------------------- traceray_rq.glsl:108-185
+#if RT_WAVEPROF
+  uint32_t cycClosest = 0, cycAny = 0;
+  RT_DEV void ClosestHit(const Ray& r) { nClosest++; const uint64_t c0 = clock64(); traceRay<false>(S, r.origin, r.direction, RT_INFINITY, seed, stack, hit, tc); cycClosest += uint32_t(clock64() - c0); }
+  RT_DEV bool AnyHit(const Ray& r, float maxDist) { nAny++; RayHit h; const uint64_t c0 = clock64(); const bool f = traceRay<true>(S, r.origin, r.direction, maxDist, seed, stack, h, tc); cycAny += uint32_t(clock64() - c0); return f; }
+#else
   RT_DEV void ClosestHit(const Ray& r) { nClosest++; traceRay<false>(S, r.origin, r.direction, RT_INFINITY, seed, stack, hit, tc); }
   RT_DEV bool AnyHit(const Ray& r, float maxDist) { nAny++; RayHit h; return traceRay<true>(S, r.origin, r.direction, maxDist, seed, stack, h, tc); }
+#endif
 
   // ----------------------------------------------------------------------------------- gltf_material.glsl
   RT_DEV static f4 SRGBtoLINEAR(f4 c) { return mk4(rt_pow(c.x, 2.2f), rt_pow(c.y, 2.2f), rt_pow(c.z, 2.2f), c.w); }  // :34-43

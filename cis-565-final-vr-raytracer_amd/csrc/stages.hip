@@ -47,6 +47,9 @@ namespace RT_VARIANT {
 __global__ __launch_bounds__(64, RT_DIRECT_LB) void k_direct_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY)
 {
   extern __shared__ uint2 s_stack[];
+#if RT_WAVEPROF
+  const uint64_t prof_c0 = clock64(), prof_w0 = wall_clock64();
+#endif
   const TileCoord tile = tileOf(tilesX, tilesY);
   if(!tile.valid) return;
   const int lane = int(threadIdx.x);
@@ -127,6 +130,9 @@ __global__ __launch_bounds__(64, RT_DIRECT_LB) void k_direct_stage(DevScene S, D
     storeImg(F.thisDirectResult, F, px, mk4(pixelColor, 1.0f));  // :286
   }
   flushCounters(F, c);
+#if RT_WAVEPROF
+  waveProfFlush(F, c, tile.x, tile.y, prof_c0, prof_w0);
+#endif
 }
 
 // Second half of direct_stage.comp's ReSTIRDirect for the spatial modes (:86-121, 236-262): two rounds of five neighbour
@@ -493,6 +499,9 @@ __global__ __launch_bounds__(64, RT_INDIRECT_LB) void k_indirect_stage(DevScene 
   // paths per wave the majority-vote loop runs fewer rounds per ray, and the idle SIMDs of an under-filled chip get work:
   // the latency of the longest multi-bounce tile — the floor of a small launch — drops.  Results do not change.
   extern __shared__ uint2 s_stack[];
+#if RT_WAVEPROF
+  const uint64_t prof_c0 = clock64(), prof_w0 = wall_clock64();
+#endif
   TileCoord tile;
   const int part = (int(blockIdx.x) >> 3) & ((1 << subShift) - 1);
   {
@@ -628,6 +637,9 @@ __global__ __launch_bounds__(64, RT_INDIRECT_LB) void k_indirect_stage(DevScene 
     }
     // Russian roulette (:218-224) is compiled out in the reference (`#ifndef RR`, pathtrace.glsl:2)
   }
+#if RT_WAVEPROF
+  waveProfFlush(F, c, tile.x | (multiBounce ? 0x10000 : 0), tile.y, prof_c0, prof_w0);
+#endif
   if(!hasSurface) { flushCounters(F, c); return; }
 
   restirIndirectFinish(c, F, st, cam, px, indSize, primState, primWo, gi, primSamplePdf);

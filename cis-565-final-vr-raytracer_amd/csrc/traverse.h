@@ -21,7 +21,16 @@ struct RayHit {
   float u, v;
 };
 
-struct TravCounters { uint32_t nodes, tris, rounds, live; };
+// RT_WAVEPROF (compile-time, measurement builds only: scripts/wave_profile.py): per-wave cycle breakdown of the traversal rounds
+#ifndef RT_WAVEPROF
+#define RT_WAVEPROF 0
+#endif
+struct TravCounters {
+  uint32_t nodes, tris, rounds, live;
+#if RT_WAVEPROF
+  uint32_t rN, rT, rC, cN, cT, cC, aTex, aOmm;   // rounds / cycles by kind (node, triangle, cooperative tail), alpha candidates by resolution
+#endif
+};
 
 // ---- texture fetch: Vulkan sampler restatement, LOD 0 (scene.cpp:513-548) -----------------
 // i mod p, result in [0, p).  `%` with a run-time divisor is a ~30-instruction software division on the GPU; for a power of two
@@ -298,7 +307,7 @@ RT_DEV void travNode(const DevScene& S, Trav& T, uint2* stack, TravCounters& tc)
 // One triangle candidate of a ray: intersect, range / closest-so-far test, opacity (micro-map first, texture only when the
 // micro-map cell is mixed).  The verdict depends on (ray, triangle) only — never on the order candidates are visited in.
 RT_DEV bool triCandidate(const DevScene& S, uint32_t triIndex, f3 o, f3 d, bool ANY, float tmax, float curT, uint32_t curG, uint32_t seed, float& t, float& u, float& v,
-                         uint32_t& gid)
+                         uint32_t& gid, TravCounters& tc)
 {
   const uint4* tp = reinterpret_cast<const uint4*>(S.tris + triIndex);
   const uint4 a = tp[0], b = tp[1], c = tp[2], om = tp[3];
@@ -321,6 +330,11 @@ RT_DEV bool triCandidate(const DevScene& S, uint32_t triIndex, f3 o, f3 d, bool 
     const int cell = cj * 8 + ci;
     const uint32_t word = (cell < 16) ? om.x : ((cell < 32) ? om.y : ((cell < 48) ? om.z : om.w));
     const uint32_t state = (word >> ((cell & 15) * 2)) & 3u;
+#if RT_WAVEPROF
+    if(state == 0u) tc.aTex++; else tc.aOmm++;
+#else
+    (void)tc;
+#endif
     bool accept;
     if(state == 1u) accept = true;
     else if(state == 2u) { uint32_t hs = candidateSeed(seed, R.globalId); accept = !(rnd(hs) > 0.0f); }
@@ -339,7 +353,7 @@ RT_DEV void travTri(const DevScene& S, Trav& T, TravCounters& tc)
   T.tgroup.y &= ~(1u << bit);
   tc.tris++;
   float t, u, v; uint32_t gid;
-  if(!triCandidate(S, T.tgroup.x + bit, T.o, T.d, ANY, T.tmax, T.hit.t, T.hit.gid, T.seed, t, u, v, gid)) return;
+  if(!triCandidate(S, T.tgroup.x + bit, T.o, T.d, ANY, T.tmax, T.hit.t, T.hit.gid, T.seed, t, u, v, gid, tc)) return;
   T.hit.t = t; T.hit.gid = gid; T.hit.u = u; T.hit.v = v;
   T.found = true;
   if(ANY) { T.tgroup.y = 0u; T.ngroup.y = 0u; T.sp = 0; }  // first accepted hit terminates the query
@@ -382,7 +396,7 @@ RT_DEV void travTriCoop(const DevScene& S, Trav& T, unsigned long long triMask, 
       }
       float t = 0.0f, u = 0.0f, v = 0.0f; uint32_t gid = 0u;
       bool ok = false;
-      if(mine >= 0) ok = triCandidate(S, tbase + uint32_t(mine), o, d, ANY, tmax, bt, bg, seed, t, u, v, gid);
+      if(mine >= 0) ok = triCandidate(S, tbase + uint32_t(mine), o, d, ANY, tmax, bt, bg, seed, t, u, v, gid, tc);
       unsigned long long okm = __ballot(ok ? 1 : 0);
       while(okm != 0ull) {
         const int w = __builtin_ctzll(okm);
@@ -426,11 +440,20 @@ RT_DEV bool travRoundMasked(const DevScene& S, Trav& T, bool live, unsigned long
   const bool wantTri = live && travHasTris(T);
   const unsigned long long triMask = __ballot(wantTri ? 1 : 0);
   const int nLive = __popcll(liveMask), nT = __popcll(triMask), nN = nLive - nT;
+#if RT_WAVEPROF
+  const uint64_t c0 = clock64();
+#endif
   if(nLive <= S.coopLive) {  // tail of the wave (wave-uniform): all pending triangles at once, then a node step for every live ray
     if(nT > 0) travTriCoop<ANY>(S, T, triMask, tc);
     if(live && travHasNodes(T)) travNode(S, T, stack, tc);
   } else if(nT >= nN) { if(wantTri) travTri<ANY>(S, T, tc); }
   else { if(live && !wantTri) travNode(S, T, stack, tc); }
+#if RT_WAVEPROF
+  {
+    const uint32_t dc = uint32_t(clock64() - c0);
+    if(nLive <= S.coopLive) { tc.rC++; tc.cC += dc; } else if(nT >= nN) { tc.rT++; tc.cT += dc; } else { tc.rN++; tc.cN += dc; }
+  }
+#endif
   return live && (travHasTris(T) || travHasNodes(T));
 }
 

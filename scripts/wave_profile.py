@@ -1,0 +1,79 @@
+"""Per-wave cycle breakdown of the traced stages on a row band (measurement build: csrc/_ab/librestir_hip_prof.so, -DRT_WAVEPROF=1).
+
+    RESTIR_HIP_LIB=.../csrc/_ab/librestir_hip_prof.so python scripts/wave_profile.py [W H] y0 y1 [y0 y1 ...]
+
+For every band: the direct stage and the indirect stage launched alone on the band (serial schedule, as a rank of the row-tiled frame runs them),
+then per stage: launch time, the slowest waves with their round counts / cycles by kind of round (node step, triangle step, cooperative tail),
+and how alpha candidates were resolved (opacity micro-map vs texture).  Builds the numbers DESIGN.md §7 quotes for the latency floor of a band."""
+import ctypes as C
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch  # noqa: F401
+from helpers import abi, host, make_scene
+from restir_amd.renderer import Renderer, hip_lib
+
+args = [int(a) for a in sys.argv[1:]]
+W, H = (1920, 1080)
+if len(args) % 2 == 0 and len(args) >= 2 and args[0] >= 640 and args[1] >= 360 and len(args) >= 4:
+    W, H = args[0], args[1]; args = args[2:]
+bands = list(zip(args[0::2], args[1::2])) or [(496, 528), (528, 576)]
+sc, env = make_scene(abi.PROC_BISTRO_EXT, 1.0, 1, (2048, 1024))
+st = host.default_state(W, H, sc, env)
+r = Renderer().setup(0); r.load_scene(sc.desc(env)); r.update(W, H)
+r.set_overlap(0)
+sc.updateCamera(W, H)
+for f in range(6):
+    st.time = 1000 + f; sc.updateCamera(W, H); r.set_camera(sc.getCamera()); r.run(st, f)
+r.sync()
+L = hip_lib()
+L.rt_debug_wave_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+NREC = 65536
+buf = np.zeros((NREC, 16), dtype=np.uint32)
+
+
+def prof():
+    rc = L.rt_debug_wave_profile(r._h, buf.ctypes.data_as(C.c_void_p), buf.nbytes)
+    assert rc == 0, rc
+    return buf.copy()
+
+
+def timed(fn, n=5):
+    fn(); r.sync(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    r.sync(); return (time.perf_counter() - t0) / n * 1e3
+
+
+def report(name, rec, ms):
+    rec = rec[rec[:, 2] > 0]
+    if len(rec) == 0:
+        print(name, "no records"); return
+    cyc = rec[:, 2].astype(np.float64)
+    ghz = cyc / np.maximum(1, rec[:, 15]) * 0.1          # cycles per 10 ns tick -> GHz
+    order = np.argsort(-cyc)
+    print(f"== {name}: launch {ms:.3f} ms, {len(rec)} waves, clock {np.median(ghz):.2f} GHz (median), slowest wave {cyc[order[0]] / np.median(ghz) / 1e6:.3f} ms")
+    tot = rec.astype(np.float64).sum(axis=0)
+    print(f"   all waves: rounds node/tri/coop {tot[5]:.0f}/{tot[6]:.0f}/{tot[7]:.0f}  cycles per round {tot[8] / max(1, tot[5]):.0f}/{tot[9] / max(1, tot[6]):.0f}/{tot[10] / max(1, tot[7]):.0f}"
+          f"  alpha candidates: texture {tot[13]:.0f}, micro-map {tot[14]:.0f} ({100 * tot[13] / max(1, tot[13] + tot[14]):.1f} % texture)")
+    print("   slowest waves: tile(x,y) | wave kcyc | closest kcyc | any kcyc | rounds n/t/c | cyc per round n/t/c | max nodes, tris of a lane | alpha tex/omm")
+    for i in order[:12]:
+        q = rec[i]
+        print(f"   ({q[0] & 0xffff:4d},{q[1]:3d}){' MB' if q[0] & 0x10000 else '   '} | {q[2] / 1e3:8.1f} | {q[3] / 1e3:8.1f} | {q[4] / 1e3:8.1f} | {q[5]:4d}/{q[6]:4d}/{q[7]:4d} | "
+              f"{q[8] / max(1, q[5]):6.0f}/{q[9] / max(1, q[6]):6.0f}/{q[10] / max(1, q[7]):6.0f} | {q[11]:4d},{q[12]:4d} | {q[13]}/{q[14]}")
+    # how much of the slowest wave is traversal
+    q = rec[order[0]]
+    print(f"   slowest wave: traversal {100.0 * (q[3] + q[4]) / q[2]:.0f} % of its cycles; rounds account for {100.0 * (q[8] + q[9] + q[10]) / max(1, q[3] + q[4]):.0f} % of the traversal cycles")
+    hist = np.percentile(cyc, [50, 90, 99, 100]) / np.median(ghz) / 1e6
+    print(f"   wave time percentiles (ms): p50 {hist[0]:.3f} p90 {hist[1]:.3f} p99 {hist[2]:.3f} max {hist[3]:.3f}")
+
+
+f = 7
+st.time = 1000 + f
+for (y0, y1) in bands:
+    print(f"#### band rows {y0}..{y1} of {W}x{H}")
+    for stage, nm, a, b in ((abi.STAGE_DIRECT, "direct", y0, y1), (abi.STAGE_INDIRECT, "indirect", y0 // 2, y1 // 2)):
+        ms = timed(lambda: r.run_stage(st, f, stage, 0, a, b))
+        prof()
+        r.run_stage(st, f, stage, 0, a, b); r.sync()
+        report(f"{nm} rows {a}..{b}", prof(), ms)
