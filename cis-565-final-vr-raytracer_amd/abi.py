@@ -69,6 +69,7 @@ class PickResult(C.Structure):  # rt_pick_result == nvvk::RayPickerKHR::PickResu
     _fields_ = [("worldRayOrigin", C.c_float * 4), ("worldRayDirection", C.c_float * 4), ("hitT", C.c_float), ("primitiveID", C.c_int32), ("instanceID", C.c_int32),
                 ("instanceCustomIndex", C.c_int32), ("baryCoord", C.c_float * 3)]
 RT_STAGE_COUNT = 7
+TRAVERSAL_AUTO, TRAVERSAL_THROUGHPUT, TRAVERSAL_LATENCY = 0, 1, 2   # rt_set_traversal
 class Counters(C.Structure):  # rt_counters
     _fields_ = [("closestHitRays", C.c_uint64), ("anyHitRays", C.c_uint64), ("nodesVisited", C.c_uint64), ("trisTested", C.c_uint64),
                 ("hitsShaded", C.c_uint64), ("risCandidates", C.c_uint64), ("stageMs", C.c_float * RT_STAGE_COUNT), ("frameMs", C.c_float), ("framesTimed", C.c_uint32),

@@ -16,7 +16,7 @@ HOST_LIB = os.path.join(_HERE, "host", "librestir_host.so")
 # (measured) and cost the v_mov that packs their operands: without it every kernel is 3-4 % faster (scripts/ab_flags.sh)
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
              "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize", "-Wno-unused-result", "-x", "hip"]
-HIP_SRC = ["rt_api.cpp", "mgpu.cpp", "bvh8_builder.cpp", "stages.hip", "wavefront.hip", "stages_sky.hip", "wavefront_sky.hip", "stages_cnt.hip", "stages_sky_cnt.hip", "post.hip", "microbench.hip"]
+HIP_SRC = ["rt_api.cpp", "mgpu.cpp", "bvh8_builder.cpp", "stages.hip", "stages_sky.hip", "stages_cnt.hip", "stages_sky_cnt.hip", "stages_lat.hip", "stages_sky_lat.hip", "post.hip", "microbench.hip"]
 HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-pthread"]
 HOST_SRC = ["scene.cpp", "scene_gen.cpp", "hdr_sampling.cpp", "gltf_loader.cpp", "jpeg_decoder.cpp", "png_writer.cpp", "host_capi.cpp"]
 

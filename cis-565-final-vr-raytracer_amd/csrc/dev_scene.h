@@ -49,20 +49,11 @@ struct DevScene {
   uint32_t stackOvfThreads; uint32_t pad3;
 };
 
-// wavefront scratch records (internal; never cross the ABI)
-struct SurfRec {   // what k_direct_resolve needs from the primary hit's shading state: 64 B
+// per-pixel scratch record (internal; never crosses the ABI)
+struct SurfRec {   // what k_direct_spatial needs from the primary hit's shading state: 64 B
   rt_vec3 position, normal, ffnormal, emission;
   float roughness, metallic;
   uint32_t matID, seed;
-};
-struct PathRec {   // one indirect path between kernels: 160 B
-  uint32_t seed, flags;
-  rt_vec3 throughput, position, ffnormal;
-  float roughness, metallic;
-  rt_vec3 albedo, pending;
-  float samplePdf, primSamplePdf;
-  rt_gi_sample gi;
-  uint32_t pad[3];
 };
 
 // per-frame screen-space state (renderer.cpp:227-302), "this"/"last" already resolved from the frame parity
@@ -75,11 +66,9 @@ struct DevFrame {
   float4* thisDirectResult; float4* thisIndirectResult;
   float4* denoiseDirA; float4* denoiseDirB; float4* denoiseIndA; float4* denoiseIndB;
   unsigned long long* counters;     // 6 x u64 (rt_counters order) or nullptr
-  // wavefront scratch (ctx-owned, sized by rt_resize)
-  float4* hitRec; SurfRec* surf; rt_direct_reservoir* cand; uint32_t* candLid;
-  float4* shadowO; float4* shadowD; uint32_t* occ; uint32_t* status; uint32_t* shadowQ;
-  PathRec* path; float4* rayCO; float4* rayCD; float4* hitC; float4* rayAO; float4* rayAD; uint32_t* occH;
-  uint32_t* qC[2]; uint32_t* qA; uint32_t* qcount;
+  // scratch (ctx-owned, sized by rt_resize): per-pixel records between k_direct_stage and k_direct_spatial (spatial reuse modes), the
+  // indirect stage's tile-list counters + the history-miss flags (qcount), per-wave profile records of measurement builds (RT_WAVEPROF)
+  SurfRec* surf; uint32_t* status; uint32_t* qcount; uint32_t* waveProf;
   // A-Trous geometry decoded once per frame: (normal.xyz, matHash bits) and (world position.xyz, 0); full-res and half-res grids
   float4* geomN; float4* geomP; float4* geomNh; float4* geomPh;
   rt_direct_reservoir* tempDirectResv;  // RT_BUF_DIRECT_RESV_TEMP: cacheTempReservoir target of the spatial reuse (direct_stage.comp:127-129)
@@ -92,12 +81,8 @@ struct DevFrame {
   // history and redo the frame; single-GPU: [0, H) and the flag never fires.
   int32_t histRow0, histRow1;
   uint32_t* histMiss;
-  // highest a-trous level that runs on the LDS-tile filter kernel (k_denoise_tile), -1 = none: chosen per launch by rt_api.cpp
-  int32_t denoiseTileMax;
-  // highest a-trous level of the DIRECT filter that runs on the one-wave LDS-staged kernel (k_denoise_lds), -1 = none; takes precedence over the tile kernel
-  int32_t denoiseLdsMax;
   int32_t stackLds;                 // traversal stack entries per lane kept in LDS by this frame's traced launches (0 = the whole stack); the rest sits in DevScene::stackOvf
-  int32_t denoiseLdsMaxInd;         // the same for the INDIRECT filter, after the tile kernel's levels
+  int32_t pad4;
 };
 
 }  // namespace rt

@@ -48,12 +48,11 @@ struct rt_ctx {
   size_t bufBytes[RT_BUF_COUNT] = {};   // logical bytes (W x H elements): readback / upload size
   size_t bufAlloc[RT_BUF_COUNT] = {};   // allocated bytes: + RT_PAD_ROWS rows so equal-height row bands can be all-gathered in place
   rt_scene_camera cam{};
-  // wavefront scratch
+  // internal per-frame scratch (DevFrame)
   std::vector<void*> scratchAllocs;
   DevFrame scratch{};
   int histRow0 = 0, histRow1 = 1 << 30;  // rt_set_history_rows
-  int pipeline = 0;  // 0 = one fused kernel per reference stage (default, fastest measured), 1 = wavefront
-  hipEvent_t evWf = nullptr; bool wfChained = false;   // wavefront stages issued through rt_run_stage are chained (shared queues)
+  int traversal = RT_TRAVERSAL_AUTO;     // rt_set_traversal: which build of the traced kernels a launch gets
   bool counting = false;
   unsigned long long* dCounters = nullptr;
   // timing: per frame one event set; event 0 = frame start, event k = end of launch k.  Sets are harvested lazily.
@@ -100,11 +99,28 @@ static hipError_t joinInFlight(rt_ctx* c)
 }
 
 typedef hipError_t (*StageLauncher)(hipStream_t, const DevScene&, const DevFrame&, const rt_state&, const rt_scene_camera&, int, int, int, int);
-static StageLauncher stageLauncher(const rt_ctx* c)
+// Which build of stages.hip runs a launch.  The traced kernels exist twice: the throughput build (majority-vote rounds, 4-5 waves per SIMD: full
+// frames are bound by instruction issue) and the latency build (csrc/stages_lat.hip: every ray advances every round, node fetch overlapped with the
+// triangle work, 2 waves per SIMD worth of registers: a row band of a multi-GPU frame or a small image is bound by the dependent accesses of its
+// slowest wave).  RT_TRAVERSAL_AUTO decides by the number of 8x8 tiles of the launch; the thresholds are where the two builds measured equal on
+// the benchmark scene (profiles/r03_lat_ab.txt).  The counting build is a throughput build.  Results are bit-identical either way.
+static int latTilesDirect() { static const int v = getenv("RESTIR_LAT_TILES") ? atoi(getenv("RESTIR_LAT_TILES")) : 9000; return v; }
+static int latTilesIndirect() { static const int v = getenv("RESTIR_LAT_TILES_IND") ? atoi(getenv("RESTIR_LAT_TILES_IND")) : 4500; return v; }
+static StageLauncher stageLauncher(const rt_ctx* c, const rt_state& st, int stage, int rowBegin, int rowEnd)
 {
-  // fused kernels come with and without the counter flush (stages.hip); the wavefront kernels always carry it
-  if(c->ds.sky) return c->pipeline ? rt::sky::launchStageWavefront : (c->counting ? rt::sky_cnt::launchStage : rt::sky::launchStage);
-  return c->pipeline ? rt::base::launchStageWavefront : (c->counting ? rt::base_cnt::launchStage : rt::base::launchStage);
+  bool lat = false;
+  if(!c->counting && (stage == RT_STAGE_DIRECT || stage == RT_STAGE_DIRECT_GEN || stage == RT_STAGE_INDIRECT)) {
+    if(c->traversal == RT_TRAVERSAL_LATENCY) lat = true;
+    else if(c->traversal == RT_TRAVERSAL_AUTO) {
+      const bool half = stage == RT_STAGE_INDIRECT;
+      const int gw = half ? st.size.x / 2 : st.size.x, gh = half ? st.size.y / 2 : st.size.y;
+      const int r1 = (rowEnd <= 0 || rowEnd > gh) ? gh : rowEnd, r0 = rowBegin < 0 ? 0 : rowBegin;
+      const long tiles = long((gw + 7) / 8) * long((std::max(0, r1 - r0) + 7) / 8);
+      lat = tiles <= (half ? latTilesIndirect() : latTilesDirect());
+    }
+  }
+  if(c->ds.sky) return lat ? rt::sky_lat::launchStage : (c->counting ? rt::sky_cnt::launchStage : rt::sky::launchStage);
+  return lat ? rt::base_lat::launchStage : (c->counting ? rt::base_cnt::launchStage : rt::base::launchStage);
 }
 
 static thread_local std::string g_createErr;
@@ -202,12 +218,16 @@ static size_t elemBytes(int id)
     default: return 16;
   }
 }
+#ifndef RT_WAVEPROF
+#define RT_WAVEPROF 0
+#endif
+static constexpr size_t WAVEPROF_RECORDS = 1 << 17;   // measurement builds: one record per workgroup of a traced launch
 static constexpr int RT_PAD_ROWS = 128;  // full-res rows of slack behind every buffer (64 for half-res buffers)
 static bool halfRes(int id) { return id == RT_BUF_INDIRECT_RESV0 || id == RT_BUF_INDIRECT_RESV1 || id == RT_BUF_INDIRECT_RESV_TEMP; }
 
 extern "C" {
 
-uint32_t rt_abi_version(void) { return (1u << 16) | 0u; }
+uint32_t rt_abi_version(void) { return (RT_ABI_VERSION_MAJOR << 16) | RT_ABI_VERSION_MINOR; }
 
 const char* rt_last_error(rt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_createErr.c_str(); }
 
@@ -245,13 +265,12 @@ int rt_create(rt_ctx** out, int device)
       ok = ok && hipEventCreateWithFlags(&c->evI[i], hipEventDisableTiming) == hipSuccess;
       ok = ok && hipEventCreateWithFlags(&c->evDone[i], hipEventDisableTiming) == hipSuccess;
     }
-    ok = ok && hipEventCreateWithFlags(&c->evWf, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming) == hipSuccess;
     if(!ok) { g_createErr = "rt_create: creating the internal streams / events failed"; rt_destroy(c); return RT_ERR_HIP; }
   }
   if(const char* e = getenv("RESTIR_OVERLAP")) c->overlap = atoi(e);
-  if(const char* e = getenv("RESTIR_PIPELINE")) c->pipeline = (strcmp(e, "wavefront") == 0) ? 1 : 0;
+  if(const char* e = getenv("RESTIR_LAT")) c->traversal = atoi(e) ? RT_TRAVERSAL_LATENCY : RT_TRAVERSAL_THROUGHPUT;   // A/B runs and the forced-variant parity tests
   if(hipMalloc(reinterpret_cast<void**>(&c->dCounters), 8 * sizeof(unsigned long long)) != hipSuccess) { g_createErr = "rt_create: hipMalloc failed"; delete c; return RT_ERR_OOM; }
   (void)hipMemset(c->dCounters, 0, 8 * sizeof(unsigned long long));
   *out = c;
@@ -275,7 +294,6 @@ int rt_destroy(rt_ctx* c)
   for(auto& E : c->evSets) for(int i = 0; i < rt_ctx::MAX_EV; i++) (void)hipEventDestroy(E.ev[i]);
   if(c->ownStream) (void)hipStreamDestroy(c->ownStream);
   if(c->sideStream) (void)hipStreamDestroy(c->sideStream);
-  if(c->evWf) (void)hipEventDestroy(c->evWf);
   if(c->evFork) (void)hipEventDestroy(c->evFork);
   if(c->evJoin) (void)hipEventDestroy(c->evJoin);
   delete c;
@@ -484,7 +502,7 @@ int rt_resize(rt_ctx* c, int w, int h)
       RT_HIP(c, hipMemset(*spare, 0, alloc));
     }
   }
-  // wavefront scratch
+  // internal scratch
   freePool(c->scratchAllocs);
   c->scratch = DevFrame{};
   auto alloc = [&](size_t bytes, void** out) -> int {
@@ -496,15 +514,14 @@ int rt_resize(rt_ctx* c, int w, int h)
   DevFrame& X = c->scratch;
   int rc;
 #define RT_SCRATCH(field, count, T) if((rc = alloc(size_t(count) * sizeof(T), reinterpret_cast<void**>(&X.field)))) return rc
-  RT_SCRATCH(hitRec, n, float4); RT_SCRATCH(surf, n, SurfRec); RT_SCRATCH(cand, n, rt_direct_reservoir); RT_SCRATCH(candLid, n, uint32_t);
-  RT_SCRATCH(shadowO, n, float4); RT_SCRATCH(shadowD, n, float4); RT_SCRATCH(occ, n, uint32_t); RT_SCRATCH(status, n, uint32_t); RT_SCRATCH(shadowQ, n, uint32_t);
-  RT_SCRATCH(path, nh, PathRec); RT_SCRATCH(rayCO, nh, float4); RT_SCRATCH(rayCD, nh, float4); RT_SCRATCH(hitC, nh, float4);
-  RT_SCRATCH(rayAO, nh, float4); RT_SCRATCH(rayAD, nh, float4); RT_SCRATCH(occH, nh, uint32_t);
-  RT_SCRATCH(qC[0], nh, uint32_t); RT_SCRATCH(qC[1], nh, uint32_t); RT_SCRATCH(qA, nh, uint32_t); RT_SCRATCH(qcount, 256, uint32_t);
+  RT_SCRATCH(surf, n, SurfRec); RT_SCRATCH(status, n, uint32_t); RT_SCRATCH(qcount, 256, uint32_t);
   RT_SCRATCH(geomN, n, float4); RT_SCRATCH(geomP, n, float4); RT_SCRATCH(geomNh, nh, float4); RT_SCRATCH(geomPh, nh, float4);
   RT_SCRATCH(postRowSums, size_t(h) * 6, double); RT_SCRATCH(postMean, 8, float);
   RT_SCRATCH(postMipD, n + 64, float4); RT_SCRATCH(postMipI, n + 64, float4);   // levels 1..7 (n/3 texels; up to n for one-pixel-wide images)
   RT_SCRATCH(tileOrder, (size_t(w / 2 + 7) / 8) * (size_t(h / 2 + 7) / 8 + 16 * 2) + 64 + 4096, uint32_t);   // 8 per-XCD lists: tiles + one chunk of slack each
+#if RT_WAVEPROF
+  RT_SCRATCH(waveProf, WAVEPROF_RECORDS * 16, uint32_t);
+#endif
 #undef RT_SCRATCH
   RT_HIP(c, hipDeviceSynchronize());  // memsets above ran on the null stream; the ctx stream does not wait for it implicitly
   c->W = w; c->H = h;
@@ -539,16 +556,6 @@ static DevFrame makeFrame(rt_ctx* c, int frames)
 {
   const int cur = frames & 1, last = (frames + 1) & 1;  // m_descSet[(frames+1)%2]: this = [!i] (renderer.cpp:157, 346-356)
   DevFrame F{};
-  // A-Trous kernel choice (bit-identical results; profiles/r02_denoise_tile_ab.txt, r02_denoise_lds_ab.txt, r02_short_stack_ab.txt): the one-wave
-  // LDS-staged kernel (k_denoise_lds) on every level of both filters, in every schedule.  The 256-thread tile kernel and the per-pixel gather stay for
-  // A/B runs: RESTIR_DENOISE_TILE / RESTIR_DENOISE_LDS / RESTIR_DENOISE_LDS_IND = <highest level on that kernel | -1>; direct filter: lds before tile,
-  // indirect filter: tile before lds, the gather takes what is left.
-  static const int tileEnv = getenv("RESTIR_DENOISE_TILE") ? atoi(getenv("RESTIR_DENOISE_TILE")) : -1;
-  F.denoiseTileMax = tileEnv;
-  static const int ldsEnv = getenv("RESTIR_DENOISE_LDS") ? atoi(getenv("RESTIR_DENOISE_LDS")) : 3;
-  F.denoiseLdsMax = ldsEnv;
-  static const int ldsIndEnv = getenv("RESTIR_DENOISE_LDS_IND") ? atoi(getenv("RESTIR_DENOISE_LDS_IND")) : 4;
-  F.denoiseLdsMaxInd = ldsIndEnv;
   F.stackLds = stackLdsEnv() ? stackLdsEnv() : (c->overlap == 2 ? 6 : 0);
   F.thisG = static_cast<uint4*>(c->bufs[RT_BUF_GBUFFER0 + cur]); F.lastG = static_cast<const uint4*>(c->bufs[RT_BUF_GBUFFER0 + last]);
   F.motion = static_cast<short2*>(c->bufs[RT_BUF_MOTION]);
@@ -565,9 +572,7 @@ static DevFrame makeFrame(rt_ctx* c, int frames)
   F.counters = c->counting ? c->dCounters : nullptr;
   F.W = c->W; F.H = c->H;
   const DevFrame& X = c->scratch;
-  F.hitRec = X.hitRec; F.surf = X.surf; F.cand = X.cand; F.candLid = X.candLid; F.shadowO = X.shadowO; F.shadowD = X.shadowD; F.occ = X.occ;
-  F.status = X.status; F.shadowQ = X.shadowQ; F.path = X.path; F.rayCO = X.rayCO; F.rayCD = X.rayCD; F.hitC = X.hitC; F.rayAO = X.rayAO;
-  F.rayAD = X.rayAD; F.occH = X.occH; F.qC[0] = X.qC[0]; F.qC[1] = X.qC[1]; F.qA = X.qA; F.qcount = X.qcount;
+  F.surf = X.surf; F.status = X.status; F.qcount = X.qcount; F.waveProf = X.waveProf;
   F.histRow0 = c->histRow0; F.histRow1 = c->histRow1; F.histMiss = X.qcount + 250;
   F.geomN = X.geomN; F.geomP = X.geomP; F.geomNh = X.geomNh; F.geomPh = X.geomPh; F.tileOrder = X.tileOrder; F.postRowSums = X.postRowSums; F.postMean = X.postMean;
   return F;
@@ -592,12 +597,10 @@ int rt_run_stage(rt_ctx* c, const rt_state* st, int frames, int stage, int level
   RT_HIP(c, joinInFlight(c));
   DevFrame F = makeFrame(c, frames);
   if(stage == RT_STAGE_INDIRECT) F.histMiss = c->scratch.qcount + 251;  // per-stage-kind flag (rt_history_miss_stage)
-  // The wavefront organisation keeps its ray queues in ONE set of scratch buffers: two of its stages must never overlap.  A
-  // caller that spreads stages over several streams (tiled.PipelinedTiledFrame) is serialised here with an event chain; the
-  // fused kernels (default) have no shared scratch between stage kinds and run concurrently.
-  if(c->pipeline == 1 && c->wfChained) RT_HIP(c, hipStreamWaitEvent(c->stream, c->evWf, 0));
-  RT_HIP(c, stageLauncher(c)(c->stream, c->ds, F, *st, c->cam, stage, level, rowBegin, rowEnd));
-  if(c->pipeline == 1) { RT_HIP(c, hipEventRecord(c->evWf, c->stream)); c->wfChained = true; }
+  // (stage kinds share no scratch: a caller may spread them over several streams, tiled.PipelinedTiledFrame does)
+  const hipError_t e = stageLauncher(c, *st, stage, rowBegin, rowEnd)(c->stream, c->ds, F, *st, c->cam, stage, level, rowBegin, rowEnd);
+  if(e == hipErrorInvalidValue) return fail(c, RT_ERR_INVALID_ARG, "rt_run_stage: level out of range for this stage (RT_STAGE_DIRECT levels 1 / 2 exist in the spatial modes only)");
+  RT_HIP(c, e);
   return RT_OK;
 }
 
@@ -613,7 +616,7 @@ int rt_render_frame(rt_ctx* c, const rt_state* st, int frames)
     c->evSets.push_back(E);
   }
   rt_ctx::EvSet& E = c->evSets[c->evUsed];
-  const bool pipelined = c->overlap >= 2 && c->pipeline == 0 && c->sideStream && c->indStream && c->spareG && c->spareMotion;
+  const bool pipelined = c->overlap >= 2 && c->sideStream && c->indStream && c->spareG && c->spareMotion;
   if(pipelined) {
     // Rotate the G-buffer (3 physical buffers) and the motion buffer (2): direct(f+1) must not overwrite what indirect(f)
     // still reads (its own G-buffer + motion, and G(f-1) for temporal reprojection).  The boundary ids keep their meaning:
@@ -626,7 +629,7 @@ int rt_render_frame(rt_ctx* c, const rt_state* st, int frames)
   const DevFrame F = makeFrame(c, frames);
   int k = 0, lastMain = 0, lastSide = 0, lastInd = 0;
   auto run = [&](hipStream_t strm, int stage, int level) -> int {
-    hipError_t e = stageLauncher(c)(strm, c->ds, F, *st, c->cam, stage, level, 0, 0);
+    hipError_t e = stageLauncher(c, *st, stage, 0, 0)(strm, c->ds, F, *st, c->cam, stage, level, 0, 0);
     if(e != hipSuccess) { c->err = std::string("launchStage: ") + hipGetErrorString(e); return RT_ERR_HIP; }
     e = hipEventRecord(E.ev[k], strm);
     if(e != hipSuccess) { c->err = std::string("hipEventRecord: ") + hipGetErrorString(e); return RT_ERR_HIP; }
@@ -814,10 +817,10 @@ int rt_rotate_buffers(rt_ctx* c, int frames)
   return RT_OK;
 }
 
-int rt_set_pipeline(rt_ctx* c, int pipeline)
+int rt_set_traversal(rt_ctx* c, int mode)
 {
-  if(!c || pipeline < 0 || pipeline > 1) return RT_ERR_INVALID_ARG;
-  c->pipeline = pipeline;
+  if(!c || mode < RT_TRAVERSAL_AUTO || mode > RT_TRAVERSAL_LATENCY) return RT_ERR_INVALID_ARG;
+  c->traversal = mode;
   return RT_OK;
 }
 
@@ -889,9 +892,9 @@ int rt_debug_wave_profile(rt_ctx* c, void* dst, size_t bytes)
   if(!c || !dst || c->W == 0) return RT_ERR_INVALID_ARG;
   RT_HIP(c, hipSetDevice(c->device));
   RT_HIP(c, syncAll(c));
-  bytes = std::min(bytes, size_t(c->W) * c->H * 16);
-  RT_HIP(c, hipMemcpy(dst, c->scratch.hitRec, bytes, hipMemcpyDeviceToHost));
-  RT_HIP(c, hipMemset(c->scratch.hitRec, 0, bytes));
+  bytes = std::min(bytes, WAVEPROF_RECORDS * 64);
+  RT_HIP(c, hipMemcpy(dst, c->scratch.waveProf, bytes, hipMemcpyDeviceToHost));
+  RT_HIP(c, hipMemset(c->scratch.waveProf, 0, bytes));
   RT_HIP(c, hipDeviceSynchronize());
   return RT_OK;
 }

@@ -1,4 +1,4 @@
-// stage_common.h — helpers shared by the fused stage kernels (stages.hip) and the wavefront pipeline (wavefront.hip).
+// stage_common.h — helpers of the stage kernels (stages.hip).
 #pragma once
 #include "shading.h"
 #include "stages.h"
@@ -64,12 +64,12 @@ RT_DEV void flushCounters(const DevFrame& F, const Ctx& c)
 }
 
 #if RT_WAVEPROF
-// per-wave profile record (measurement builds): 16 x u32 per workgroup in the (otherwise unused) hitRec scratch, merged with atomicMax / atomicAdd.
+// per-wave profile record (measurement builds): 16 x u32 per workgroup in DevFrame::waveProf, merged with atomicMax / atomicAdd.
 //  0 tile x | 1 tile y | 2 wave cycles | 3 cycles in closest-hit traces | 4 in any-hit traces | 5-7 rounds node / tri / coop | 8-10 their cycles |
 //  11 max nodes per lane | 12 max tris per lane | 13 alpha candidates resolved by the texture (sum) | 14 by the micro-map (sum) | 15 100 MHz ticks
 RT_DEV void waveProfFlush(const DevFrame& F, const Ctx& c, int tx, int ty, uint64_t c0, uint64_t w0)
 {
-  uint32_t* rec = reinterpret_cast<uint32_t*>(F.hitRec) + size_t(blockIdx.x) * 16;
+  uint32_t* rec = F.waveProf + size_t(blockIdx.x) * 16;
   rec[0] = uint32_t(tx); rec[1] = uint32_t(ty);
   atomicMax(&rec[2], uint32_t(clock64() - c0)); atomicMax(&rec[3], c.cycClosest); atomicMax(&rec[4], c.cycAny);
   atomicMax(&rec[5], c.tc.rN); atomicMax(&rec[6], c.tc.rT); atomicMax(&rec[7], c.tc.rC);

@@ -3,19 +3,21 @@
 #include "dev_scene.h"
 namespace rt {
 constexpr int STACK_MAX = 64;  // LDS traversal stack entries per lane (8 B each) upper bound; rt_build_accel rejects deeper trees
-// one entry of Renderer::run's dispatch list (renderer.cpp:163-205) on `stream`
-// (two builds of each: namespace base = HDR environment only, namespace sky = sun & sky code paths compiled in)
+// one entry of Renderer::run's dispatch list (renderer.cpp:163-205) on `stream`.  stages.hip is compiled six times:
+//   base / sky          HDR environment only / sun & sky code paths compiled in
+//   base_cnt / sky_cnt  the same with the counters of rt_set_counting flushed
+//   base_lat / sky_lat  the traced kernels for small launches (latency-mode traversal); every other stage forwards to base / sky
 #define RT_DECL_LAUNCH(ns)                                                                                                                              \
   namespace ns {                                                                                                                                        \
   hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F, const rt_state& st, const rt_scene_camera& cam, int stage, int level, \
                          int rowBegin, int rowEnd);                                                                                                     \
-  hipError_t launchStageWavefront(hipStream_t stream, const DevScene& S, const DevFrame& F, const rt_state& st, const rt_scene_camera& cam, int stage,  \
-                                  int level, int rowBegin, int rowEnd);                                                                                 \
   }
 RT_DECL_LAUNCH(base)
 RT_DECL_LAUNCH(sky)
-namespace base_cnt { hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F, const rt_state& st, const rt_scene_camera& cam, int stage, int level, int rowBegin, int rowEnd); }
-namespace sky_cnt { hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F, const rt_state& st, const rt_scene_camera& cam, int stage, int level, int rowBegin, int rowEnd); }
+RT_DECL_LAUNCH(base_cnt)
+RT_DECL_LAUNCH(sky_cnt)
+RT_DECL_LAUNCH(base_lat)
+RT_DECL_LAUNCH(sky_lat)
 #undef RT_DECL_LAUNCH
 
 // uniform-only terms of sun_and_sky() (sky.h), one thread

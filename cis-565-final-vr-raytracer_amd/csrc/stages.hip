@@ -4,24 +4,39 @@
 //   k_direct_gen       direct_gen.comp:77-149     (compiled by the reference, dispatch disabled: renderer.cpp:166-168)
 //   k_direct_reuse     direct_reuse.comp:102-153  (idem, renderer.cpp:170-171)
 //   k_indirect_stage   indirect_stage.comp:129-309, half resolution, tile-level multi-bounce
-//   k_denoise<IND,FAST> denoise_direct.comp / denoise_indirect.comp: one edge-avoiding A-Trous level
+//   k_denoise_lds<IND,FAST> denoise_direct.comp / denoise_indirect.comp: one edge-avoiding A-Trous level
 //   k_compose          compose.comp:23-43
 //
 // Launch shape: one wave64 per 8x8 pixel tile (= the reference's 8x8 workgroups, host_device.h:31-38), 1-D grid with
 // an XCD-aware tile order: consecutive workgroup ids land on different XCDs (observed b % 8), so XCD x gets the x-th
 // contiguous band of tile rows and its private 4 MiB L2 sees one compact screen region + the BVH subtrees under it.
-// This file is compiled four times: as is, and through stages_{sky,cnt,sky_cnt}.hip with RT_SKY / RT_COUNT set.
+// This file is compiled six times: as is, and through stages_{sky,cnt,sky_cnt,lat,sky_lat}.hip with RT_SKY / RT_COUNT / RT_LAT set.
 //   RT_SKY = 1    procedural sun & sky code paths compiled in.  Keeping sun_and_sky() out of the default kernels saves 13 VGPRs
 //                 in k_direct_stage — the procedural sky is the rarely used mode (default in_use = 0, sample_example.hpp:202).
 //   RT_COUNT = 1  traversal / shading counters (rt_set_counting) are flushed at the end of the traced kernels.  Without the
 //                 flush the compiler removes the per-round counter increments from the traversal loops: -1.7 % frame time.
+//   RT_LAT = 1    the traced kernels for SMALL launches (row bands of a multi-GPU frame, small images): the latency-mode traversal round of
+//                 traverse.h and two waves per SIMD worth of registers.  Only the three traced kernels are compiled; every other stage forwards to
+//                 the throughput build.  rt_api.cpp picks per launch (launch size; RESTIR_LAT=0|1 forces).  Same bits.
 #ifndef RT_SKY
 #define RT_SKY 0
 #endif
 #ifndef RT_COUNT
 #define RT_COUNT 0
 #endif
-#if RT_SKY && RT_COUNT
+#ifndef RT_LAT
+#define RT_LAT 0
+#endif
+#if RT_LAT && RT_COUNT
+#error "the counting build exists for the throughput kernels only"
+#endif
+#if RT_LAT && RT_SKY
+#define RT_VARIANT sky_lat
+#define RT_FORWARD sky
+#elif RT_LAT
+#define RT_VARIANT base_lat
+#define RT_FORWARD base
+#elif RT_SKY && RT_COUNT
 #define RT_VARIANT sky_cnt
 #elif RT_SKY
 #define RT_VARIANT sky
@@ -42,7 +57,11 @@ namespace RT_VARIANT {
 // launch bounds of the two traced kernels, re-measured in round 2 under the final schedule (frames in flight, ms/frame, same box):
 // (direct, indirect) waves per SIMD = (5,5) 3.155, (4,5) 3.121, (4,4) 3.29, (5,4) 3.59, (3,5) 3.16, (4,6) 3.15  =>  (4, 5)
 #ifndef RT_DIRECT_LB
+#if RT_LAT
+#define RT_DIRECT_LB 2
+#else
 #define RT_DIRECT_LB 4
+#endif
 #endif
 __global__ __launch_bounds__(64, RT_DIRECT_LB) void k_direct_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY)
 {
@@ -135,6 +154,7 @@ __global__ __launch_bounds__(64, RT_DIRECT_LB) void k_direct_stage(DevScene S, D
 #endif
 }
 
+#if !RT_LAT
 // Second half of direct_stage.comp's ReSTIRDirect for the spatial modes (:86-121, 236-262): two rounds of five neighbour
 // merges from the cached reservoirs, the final merge and the shading.  No rays.
 // The 10 x 10 block of cached reservoirs around the 8 x 8 tile (every neighbour lies within one pixel) is staged in LDS once and the
@@ -210,6 +230,8 @@ __global__ __launch_bounds__(64) void k_direct_spatial(DevScene S, DevFrame F, r
   storeImg(F.thisDirectResult, F, px, mk4(c.clampRadiance(radiance), 1.0f));
 }
 
+#endif  // !RT_LAT
+
 // ------------------------------------------------------------------------------------------------------------
 // direct_gen.comp / direct_reuse.comp
 // ------------------------------------------------------------------------------------------------------------
@@ -252,6 +274,7 @@ __global__ __launch_bounds__(64) void k_direct_gen(DevScene S, DevFrame F, rt_st
   flushCounters(F, c);
 }
 
+#if !RT_LAT
 __global__ __launch_bounds__(64) void k_direct_reuse(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY)
 {
   const TileCoord tile = tileOf(tilesX, tilesY);
@@ -286,6 +309,8 @@ __global__ __launch_bounds__(64) void k_direct_reuse(DevScene S, DevFrame F, rt_
   F.thisLightId[index] = lid;
   storeImg(F.thisDirectResult, F, px, mk4(HDRToLDR(c.clampRadiance(direct)), 1.0f));
 }
+
+#endif  // !RT_LAT
 
 // ------------------------------------------------------------------------------------------------------------
 // indirect_stage.comp
@@ -489,7 +514,11 @@ RT_DEV void indirectSingleBounceTiles(const DevScene& S, const DevFrame& F, cons
 // 5 waves/SIMD (96 VGPRs, a few more spills) instead of 4: the stage alone is no faster, but with frames in flight its waves
 // share the SIMDs with the next frame's direct stage and the frame is 2.7 % shorter (3, 4, 6 measured: 3.96 / 3.47 / 3.42 vs 3.37 ms)
 #ifndef RT_INDIRECT_LB
+#if RT_LAT
+#define RT_INDIRECT_LB 2
+#else
 #define RT_INDIRECT_LB 5
+#endif
 #endif
 __global__ __launch_bounds__(64, RT_INDIRECT_LB) void k_indirect_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY, int cap,
                                                           const uint32_t* lists, const uint32_t* counts, int subShift, int sbK, int genericBlocks)
@@ -646,6 +675,7 @@ __global__ __launch_bounds__(64, RT_INDIRECT_LB) void k_indirect_stage(DevScene 
   flushCounters(F, c);
 }
 
+#if !RT_LAT
 // ------------------------------------------------------------------------------------------------------------
 // denoise_common.glsl + denoise_direct.comp + denoise_indirect.comp
 // ------------------------------------------------------------------------------------------------------------
@@ -731,97 +761,14 @@ __device__ constexpr float kGauss[5][5] = {{.0030f, .0133f, .0219f, .0133f, .003
                                 {.0133f, .0596f, .0983f, .0596f, .0133f},
                                 {.0030f, .0133f, .0219f, .0133f, .0030f}};  // denoise_common.glsl:15-21
 
-// One tap of waveletFilter.  CHECK: the tap may fall outside the image (border tiles); interior tiles skip the tests.
-template <bool IND, bool FAST, bool CHECK>
-RT_DEV void denoiseTap(const float4* __restrict__ src, const float4* __restrict__ gN, const float4* __restrict__ gP, int pitch, i2 bound, i2 q, float gauss, f3 color, f3 norm,
-                       f3 pos, uint32_t matHash, float sigL, float sigN, float sigD, float yL, float yN, float yD, f3& sum, float& sumWeight)
-{
-  if(CHECK) { if(q.x >= bound.x || q.y >= bound.y || q.x < 0 || q.y < 0) return; }
-  const size_t qi = size_t(q.y) * bound.x + q.x;
-  const float4 qN = gN[qi];
-  const uint32_t matHashQ = rt_f2u(qN.w);
-  if(matHash != matHashQ || matHashQ == RT_INVALID_MAT_ID) return;
-  const float4 qP = gP[qi];
-  const float4 cq = src[size_t(q.y) * pitch + q.x];
-  const f3 normQ = mk3(qN.x, qN.y, qN.z), posQ = mk3(qP.x, qP.y, qP.z), colorQ = mk3(cq.x, cq.y, cq.z);
-  const float distColor = IND ? dot(color - colorQ, color - colorQ) : rt_abs(luminance(color) - luminance(colorQ));
-  const float wColor = expNonPositive(-divUniform<FAST>(distColor, sigL, yL)) + 1e-2f;
-  const float distNorm2 = dot(norm - normQ, norm - normQ);
-  const float wNorm = rt_min(1.0f, expNonPositive(-divUniform<FAST>(distNorm2, sigN, yN)));
-  const float distPos2 = dot(pos - posQ, pos - posQ);
-  const float wDepth = expNonPositive(-divUniform<FAST>(distPos2, sigD, yD)) + 1e-2f;
-  const float weight = wColor * wNorm * wDepth * gauss;
-  sum += colorQ * weight;
-  sumWeight += weight;
-}
-
-template <bool IND, bool FAST>
-__global__ __launch_bounds__(64) void k_denoise(DevFrame F, rt_state st, const float4* src, float4* dst, int level, int rowBegin, int rowEnd, int tilesX, int tilesY, float yL,
-                                                float yN, float yD)
-{
-  const TileCoord tile = tileOf(tilesX, tilesY);
-  if(!tile.valid) return;
-  const int lane = int(threadIdx.x);
-  const i2 bound = IND ? i2{st.size.x / 2, st.size.y / 2} : i2{st.size.x, st.size.y};
-  const i2 coord{tile.x * 8 + (lane & 7), rowBegin + tile.y * 8 + (lane >> 3)};
-  if(coord.x >= bound.x || coord.y >= bound.y || coord.y >= rowEnd) return;
-  const float sigLumin = IND ? st.sigLuminIndirect : st.sigLuminDirect;
-  const float sigNormal = IND ? st.sigNormalIndirect : st.sigNormalDirect;
-  const float sigDepth = IND ? st.sigDepthIndirect : st.sigDepthDirect;
-  const int last = IND ? 4 : 3;
-  const float4* gN = IND ? F.geomNh : F.geomN;
-  const float4* gP = IND ? F.geomPh : F.geomP;
-
-  const size_t ci = size_t(coord.y) * bound.x + coord.x;
-  const float4 cN = gN[ci], cP = gP[ci];
-  const f3 norm = mk3(cN.x, cN.y, cN.z), pos = mk3(cP.x, cP.y, cP.z);
-  const uint32_t matHash = rt_f2u(cN.w);
-
-  f3 res = mk3(0.0f);
-  if(matHash != RT_INVALID_MAT_ID) {  // waveletFilter, denoise_direct.comp:19-71 / denoise_indirect.comp:23-75
-    const int step = 1 << level;
-    f3 sum = mk3(0.0f);
-    float sumWeight = 0.0f;
-    const f3 color = xyz(loadImg(src, F, coord));
-    // wave-uniform: every tap of every pixel of this 8x8 tile lies inside the image
-    const int tx0 = tile.x * 8, ty0 = rowBegin + tile.y * 8;
-    const bool interior = tx0 - 2 * step >= 0 && ty0 - 2 * step >= 0 && tx0 + 7 + 2 * step < bound.x && ty0 + 7 + 2 * step < bound.y;
-    // the accumulation order of the reference's loops (j outer, i inner) is kept: float sums are order dependent
-    if(interior) {
-#pragma unroll
-      for(int j = -2; j <= 2; j++)
-#pragma unroll
-        for(int i = -2; i <= 2; i++)
-          denoiseTap<IND, FAST, false>(src, gN, gP, F.W, bound, i2{coord.x + i * step, coord.y + j * step}, kGauss[i + 2][j + 2], color, norm, pos, matHash, sigLumin,
-                                       sigNormal, sigDepth, yL, yN, yD, sum, sumWeight);
-    } else {
-      for(int j = -2; j <= 2; j++)
-        for(int i = -2; i <= 2; i++)
-          denoiseTap<IND, FAST, true>(src, gN, gP, F.W, bound, i2{coord.x + i * step, coord.y + j * step}, kGauss[i + 2][j + 2], color, norm, pos, matHash, sigLumin,
-                                      sigNormal, sigDepth, yL, yN, yD, sum, sumWeight);
-    }
-    res = (sumWeight < 1e-5f) ? mk3(0.0f) : sum / sumWeight;
-    if(hasNan(res) || res.x < 0 || res.y < 0 || res.z < 0 || res.x > 1e8f || res.y > 1e8f || res.z > 1e8f) res = mk3(0.0f);
-  }
-  if(level == last) res = LDRToHDR(res);
-  storeImg(dst, F, coord, mk4(res, 1.0f));
-}
-
 // ------------------------------------------------------------------------------------------------------------
 // waveletFilter on chip.  The weight of tap q in pixel p's sum is, bit for bit, the weight of tap p in pixel q's sum:
 // |a - b| = |b - a|, (a - b)^2 = (b - a)^2 component by component, the material test is symmetric and the 5x5 kernel is
-// point symmetric.  So one workgroup takes a 16 x 16 tile of ONE a-trous sub-lattice (the pixels with equal coordinates modulo
-// 2^level: on it the dilated stencil is a dense 5 x 5), stages colour (+ luminance), normal + material hash and position of the
-// tile and its 2-pixel ring in LDS once, computes every pair weight ONCE (12 "forward" offsets per source pixel, sources =
-// the tile plus the two lattice rows above it and the two lattice columns either side) into LDS, and then every pixel gathers
-// its 25 taps in the reference's order (j outer, i inner: float sums are order dependent) — forward taps read the pixel's own
-// weights, backward taps the neighbour's.  Per pixel: 13 + (ring overhead) weight evaluations instead of 25, no global gathers
-// inside the loop, no 64-bit address arithmetic.  Same expressions => same bits as k_denoise (kept for RESTIR_DENOISE_TILE=0).
+// point symmetric.  On ONE a-trous sub-lattice (the pixels with equal coordinates modulo 2^level) the dilated stencil is a dense 5 x 5,
+// so a workgroup that stages a lattice tile and its 2-pixel ring in LDS can evaluate every pair weight once: 12 "forward" offsets per pixel,
+// backward taps from the neighbour's forward weights.  (A 256-thread / 16 x 16 tile version and the per-pixel gather were the first two
+// forms of this filter; both are superseded by k_denoise_lds below and were removed in round 3 — profiles/r02_denoise_*_ab.txt.)
 // ------------------------------------------------------------------------------------------------------------
-constexpr int DT_T = 16;             // tile edge in lattice pixels
-constexpr int DT_S = DT_T + 4;       // staged edge (2-pixel ring)
-constexpr int DT_SRC_ROWS = DT_T + 2;  // weight sources: ring rows above + tile rows
-constexpr int DT_NSRC = DT_SRC_ROWS * DT_S;
 constexpr int DT_NFWD = 12;
 // forward half of the stencil in (i, j), j > 0 or (j == 0 and i > 0)
 __device__ constexpr int8_t kFwdI[DT_NFWD] = {1, 2, -2, -1, 0, 1, 2, -2, -1, 0, 1, 2};
@@ -841,121 +788,15 @@ RT_DEV float denoisePairWeight(f3 color, float lum, f3 norm, f3 pos, f3 colorQ, 
   return wColor * wNorm * wDepth * gauss;
 }
 
-template <bool IND, bool FAST>
-__global__ __launch_bounds__(256) void k_denoise_tile(DevFrame F, rt_state st, const float4* src, float4* dst, int level, int rowBegin, int rowEnd, int tilesX, int tilesY,
-                                                      float yL, float yN, float yD)
-{
-  __shared__ float4 sC[DT_S * DT_S];            // colour.xyz, luminance (direct filter)
-  __shared__ float4 sN[DT_S * DT_S];            // normal.xyz, material hash bits (RT_INVALID_MAT_ID: no tap)
-  __shared__ float4 sP[DT_S * DT_S];            // reconstructed position
-  __shared__ float sW[DT_NFWD * DT_NSRC];       // forward pair weights, [offset][source]; -1 = no tap
-  const int step = 1 << level;
-  // consecutive work items (the step^2 sub-lattices of one tile region share their cache lines) go to the same XCD; a workgroup
-  // loops over work items gridDim.x / 8 apart (persistent launch: the LDS this kernel holds per CU is bounded by the grid size,
-  // so that traversal kernels of the neighbouring frames in flight keep their LDS stacks)
-  const int total = tilesX * tilesY * step * step, perXcd = (total + 7) / 8;
-  for(int local = int(blockIdx.x >> 3); local < perXcd; local += int(gridDim.x >> 3)) {
-  const int work = int(blockIdx.x & 7u) * perXcd + local;
-  if(work >= total) break;
-  __syncthreads();   // the previous item's gather is done before its LDS is overwritten
-  const int sub = work % (step * step), tileIdx = work / (step * step);
-  const int a = sub % step, b = sub / step;
-  const int X0 = (tileIdx % tilesX) * DT_T, Y0 = (tileIdx / tilesX) * DT_T;
-  const i2 bound = IND ? i2{st.size.x / 2, st.size.y / 2} : i2{st.size.x, st.size.y};
-  const float sigLumin = IND ? st.sigLuminIndirect : st.sigLuminDirect;
-  const float sigNormal = IND ? st.sigNormalIndirect : st.sigNormalDirect;
-  const float sigDepth = IND ? st.sigDepthIndirect : st.sigDepthDirect;
-  const int last = IND ? 4 : 3;
-  const float4* gN = IND ? F.geomNh : F.geomN;
-  const float4* gP = IND ? F.geomPh : F.geomP;
-  const int tid = int(threadIdx.x);
-
-  // ---- 1. stage the tile and its ring ----
-  for(int idx = tid; idx < DT_S * DT_S; idx += 256) {
-    const int lx = idx % DT_S, ly = idx / DT_S;
-    const int px = a + step * (X0 - 2 + lx), py = rowBegin + b + step * (Y0 - 2 + ly);
-    float4 c = make_float4(0.f, 0.f, 0.f, 0.f), n = make_float4(0.f, 0.f, 0.f, rt_u2f(RT_INVALID_MAT_ID)), q = make_float4(0.f, 0.f, 0.f, 0.f);
-    if(px >= 0 && py >= 0 && px < bound.x && py < bound.y) {
-      const size_t gi = size_t(py) * bound.x + px;
-      n = gN[gi]; q = gP[gi];
-      c = src[size_t(py) * F.W + px];
-      c.w = IND ? 0.0f : luminance(mk3(c.x, c.y, c.z));
-    }
-    sC[idx] = c; sN[idx] = n; sP[idx] = q;
-  }
-  __syncthreads();
-
-  // ---- 2. every pair weight once ----
-  for(int sidx = tid; sidx < DT_NSRC; sidx += 256) {
-    const int sx = sidx % DT_S, sy = sidx / DT_S;
-    const float4 cN = sN[sidx], cP = sP[sidx], cC = sC[sidx];
-    const uint32_t hash = rt_f2u(cN.w);
-    const bool srcInTile = sx >= 2 && sx < DT_T + 2 && sy >= 2;
-#pragma unroll
-    for(int k = 0; k < DT_NFWD; k++) {
-      const int i = kFwdI[k], j = kFwdJ[k];
-      const int tx = sx + i, ty = sy + j;
-      float w = -1.0f;
-      if(tx >= 0 && tx < DT_S) {
-        const bool tgtInTile = tx >= 2 && tx < DT_T + 2 && ty >= 2 && ty < DT_T + 2;
-        const int tidx = ty * DT_S + tx;
-        const float4 qN = sN[tidx];
-        if((srcInTile || tgtInTile) && hash != RT_INVALID_MAT_ID && rt_f2u(qN.w) == hash) {
-          const float4 qP = sP[tidx], qC = sC[tidx];
-          w = denoisePairWeight<IND, FAST>(mk3(cC.x, cC.y, cC.z), cC.w, mk3(cN.x, cN.y, cN.z), mk3(cP.x, cP.y, cP.z), mk3(qC.x, qC.y, qC.z), qC.w, mk3(qN.x, qN.y, qN.z),
-                                           mk3(qP.x, qP.y, qP.z), kGauss[i + 2][j + 2], sigLumin, sigNormal, sigDepth, yL, yN, yD);
-        }
-      }
-      sW[k * DT_NSRC + sidx] = w;
-    }
-  }
-  __syncthreads();
-
-  // ---- 3. gather in the reference's tap order ----
-  const int ux = tid % DT_T, uy = tid / DT_T;
-  const i2 coord{a + step * (X0 + ux), rowBegin + b + step * (Y0 + uy)};
-  if(coord.x >= bound.x || coord.y >= bound.y || coord.y >= rowEnd) continue;
-  const int cx = ux + 2, cy = uy + 2, cidx = cy * DT_S + cx;
-  const float4 cN = sN[cidx];
-  f3 res = mk3(0.0f);
-  if(rt_f2u(cN.w) != RT_INVALID_MAT_ID) {
-    const float4 cC = sC[cidx], cP = sP[cidx];
-    f3 sum = mk3(0.0f);
-    float sumWeight = 0.0f;
-#pragma unroll
-    for(int j = -2; j <= 2; j++)
-#pragma unroll
-      for(int i = -2; i <= 2; i++) {
-        float w;
-        if(i == 0 && j == 0)
-          w = denoisePairWeight<IND, FAST>(mk3(cC.x, cC.y, cC.z), cC.w, mk3(cN.x, cN.y, cN.z), mk3(cP.x, cP.y, cP.z), mk3(cC.x, cC.y, cC.z), cC.w, mk3(cN.x, cN.y, cN.z),
-                                           mk3(cP.x, cP.y, cP.z), kGauss[2][2], sigLumin, sigNormal, sigDepth, yL, yN, yD);
-        else if(j > 0 || (j == 0 && i > 0)) w = sW[fwdIndex(i, j) * DT_NSRC + cidx];
-        else w = sW[fwdIndex(-i, -j) * DT_NSRC + (cidx + j * DT_S + i)];
-        if(w != -1.0f) {
-          const float4 q = sC[cidx + j * DT_S + i];
-          sum += mk3(q.x, q.y, q.z) * w;
-          sumWeight += w;
-        }
-      }
-    res = (sumWeight < 1e-5f) ? mk3(0.0f) : sum / sumWeight;
-    if(hasNan(res) || res.x < 0 || res.y < 0 || res.z < 0 || res.x > 1e8f || res.y > 1e8f || res.z > 1e8f) res = mk3(0.0f);
-  }
-  if(level == last) res = LDRToHDR(res);
-  storeImg(dst, F, coord, mk4(res, 1.0f));
-  }
-}
-
-// The same filter with the inputs of ONE wave staged in LDS (k_denoise_lds): a 64-thread workgroup takes an 8 x 8 tile of one a-trous sub-lattice,
-// stages colour (+ luminance), normal + material hash and position of the tile and its 2-pixel ring (12 x 12 lattice pixels, 6.9 KB) and every lane takes
-// its 25 taps from there: 7 global loads per lane instead of 75.  The gather kernel keeps the texture-address path 66-82 % busy when it runs alone
-// (TA_BUSY, profiles/r02_denoise_lds_ab.txt) and shares that path with the traversal kernels when frames are in flight; this one needs a tenth of it,
-// and — unlike k_denoise_tile — its one-wave workgroups fit into any free wave slot.
-// Every pair weight is evaluated once (the symmetry k_denoise_tile uses): a lane owns its pixel's 12 forward weights and the centre weight; a backward
+// k_denoise_lds: a 64-thread workgroup takes an 8 x 8 tile of one a-trous sub-lattice, stages colour (+ luminance), normal + material hash and
+// position of the tile and its 2-pixel ring (12 x 12 lattice pixels, 6.9 KB) and every lane takes its 25 taps from there: 7 global loads per lane
+// instead of the 75 of a per-pixel gather (which kept the texture-address path 66-82 % busy, profiles/r02_denoise_lds_ab.txt); its one-wave
+// workgroups fit into any free wave slot beside the traversal kernels of the frames in flight.
+// Every pair weight is evaluated once: a lane owns its pixel's 12 forward weights and the centre weight; a backward
 // tap takes the neighbour's forward weight when that neighbour is one of the tile's 64 pixels (71 % of the backward taps), the other 222 (pixel, offset)
 // pairs of a tile are the same for every tile — a compile-time list, fetched before the first barrier and worked off in four full-wave passes.  17 weight
 // evaluations per lane instead of 25 (-20 % executed VALU instructions); the weights travel through the LDS that held normals and positions, which are
-// dead by then.  Same expressions, same accumulation order as k_denoise: bit-identical.
+// dead by then.  Same expressions and the accumulation order of the reference's loops (j outer, i inner): bit-identical to a per-pixel gather.
 constexpr int DL_T = 8, DL_S = DL_T + 4;
 // the (pixel p, forward offset k) pairs whose backward partner q = p - offset(k) lies outside the tile, offsets ascending, pixels ascending within an offset:
 // pair = LDS index of p | LDS index of q << 8 in the staged 12 x 12 block, gauss = the kernel factor of the offset, base[k] = first pair of offset k
@@ -1131,18 +972,36 @@ __global__ __launch_bounds__(64) void k_compose(DevFrame F, rt_state st, int row
   }
 }
 
+#endif  // !RT_LAT
+
 // ------------------------------------------------------------------------------------------------------------
 // host-side launch (one entry of Renderer::run's dispatch list, renderer.cpp:163-205)
 // ------------------------------------------------------------------------------------------------------------
 // divUniform's fast path: the divisor must keep every intermediate in the normal range (see there)
 static bool uniformDivOk(float s) { return s >= 1e-6f && s <= 1e6f; }
-// RESTIR_DENOISE_WGS: upper bound of resident k_denoise_tile workgroups (multiple of 8; each holds 36.5 KB of LDS); default: one per work item
-static unsigned denoiseTileGridCap() { static const unsigned v = getenv("RESTIR_DENOISE_WGS") ? (unsigned(atoi(getenv("RESTIR_DENOISE_WGS"))) + 7u) / 8u * 8u : 1u << 30; return std::max(8u, v); }
-// RESTIR_DENOISE_TILE=0 selects the per-pixel gather kernels (k_denoise) for A/B runs; results are bit-identical
+
+#if !RT_LAT
+// one level of an a-trous chain on the one-wave LDS-staged kernel
+template <bool IND>
+static void launchDenoiseLevel(hipStream_t stream, const DevFrame& F, const rt_state& st, const float4* src, float4* dst, int level, int rowBegin, int rowEnd, int gw)
+{
+  const float sL = IND ? st.sigLuminIndirect : st.sigLuminDirect, sN = IND ? st.sigNormalIndirect : st.sigNormalDirect, sD = IND ? st.sigDepthIndirect : st.sigDepthDirect;
+  const int stp = 1 << level, ltx = ((gw + stp - 1) / stp + DL_T - 1) / DL_T, lty = ((rowEnd - rowBegin + stp - 1) / stp + DL_T - 1) / DL_T;
+  const unsigned nwg = 8u * unsigned((ltx * lty * stp * stp + 7) / 8);
+  if(uniformDivOk(sL) && uniformDivOk(sN) && uniformDivOk(sD))
+    hipLaunchKernelGGL((k_denoise_lds<IND, true>), dim3(nwg), dim3(64), 0, stream, F, st, src, dst, level, rowBegin, rowEnd, ltx, lty, 1.0f / sL, 1.0f / sN, 1.0f / sD);
+  else
+    hipLaunchKernelGGL((k_denoise_lds<IND, false>), dim3(nwg), dim3(64), 0, stream, F, st, src, dst, level, rowBegin, rowEnd, ltx, lty, 0.f, 0.f, 0.f);
+}
+#endif
 
 hipError_t launchStage(hipStream_t stream, const DevScene& Sin, const DevFrame& F, const rt_state& st, const rt_scene_camera& cam, int stage, int level,
                        int rowBegin, int rowEnd)
 {
+#if RT_LAT
+  // only the traced kernels exist in this build
+  if(stage != RT_STAGE_DIRECT && stage != RT_STAGE_DIRECT_GEN && stage != RT_STAGE_INDIRECT) return rt::RT_FORWARD::launchStage(stream, Sin, F, st, cam, stage, level, rowBegin, rowEnd);
+#endif
   DevScene S = Sin;
   S.stackEntries = F.stackLds > 0 ? std::min(F.stackLds, S.stackTotal) : S.stackTotal;   // LDS part of the traversal stack for this launch
   if(stage == RT_STAGE_INDIRECT) S.stackOvf = Sin.stackOvfInd;   // a direct-kind kernel of the next frame can be in flight beside it
@@ -1155,6 +1014,7 @@ hipError_t launchStage(hipStream_t stream, const DevScene& Sin, const DevFrame& 
   const int tilesX = (gw + 7) / 8, tilesY = (rowEnd - rowBegin + 7) / 8;
   const dim3 grid(tileGrid(tilesX, tilesY)), block(64);
   const size_t lds = size_t(S.stackEntries) * 64 * sizeof(uint2);
+  const bool spatial = st.ReSTIRState == RT_RESTIR_SPATIAL || st.ReSTIRState == RT_RESTIR_SPATIOTEMPORAL;
   switch(stage) {
     case RT_STAGE_DIRECT:
       // (a K-tiles-per-wave variant of this kernel — primary and shadow rays through the LDS ray pool, pixel state in the scratch
@@ -1162,16 +1022,21 @@ hipError_t launchStage(hipStream_t stream, const DevScene& Sin, const DevFrame& 
       //  split shading costs more than the shorter tail saves.  The single-bounce indirect tiles are where pooling pays.)
       // `level` selects the halves of the stage for hosts that must exchange the cached reservoirs of neighbouring rows in between
       // (row-tiled multi-GPU frames with spatial reuse): 0 = the whole stage, 1 = k_direct_stage only, 2 = k_direct_spatial only
+      if(level < 0 || level > 2 || (level != 0 && !spatial)) return hipErrorInvalidValue;
       if(needOvf && grid.x * 64u > S.stackOvfThreads) return hipErrorInvalidValue;
       if(level != 2) hipLaunchKernelGGL(k_direct_stage, grid, block, lds, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY);
-      if(level != 1 && (st.ReSTIRState == RT_RESTIR_SPATIAL || st.ReSTIRState == RT_RESTIR_SPATIOTEMPORAL))
+      if(level != 1 && spatial) {
+#if RT_LAT
+        return rt::RT_FORWARD::launchStage(stream, Sin, F, st, cam, stage, 2, rowBegin, rowEnd);
+#else
         hipLaunchKernelGGL(k_direct_spatial, grid, block, 0, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY);
+#endif
+      }
       break;
     case RT_STAGE_DIRECT_GEN:
       if(needOvf && grid.x * 64u > S.stackOvfThreads) return hipErrorInvalidValue;
       hipLaunchKernelGGL(k_direct_gen, grid, block, lds, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY);
       break;
-    case RT_STAGE_DIRECT_REUSE: hipLaunchKernelGGL(k_direct_reuse, grid, block, 0, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY); break;
     case RT_STAGE_INDIRECT: {
       // per-XCD tile lists: capacity = the tiles one XCD can own under the striped mapping
       const int cap = int(tileGrid(tilesX, tilesY) / 8);
@@ -1180,10 +1045,9 @@ hipError_t launchStage(hipStream_t stream, const DevScene& Sin, const DevFrame& 
       static const int subEnv = getenv("RESTIR_IND_SUB") ? atoi(getenv("RESTIR_IND_SUB")) : -1;
       const int nTiles = tilesX * tilesY;
       const int subShift = subEnv >= 0 ? subEnv : (nTiles <= 1536 ? 2 : (nTiles <= 3072 ? 1 : 0));
-      // throughput-bound launches: single-bounce tiles go K per wave (indirectSingleBounceTiles); latency-bound ones keep one
-      // (part of a) tile per wave
-      static const int sbEnv = getenv("RESTIR_IND_SBK") ? atoi(getenv("RESTIR_IND_SBK")) : -1;
-      const int sbK = sbEnv >= 0 ? std::min(sbEnv, 3) : (subShift > 0 ? 0 : 3);   // 3 per wave: fewer wave instructions than 2 (frames in flight: -1.3 %), longer stage alone (+4 %)
+      // throughput-bound launches: single-bounce tiles go K per wave (indirectSingleBounceTiles; 3 per wave: fewer wave instructions than 2, frames
+      // in flight -1.3 %, the stage alone +4 %); latency-bound ones keep one (part of a) tile per wave
+      const int sbK = subShift > 0 ? 0 : 3;
       const unsigned genericBlocks = grid.x << subShift;
       const unsigned sbBlocks = sbK > 0 ? 8u * unsigned((cap + sbK - 1) / sbK) : 0u;
       const size_t poolBytes = std::max<size_t>(POOL_BYTES, size_t(sbK) * 64 * 33);
@@ -1192,6 +1056,8 @@ hipError_t launchStage(hipStream_t stream, const DevScene& Sin, const DevFrame& 
                          (const uint32_t*)F.tileOrder, (const uint32_t*)(F.qcount + 192), subShift, sbK, int(genericBlocks));
       break;
     }
+#if !RT_LAT
+    case RT_STAGE_DIRECT_REUSE: hipLaunchKernelGGL(k_direct_reuse, grid, block, 0, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY); break;
     case RT_STAGE_DENOISE_DIRECT: {
       // DirectResult -> DirA -> DirB -> DirA -> DirectResult (denoise_direct.comp:152-172)
       const float4* src[4] = {F.thisDirectResult, F.denoiseDirA, F.denoiseDirB, F.denoiseDirA};
@@ -1202,31 +1068,7 @@ hipError_t launchStage(hipStream_t stream, const DevScene& Sin, const DevFrame& 
         const int gty = (g1 - g0 + 7) / 8;
         hipLaunchKernelGGL(k_denoise_geom<false>, dim3(tileGrid(tilesX, gty)), block, 0, stream, F, st, cam, g0, g1, tilesX, gty);
       }
-      if(level <= F.denoiseLdsMax) {
-        const int stp = 1 << level, ltx = ((gw + stp - 1) / stp + DL_T - 1) / DL_T, lty = ((rowEnd - rowBegin + stp - 1) / stp + DL_T - 1) / DL_T;
-        const unsigned nwg = 8u * unsigned((ltx * lty * stp * stp + 7) / 8);
-        if(uniformDivOk(st.sigLuminDirect) && uniformDivOk(st.sigNormalDirect) && uniformDivOk(st.sigDepthDirect))
-          hipLaunchKernelGGL((k_denoise_lds<false, true>), dim3(nwg), dim3(64), 0, stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, ltx, lty,
-                             1.0f / st.sigLuminDirect, 1.0f / st.sigNormalDirect, 1.0f / st.sigDepthDirect);
-        else
-          hipLaunchKernelGGL((k_denoise_lds<false, false>), dim3(nwg), dim3(64), 0, stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, ltx, lty, 0.f, 0.f, 0.f);
-        break;
-      }
-      if(level <= F.denoiseTileMax) {
-        const int stp = 1 << level, ltx = ((gw + stp - 1) / stp + DT_T - 1) / DT_T, lty = ((rowEnd - rowBegin + stp - 1) / stp + DT_T - 1) / DT_T;
-        const unsigned nwg = std::min(8u * unsigned((ltx * lty * stp * stp + 7) / 8), denoiseTileGridCap());
-        if(uniformDivOk(st.sigLuminDirect) && uniformDivOk(st.sigNormalDirect) && uniformDivOk(st.sigDepthDirect))
-          hipLaunchKernelGGL((k_denoise_tile<false, true>), dim3(nwg), dim3(256), 0, stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, ltx, lty,
-                             1.0f / st.sigLuminDirect, 1.0f / st.sigNormalDirect, 1.0f / st.sigDepthDirect);
-        else
-          hipLaunchKernelGGL((k_denoise_tile<false, false>), dim3(nwg), dim3(256), 0, stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, ltx, lty, 0.f, 0.f, 0.f);
-        break;
-      }
-      if(uniformDivOk(st.sigLuminDirect) && uniformDivOk(st.sigNormalDirect) && uniformDivOk(st.sigDepthDirect))
-        hipLaunchKernelGGL((k_denoise<false, true>), grid, block, 0, stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, tilesX, tilesY,
-                           1.0f / st.sigLuminDirect, 1.0f / st.sigNormalDirect, 1.0f / st.sigDepthDirect);
-      else
-        hipLaunchKernelGGL((k_denoise<false, false>), grid, block, 0, stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, tilesX, tilesY, 0.f, 0.f, 0.f);
+      launchDenoiseLevel<false>(stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, gw);
       break;
     }
     case RT_STAGE_DENOISE_INDIRECT: {
@@ -1240,34 +1082,11 @@ hipError_t launchStage(hipStream_t stream, const DevScene& Sin, const DevFrame& 
         const int gty = (g1 - g0 + 7) / 8;
         hipLaunchKernelGGL(k_denoise_geom<true>, dim3(tileGrid(tilesX, gty)), block, 0, stream, F, st, cam, g0, g1, tilesX, gty);
       }
-      if(level <= F.denoiseTileMax) {
-        const int stp = 1 << level, ltx = ((gw + stp - 1) / stp + DT_T - 1) / DT_T, lty = ((rowEnd - rowBegin + stp - 1) / stp + DT_T - 1) / DT_T;
-        const unsigned nwg = std::min(8u * unsigned((ltx * lty * stp * stp + 7) / 8), denoiseTileGridCap());
-        if(uniformDivOk(st.sigLuminIndirect) && uniformDivOk(st.sigNormalIndirect) && uniformDivOk(st.sigDepthIndirect))
-          hipLaunchKernelGGL((k_denoise_tile<true, true>), dim3(nwg), dim3(256), 0, stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, ltx, lty,
-                             1.0f / st.sigLuminIndirect, 1.0f / st.sigNormalIndirect, 1.0f / st.sigDepthIndirect);
-        else
-          hipLaunchKernelGGL((k_denoise_tile<true, false>), dim3(nwg), dim3(256), 0, stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, ltx, lty, 0.f, 0.f, 0.f);
-        break;
-      }
-      if(level <= F.denoiseLdsMaxInd) {
-        const int stp = 1 << level, ltx = ((gw + stp - 1) / stp + DL_T - 1) / DL_T, lty = ((rowEnd - rowBegin + stp - 1) / stp + DL_T - 1) / DL_T;
-        const unsigned nwg = 8u * unsigned((ltx * lty * stp * stp + 7) / 8);
-        if(uniformDivOk(st.sigLuminIndirect) && uniformDivOk(st.sigNormalIndirect) && uniformDivOk(st.sigDepthIndirect))
-          hipLaunchKernelGGL((k_denoise_lds<true, true>), dim3(nwg), dim3(64), 0, stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, ltx, lty,
-                             1.0f / st.sigLuminIndirect, 1.0f / st.sigNormalIndirect, 1.0f / st.sigDepthIndirect);
-        else
-          hipLaunchKernelGGL((k_denoise_lds<true, false>), dim3(nwg), dim3(64), 0, stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, ltx, lty, 0.f, 0.f, 0.f);
-        break;
-      }
-      if(uniformDivOk(st.sigLuminIndirect) && uniformDivOk(st.sigNormalIndirect) && uniformDivOk(st.sigDepthIndirect))
-        hipLaunchKernelGGL((k_denoise<true, true>), grid, block, 0, stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, tilesX, tilesY,
-                           1.0f / st.sigLuminIndirect, 1.0f / st.sigNormalIndirect, 1.0f / st.sigDepthIndirect);
-      else
-        hipLaunchKernelGGL((k_denoise<true, false>), grid, block, 0, stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, tilesX, tilesY, 0.f, 0.f, 0.f);
+      launchDenoiseLevel<true>(stream, F, st, src[level], dst[level], level, rowBegin, rowEnd, gw);
       break;
     }
     case RT_STAGE_COMPOSE: hipLaunchKernelGGL(k_compose, grid, block, 0, stream, F, st, rowBegin, rowEnd, tilesX, tilesY); break;
+#endif
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -111,46 +111,75 @@ RT_DEV float rnd(uint32_t& seed)  // rand(), random.glsl:98-102
 // HitTest, traceray_rq.glsl:32-102, on the pre-gathered AlphaRec.  The stochastic draw comes from a hash of
 // (ray seed, triangle id) instead of advancing prd.seed per candidate, so the outcome does not depend on candidate
 // order.  Only the alpha channel of the bilinear fetch is evaluated (same arithmetic).
-RT_DEV float texelAlpha(const uint8_t* bgra, int w, int x, int y)
-{
-  return unorm8ToFloat(bgra[(size_t(y) * w + x) * 4 + 3]);
-}
 // seed of the draw for one (ray, triangle) pair; never the ray's own seed (triangle 0 included), so the pixel's next rand() does
 // not repeat the alpha draw
 RT_DEV uint32_t candidateSeed(uint32_t raySeed, uint32_t gid) { return (raySeed ^ 0x9e3779b9u) + (gid + 1u) * 2654435761u; }
-RT_DEV bool hitTestAlpha(const DevScene& S, uint32_t alphaIdx, uint32_t gid, float u, float v, uint32_t raySeed)
+// HitTest in three pieces so that the latency-mode traversal (RT_LAT) can issue the record loads of several candidates, then all their
+// texel loads, before it evaluates any of them; hitTestAlpha() below is the three pieces back to back — same operations, same order.
+struct AlphaRegs { uint4 r0, r1, r2, r3; };
+struct AlphaFetch { const uint8_t* p00; const uint8_t* p10; const uint8_t* p01; const uint8_t* p11; float ax, ay; int kind; };   // kind: 0 no texture, 1 nearest (p00), 2 bilinear
+RT_DEV AlphaRegs alphaLoad(const DevScene& S, uint32_t alphaIdx)
 {
   const uint4* rp = reinterpret_cast<const uint4*>(S.alphaRec + alphaIdx);
-  const uint4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
-  float baseColorAlpha = rt_u2f(r1.z);
-  const uint8_t* bgra = reinterpret_cast<const uint8_t*>((uint64_t(r2.y) << 32) | uint64_t(r2.x));
+  AlphaRegs A; A.r0 = rp[0]; A.r1 = rp[1]; A.r2 = rp[2]; A.r3 = rp[3];
+  return A;
+}
+// texel addresses of the fetch; without a texture every address is `safe` (a readable dummy) so that callers may load unconditionally
+RT_DEV AlphaFetch alphaAddr(const AlphaRegs& A, float u, float v, const uint8_t* safe)
+{
+  AlphaFetch F; F.p00 = F.p10 = F.p01 = F.p11 = safe; F.ax = F.ay = 0.0f; F.kind = 0;
+  const uint8_t* bgra = reinterpret_cast<const uint8_t*>((uint64_t(A.r2.y) << 32) | uint64_t(A.r2.x));
   if(bgra) {
     const f3 bary = mk3((1.0f - u) - v, u, v);
-    const f2 uv = (mk2(rt_u2f(r0.x), rt_u2f(r0.y)) * bary.x + mk2(rt_u2f(r0.z), rt_u2f(r0.w)) * bary.y) + mk2(rt_u2f(r1.x), rt_u2f(r1.y)) * bary.z;
-    const int w = int(r2.z), h = int(r2.w), wrapS = int(r3.x), wrapT = int(r3.y), filter = int(r3.z);
+    const f2 uv = (mk2(rt_u2f(A.r0.x), rt_u2f(A.r0.y)) * bary.x + mk2(rt_u2f(A.r0.z), rt_u2f(A.r0.w)) * bary.y) + mk2(rt_u2f(A.r1.x), rt_u2f(A.r1.y)) * bary.z;
+    const int w = int(A.r2.z), h = int(A.r2.w), wrapS = int(A.r3.x), wrapT = int(A.r3.y), filter = int(A.r3.z);
     float fx = uv.x * float(w), fy = uv.y * float(h);
-    float a;
     if(filter == RT_FILTER_NEAREST) {
-      a = texelAlpha(bgra, w, wrapCoord(rt_ftoi(rt_floor(fx)), w, wrapS), wrapCoord(rt_ftoi(rt_floor(fy)), h, wrapT));
+      const int x = wrapCoord(rt_ftoi(rt_floor(fx)), w, wrapS), y = wrapCoord(rt_ftoi(rt_floor(fy)), h, wrapT);
+      F.p00 = F.p10 = F.p01 = F.p11 = bgra + (size_t(y) * w + x) * 4 + 3;
+      F.kind = 1;
     } else {
       fx = fx - 0.5f; fy = fy - 0.5f;
       const float x0f = rt_floor(fx), y0f = rt_floor(fy);
-      const float ax = fx - x0f, ay = fy - y0f;
+      F.ax = fx - x0f; F.ay = fy - y0f;
       const int x0 = rt_ftoi(x0f), y0 = rt_ftoi(y0f);
       const int xa = wrapCoord(x0, w, wrapS), xb = wrapCoord(x0 + 1, w, wrapS);
       const int ya = wrapCoord(y0, h, wrapT), yb = wrapCoord(y0 + 1, h, wrapT);
-      const float top = mixf(texelAlpha(bgra, w, xa, ya), texelAlpha(bgra, w, xb, ya), ax);
-      const float bot = mixf(texelAlpha(bgra, w, xa, yb), texelAlpha(bgra, w, xb, yb), ax);
-      a = mixf(top, bot, ay);
+      F.p00 = bgra + (size_t(ya) * w + xa) * 4 + 3; F.p10 = bgra + (size_t(ya) * w + xb) * 4 + 3;
+      F.p01 = bgra + (size_t(yb) * w + xa) * 4 + 3; F.p11 = bgra + (size_t(yb) * w + xb) * 4 + 3;
+      F.kind = 2;
+    }
+  }
+  return F;
+}
+RT_DEV bool alphaFinish(const AlphaRegs& A, const AlphaFetch& F, uint8_t a00, uint8_t a10, uint8_t a01, uint8_t a11, uint32_t gid, uint32_t raySeed)
+{
+  float baseColorAlpha = rt_u2f(A.r1.z);
+  if(F.kind != 0) {
+    float a;
+    if(F.kind == 1) a = unorm8ToFloat(a00);
+    else {
+      const float top = mixf(unorm8ToFloat(a00), unorm8ToFloat(a10), F.ax);
+      const float bot = mixf(unorm8ToFloat(a01), unorm8ToFloat(a11), F.ax);
+      a = mixf(top, bot, F.ay);
     }
     baseColorAlpha = baseColorAlpha * a;
   }
   float opacity;
-  if(int(r3.w) == RT_ALPHA_MASK) opacity = baseColorAlpha > rt_u2f(r1.w) ? 1.0f : 0.0f;
+  if(int(A.r3.w) == RT_ALPHA_MASK) opacity = baseColorAlpha > rt_u2f(A.r1.w) ? 1.0f : 0.0f;
   else opacity = baseColorAlpha;
   uint32_t s = candidateSeed(raySeed, gid);
   const float r = rnd(s);
   return !(r > opacity);
+}
+RT_DEV bool hitTestAlpha(const DevScene& S, uint32_t alphaIdx, uint32_t gid, float u, float v, uint32_t raySeed)
+{
+  const AlphaRegs A = alphaLoad(S, alphaIdx);
+  const AlphaFetch F = alphaAddr(A, u, v, reinterpret_cast<const uint8_t*>(S.alphaRec));
+  uint8_t a00 = 0, a10 = 0, a01 = 0, a11 = 0;
+  if(F.kind == 1) a00 = *F.p00;
+  else if(F.kind == 2) { a00 = *F.p00; a10 = *F.p10; a01 = *F.p01; a11 = *F.p11; }
+  return alphaFinish(A, F, a00, a10, a01, a11, gid, raySeed);
 }
 
 // Möller–Trumbore in the fixed operation order of DESIGN.md §Numerics (this TU is compiled with -ffp-contract=off)
@@ -256,22 +285,34 @@ RT_DEV void stackPush(const DevScene& S, Trav& T, uint2* stack, uint2 g)
 }
 
 // Node step (precondition: no pending triangles, travHasNodes).  `stack` = this lane's LDS column (stride 64 entries).
-RT_DEV void travNode(const DevScene& S, Trav& T, uint2* stack, TravCounters& tc)
+// In two halves — pick the nearest pending child (travNodeSelect: stack traffic only, yields the node to fetch), test the fetched node's eight
+// children (travNodeTest) — so that the latency-mode round (RT_LAT) can put a round's triangle work between the fetch and the test.
+struct NodeRegs { uint4 n0, n1, n2, n3, n4; };
+RT_DEV uint32_t travNodeSelect(const DevScene& S, Trav& T, uint2* stack)
 {
   uint2 ngroup = T.ngroup;
   if(ngroup.y <= 0x00FFFFFFu) ngroup = stackPop(S, T, stack);
-  const bool nx = T.d.x < 0.0f, ny = T.d.y < 0.0f, nz = T.d.z < 0.0f;
-  const uint32_t octinv = T.octinv;
-  const uint32_t octinv4 = octinv * 0x01010101u;
   const uint32_t hits = ngroup.y;
   const uint32_t bit = 31u - uint32_t(__clz(int(hits)));
   ngroup.y &= ~(1u << bit);
   if(ngroup.y > 0x00FFFFFFu) stackPush(S, T, stack, ngroup);
-  const uint32_t slot = (bit - 24u) ^ octinv;
+  const uint32_t slot = (bit - 24u) ^ T.octinv;
   const uint32_t rel = uint32_t(__popc(hits & ~(0xFFFFFFFFu << slot) & 0xFFu));
-  const uint4* np = reinterpret_cast<const uint4*>(S.nodes + (ngroup.x + rel));
-  const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-  tc.nodes++;
+  T.ngroup.y = 0u;   // consumed: what is left of the group sits on the stack
+  return ngroup.x + rel;
+}
+RT_DEV NodeRegs nodeLoad(const DevScene& S, uint32_t index)
+{
+  const uint4* np = reinterpret_cast<const uint4*>(S.nodes + index);
+  NodeRegs N; N.n0 = np[0]; N.n1 = np[1]; N.n2 = np[2]; N.n3 = np[3]; N.n4 = np[4];
+  return N;
+}
+RT_DEV void travNodeTest(Trav& T, const NodeRegs& N)
+{
+  const uint4 n0 = N.n0, n1 = N.n1, n2 = N.n2, n3 = N.n3, n4 = N.n4;
+  const bool nx = T.d.x < 0.0f, ny = T.d.y < 0.0f, nz = T.d.z < 0.0f;
+  const uint32_t octinv = T.octinv;
+  const uint32_t octinv4 = octinv * 0x01010101u;
   const float adjx = rt_u2f((n0.w & 0xffu) << 23) * T.idx;
   const float adjy = rt_u2f(((n0.w >> 8) & 0xffu) << 23) * T.idy;
   const float adjz = rt_u2f(((n0.w >> 16) & 0xffu) << 23) * T.idz;
@@ -303,27 +344,41 @@ RT_DEV void travNode(const DevScene& S, Trav& T, uint2* stack, TravCounters& tc)
   T.ngroup = make_uint2(n1.x, (hitmask & 0xFF000000u) | imask);
   T.tgroup = make_uint2(n1.y, hitmask & 0x00FFFFFFu);
 }
+RT_DEV void travNode(const DevScene& S, Trav& T, uint2* stack, TravCounters& tc)
+{
+  const uint32_t index = travNodeSelect(S, T, stack);
+  const NodeRegs N = nodeLoad(S, index);
+  tc.nodes++;
+  travNodeTest(T, N);
+}
 
 // One triangle candidate of a ray: intersect, range / closest-so-far test, opacity (micro-map first, texture only when the
 // micro-map cell is mixed).  The verdict depends on (ray, triangle) only — never on the order candidates are visited in.
-RT_DEV bool triCandidate(const DevScene& S, uint32_t triIndex, f3 o, f3 d, bool ANY, float tmax, float curT, uint32_t curG, uint32_t seed, float& t, float& u, float& v,
-                         uint32_t& gid, TravCounters& tc)
+struct TriRegs { uint4 a, b, c, om; };
+RT_DEV TriRegs triLoad(const DevScene& S, uint32_t triIndex)
 {
   const uint4* tp = reinterpret_cast<const uint4*>(S.tris + triIndex);
-  const uint4 a = tp[0], b = tp[1], c = tp[2], om = tp[3];
+  TriRegs Q; Q.a = tp[0]; Q.b = tp[1]; Q.c = tp[2]; Q.om = tp[3];
+  return Q;
+}
+// everything but the texture fetch: 0 = rejected, 1 = accepted, 2 = accepted iff HitTest on the triangle's AlphaRec (alphaIdx) accepts
+RT_DEV int triCandidateGeom(const DevScene& S, const TriRegs& Q, f3 o, f3 d, bool ANY, float tmax, float curT, uint32_t curG, uint32_t seed, float& t, float& u, float& v,
+                            uint32_t& gid, uint32_t& alphaIdx, TravCounters& tc)
+{
+  const uint4 a = Q.a, b = Q.b, c = Q.c, om = Q.om;
   Tri48 R;
   R.v0x = rt_u2f(a.x); R.v0y = rt_u2f(a.y); R.v0z = rt_u2f(a.z); R.e1x = rt_u2f(a.w);
   R.e1y = rt_u2f(b.x); R.e1z = rt_u2f(b.y); R.e2x = rt_u2f(b.z); R.e2y = rt_u2f(b.w);
   R.e2z = rt_u2f(c.x); R.globalId = c.y; R.flags = c.z; R.alphaIdx = c.w;
-  gid = R.globalId;
-  if(!intersectTri(R, o, d, t, u, v)) return false;
+  gid = R.globalId; alphaIdx = R.alphaIdx;
+  if(!intersectTri(R, o, d, t, u, v)) return 0;
   if(ANY) {
-    if(!(t > 0.0f && t < tmax)) return false;
+    if(!(t > 0.0f && t < tmax)) return 0;
   } else {
-    if(!(t > 0.0f && t < RT_INFINITY)) return false;
-    if(!(t < curT || (t == curT && R.globalId < curG))) return false;
+    if(!(t > 0.0f && t < RT_INFINITY)) return 0;
+    if(!(t < curT || (t == curT && R.globalId < curG))) return 0;
   }
-  if(!hitInsidePaddedBox(R, o, d, S.triPad, t)) return false;
+  if(!hitInsidePaddedBox(R, o, d, S.triPad, t)) return 0;
   if(!(R.flags & TRI_OPAQUE)) {
     // opacity micro-map first: most candidates resolve without touching the texture
     const int ci = min(int(u * 8.0f), 7), cj = min(int(v * 8.0f), 7);
@@ -335,13 +390,20 @@ RT_DEV bool triCandidate(const DevScene& S, uint32_t triIndex, f3 o, f3 d, bool 
 #else
     (void)tc;
 #endif
-    bool accept;
-    if(state == 1u) accept = true;
-    else if(state == 2u) { uint32_t hs = candidateSeed(seed, R.globalId); accept = !(rnd(hs) > 0.0f); }
-    else accept = hitTestAlpha(S, R.alphaIdx, R.globalId, u, v, seed);
-    if(!accept) return false;
+    if(state == 1u) return 1;
+    if(state == 2u) { uint32_t hs = candidateSeed(seed, R.globalId); return !(rnd(hs) > 0.0f) ? 1 : 0; }
+    return 2;
   }
-  return true;
+  return 1;
+}
+RT_DEV bool triCandidate(const DevScene& S, uint32_t triIndex, f3 o, f3 d, bool ANY, float tmax, float curT, uint32_t curG, uint32_t seed, float& t, float& u, float& v,
+                         uint32_t& gid, TravCounters& tc)
+{
+  const TriRegs Q = triLoad(S, triIndex);
+  uint32_t alphaIdx;
+  const int s = triCandidateGeom(S, Q, o, d, ANY, tmax, curT, curG, seed, t, u, v, gid, alphaIdx, tc);
+  if(s == 2) return hitTestAlpha(S, alphaIdx, gid, u, v, seed);
+  return s == 1;
 }
 
 // Triangle step (precondition: travHasTris): test one pending triangle.
@@ -457,6 +519,96 @@ RT_DEV bool travRoundMasked(const DevScene& S, Trav& T, bool live, unsigned long
   return live && (travHasTris(T) || travHasNodes(T));
 }
 
+// ---- latency-mode round (RT_LAT = 1: the traced kernels of SMALL launches, csrc/stages_lat.hip) -----------------------------------------------------
+// A row band of a multi-GPU frame (or a small image) puts about one wave on a SIMD: nothing hides a memory access, and the launch takes what its
+// slowest wave takes — measured on the horizon bands of the benchmark frame (profiles/r03a_wave_profile_baseline.txt): 3000 cycles per node round, 5500
+// per triangle round (record -> AlphaRec -> texels: three dependent accesses whenever one lane of the wave meets an unresolved alpha candidate), and
+// 544 majority-vote rounds for a lane maximum of 337 steps.  Issue slots and registers are free in that regime, dependent accesses are what costs.
+// So this round does for EVERY live ray, every round:
+//   1. pick the next node and issue its five loads (nothing waits for them yet),
+//   2. work off ALL pending triangles of the current leaf group, two records per lane and iteration in one burst; the candidates that need the
+//      texture resolve together afterwards (their AlphaRecs in one burst, then all texels in one burst),
+//   3. test the node's children with the bound the triangles just tightened.
+// A wave then runs as many rounds as its slowest ray visits nodes, with one memory latency per round for node + triangle records.  Verdicts are
+// functions of (ray, triangle) and the closest hit is a minimum over (t, id): the order of the steps does not change a bit of the result.
+#ifndef RT_LAT
+#define RT_LAT 0
+#endif
+#if RT_LAT
+RT_DEV void latAccept(Trav& T, bool ANY, float t, float u, float v, uint32_t gid)
+{
+  T.hit.t = t; T.hit.gid = gid; T.hit.u = u; T.hit.v = v;
+  T.found = true;
+  if(ANY) { T.tgroup.y = 0u; T.ngroup.y = 0u; T.sp = 0; }  // first accepted hit terminates the query
+}
+RT_DEV bool latCloser(const Trav& T, bool ANY, float t, uint32_t gid) { return ANY || t < T.hit.t || (t == T.hit.t && gid < T.hit.gid); }
+
+template <int MODE>
+RT_DEV void travTriBurst(const DevScene& S, Trav& T, TravCounters& tc)
+{
+  const bool ANY = MODE == 2 ? T.isAny : MODE == 1;
+  uint32_t bits = T.tgroup.y;
+  const uint32_t b0 = 31u - uint32_t(__clz(int(bits)));
+  bits &= ~(1u << b0);
+  const bool has1 = bits != 0u;
+  const uint32_t b1 = has1 ? 31u - uint32_t(__clz(int(bits))) : b0;   // no second triangle: the same record again (same cache line, result unused)
+  bits &= ~(1u << b1);
+  T.tgroup.y = bits;
+  const TriRegs Q0 = triLoad(S, T.tgroup.x + b0), Q1 = triLoad(S, T.tgroup.x + b1);
+  tc.tris += has1 ? 2u : 1u;
+  float t0, u0, v0, t1 = 0.f, u1 = 0.f, v1 = 0.f; uint32_t g0, g1 = 0u, a0, a1 = 0u;
+  const int s0 = triCandidateGeom(S, Q0, T.o, T.d, ANY, T.tmax, T.hit.t, T.hit.gid, T.seed, t0, u0, v0, g0, a0, tc);
+  if(s0 == 1) latAccept(T, ANY, t0, u0, v0, g0);
+  int s1 = 0;
+  if(has1 && !(ANY && T.found)) {
+    s1 = triCandidateGeom(S, Q1, T.o, T.d, ANY, T.tmax, T.hit.t, T.hit.gid, T.seed, t1, u1, v1, g1, a1, tc);
+    if(s1 == 1) latAccept(T, ANY, t1, u1, v1, g1);
+  }
+  bool q0 = s0 == 2, q1 = s1 == 2;
+  if(ANY && T.found) { q0 = false; q1 = false; }
+  if(q0 || q1) {
+    const uint8_t* safe = reinterpret_cast<const uint8_t*>(S.alphaRec);
+    const AlphaRegs A0 = alphaLoad(S, q0 ? a0 : 0u), A1 = alphaLoad(S, q1 ? a1 : 0u);   // record 0 is a dummy without a texture
+    const AlphaFetch F0 = alphaAddr(A0, u0, v0, safe), F1 = alphaAddr(A1, u1, v1, safe);
+    const uint8_t x00 = *F0.p00, x10 = *F0.p10, x01 = *F0.p01, x11 = *F0.p11, y00 = *F1.p00, y10 = *F1.p10, y01 = *F1.p01, y11 = *F1.p11;
+    if(q0 && latCloser(T, ANY, t0, g0) && alphaFinish(A0, F0, x00, x10, x01, x11, g0, T.seed)) latAccept(T, ANY, t0, u0, v0, g0);
+    if(q1 && !(ANY && T.found) && latCloser(T, ANY, t1, g1) && alphaFinish(A1, F1, y00, y10, y01, y11, g1, T.seed)) latAccept(T, ANY, t1, u1, v1, g1);
+  }
+}
+
+template <int MODE>
+RT_DEV bool travRoundLat(const DevScene& S, Trav& T, bool live, uint2* stack, TravCounters& tc)
+{
+  const bool ANY = MODE == 2 ? T.isAny : MODE == 1;
+  tc.rounds++; tc.live += live ? 1u : 0u;
+#if RT_WAVEPROF
+  const uint64_t c0 = clock64();
+#endif
+  // 1. the node this ray visits next: fetched now, tested after the triangles
+  const bool sel = live && travHasNodes(T);
+  NodeRegs N{};
+  if(sel) { N = nodeLoad(S, travNodeSelect(S, T, stack)); tc.nodes++; }
+  // 2. every pending triangle of every ray
+  bool wantTri = live && travHasTris(T);
+#if RT_WAVEPROF
+  uint32_t it = 0;
+#endif
+  while(__ballot(wantTri ? 1 : 0) != 0ull) {
+    if(wantTri) travTriBurst<MODE>(S, T, tc);
+    wantTri = live && travHasTris(T);
+#if RT_WAVEPROF
+    it++;
+#endif
+  }
+  // 3. the node's children against the tightened bound (an any-hit ray that found its hit is done)
+  if(sel && !(ANY && T.found)) travNodeTest(T, N);
+#if RT_WAVEPROF
+  { const uint32_t dc = uint32_t(clock64() - c0); tc.rN++; tc.cN += dc; tc.rT += it; }
+#endif
+  return live && (travHasTris(T) || travHasNodes(T));
+}
+#endif  // RT_LAT
+
 template <int ANY>
 RT_DEV bool traceRay(const DevScene& S, f3 o, f3 d, float tmax, uint32_t raySeed, uint2* stack, RayHit& hit, TravCounters& tc)
 {
@@ -466,7 +618,11 @@ RT_DEV bool traceRay(const DevScene& S, f3 o, f3 d, float tmax, uint32_t raySeed
   // (travRound with its ballots shared between the vote and the loop condition: two per round instead of three)
   unsigned long long liveMask = __ballot(live ? 1 : 0);
   while(liveMask != 0ull) {
+#if RT_LAT
+    live = travRoundLat<ANY>(S, T, live, stack, tc);
+#else
     live = travRoundMasked<ANY>(S, T, live, liveMask, stack, tc);
+#endif
     liveMask = __ballot(live ? 1 : 0);
   }
   hit = T.hit;
@@ -530,7 +686,11 @@ RT_DEV void tracePool(const DevScene& S, float4* pool, bool hasC, bool hasS, uin
       if(next >= n) break;
       continue;
     }
+#if RT_LAT
+    const bool still = travRoundLat<2>(S, T, live, stack, tc);
+#else
     const bool still = travRoundMasked<2>(S, T, live, liveMask, stack, tc);
+#endif
     if(live && !still) pool[mySlot * POOL_SLOT_F4] = make_float4(T.hit.t, rt_u2f(T.hit.gid), T.hit.u, T.hit.v);
     live = still;
   }
@@ -577,7 +737,11 @@ RT_DEV void tracePoolTiles(const DevScene& S, float4* pool, uint32_t have /* bit
       if(next >= n) break;
       continue;
     }
+#if RT_LAT
+    const bool still = travRoundLat<ANY>(S, T, live, stack, tc);
+#else
     const bool still = travRoundMasked<ANY>(S, T, live, liveMask, stack, tc);
+#endif
     if(live && !still) pool[mySlot * POOL_SLOT_F4] = make_float4(T.hit.t, rt_u2f(T.hit.gid), T.hit.u, T.hit.v);
     live = still;
   }

@@ -15,7 +15,7 @@ _lib = None
 # every symbol include/rt_abi.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_build_accel", "rt_resize", "rt_set_camera",
                "rt_render_frame", "rt_run_stage", "rt_readback", "rt_upload_history", "rt_buffer_bytes", "rt_device_ptr",
-               "rt_set_counting", "rt_get_counters", "rt_sync", "rt_last_error", "rt_abi_version", "rt_set_pipeline", "rt_set_history_rows", "rt_history_miss", "rt_set_overlap", "rt_tonemap", "rt_set_sun_and_sky", "rt_pick", "rt_history_miss_stage", "rt_rotate_buffers", "rt_measure_valu_peak",
+               "rt_set_counting", "rt_get_counters", "rt_sync", "rt_last_error", "rt_abi_version", "rt_set_traversal", "rt_set_history_rows", "rt_history_miss", "rt_set_overlap", "rt_tonemap", "rt_set_sun_and_sky", "rt_pick", "rt_history_miss_stage", "rt_rotate_buffers", "rt_measure_valu_peak",
                "rt_mgpu_create", "rt_mgpu_destroy", "rt_mgpu_upload_scene", "rt_mgpu_resize", "rt_mgpu_set_camera", "rt_mgpu_render_frame", "rt_mgpu_readback",
                "rt_mgpu_sync", "rt_mgpu_set_balance", "rt_mgpu_set_serialize", "rt_mgpu_get_stats", "rt_mgpu_last_error", "rt_mgpu_plan_bands"]
 
@@ -52,7 +52,7 @@ def hip_lib():
         L.rt_upload_history.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         L.rt_device_ptr.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         L.rt_set_counting.argtypes = [C.c_void_p, C.c_int]
-        L.rt_set_pipeline.argtypes = [C.c_void_p, C.c_int]
+        L.rt_set_traversal.argtypes = [C.c_void_p, C.c_int]
         L.rt_set_overlap.argtypes = [C.c_void_p, C.c_int]
         L.rt_tonemap.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.rt_set_sun_and_sky.argtypes = [C.c_void_p, C.c_void_p]
@@ -172,8 +172,9 @@ class Renderer:
         self._chk(hip_lib().rt_device_ptr(self._h, buf, C.byref(p), C.byref(n), C.byref(pitch)), "rt_device_ptr")
         return _DevArray(p.value, n.value, self), pitch.value
 
-    def set_pipeline(self, wavefront=True):
-        self._chk(hip_lib().rt_set_pipeline(self._h, 1 if wavefront else 0), "rt_set_pipeline")
+    def set_traversal(self, mode):
+        """abi.TRAVERSAL_AUTO (per launch, by its size) / TRAVERSAL_THROUGHPUT / TRAVERSAL_LATENCY: which build of the traced kernels runs; same bits."""
+        self._chk(hip_lib().rt_set_traversal(self._h, int(mode)), "rt_set_traversal")
 
     def tonemap(self, tm=None, debugging_mode=0, frames=0):
         """RenderOutput::run (render_output.cpp:224-237): post.frag over the result images of `frames` -> BUF_LDR (RGBA8)."""

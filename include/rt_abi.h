@@ -367,9 +367,6 @@ int rt_history_miss_stage(rt_ctx* ctx, int stage, int* missed);
  * still running on another stream, reads.  Calling it a second time with the same `frames` undoes the swap.
  * Invalidates rt_device_ptr results for those three buffers. */
 int rt_rotate_buffers(rt_ctx* ctx, int frames);
-/* Kernel organisation of the direct / indirect stages: 0 = one fused kernel per reference stage (default, the fastest
- * measured), 1 = wavefront (lean trace kernels + shading kernels with ray compaction).  Outputs are bit-identical; this is
- * an A/B performance switch (also settable with the environment variable RESTIR_PIPELINE=fused|wavefront before rt_create). */
 /* RenderOutput::run (render_output.cpp:224-237) + post.frag:103-175 as a compute pass: reads the two result images of
  * frame `frames` (RT_BUF_DIRECT_RESULT0/INDIRECT_RESULT0 + (frames & 1)), applies auto-exposure (tonemapping by the image
  * mean, post.frag:133-153), the Uncharted-2 tone curve (tonemapping.glsl:48-66), dithering (post.frag:50-55), contrast /
@@ -380,7 +377,13 @@ int rt_rotate_buffers(rt_ctx* ctx, int frames);
  * formula of RenderOutput::genMipmap (render_output.cpp:243-254; 2x2 box for even sizes) and sampled bilinearly at the fragment;
  * the variable the reference leaves uninitialised in the default view (`v2 ==` at post.frag:91) is 0. */
 int rt_tonemap(rt_ctx* ctx, const rt_tonemapper* tm, int debugging_mode, int frames);
-int rt_set_pipeline(rt_ctx* ctx, int pipeline);
+/* Which build of the ray-traced kernels (direct_stage / direct_gen / indirect_stage) a launch gets.  There are two, with identical
+ * results: THROUGHPUT (majority-vote traversal rounds, 4-5 waves per SIMD — a full frame is bound by instruction issue) and LATENCY
+ * (every ray advances every round, node fetches overlapped with the triangle work, register budget of 2 waves per SIMD — a row band
+ * of a multi-GPU frame or a small image is bound by the dependent memory accesses of its slowest wave).  AUTO (default) picks per
+ * launch from its size.  ABI 2.0: replaces the pipeline switch of ABI 1.0, whose second (queue-based) kernel organisation was removed. */
+enum { RT_TRAVERSAL_AUTO = 0, RT_TRAVERSAL_THROUGHPUT = 1, RT_TRAVERSAL_LATENCY = 2 };
+int rt_set_traversal(rt_ctx* ctx, int mode);
 /* SampleExample::screenPicking (sample_example.cpp:456-497): nvvk::RayPickerKHR — one camera ray through the normalised
  * window position (pickX, pickY in [0,1]) built like raySpawn (origin = modelViewInv * (0,0,0,1), direction = modelViewInv *
  * normalize(perspectiveInv * (2*pick-1, 1, 1))), traced with the path's ClosestHit rules.  The result mirrors
@@ -455,7 +458,10 @@ int rt_measure_valu_peak(rt_ctx* ctx, int variant, int wavesPerSimd, double* wav
 int rt_sync(rt_ctx* ctx);
 /* Last error message of this ctx (or of rt_create when ctx == NULL). Never NULL. */
 const char* rt_last_error(rt_ctx* ctx);
-/* ABI version: (major<<16)|minor */
+/* ABI version: (major<<16)|minor.  2.0 (round 3): rt_set_pipeline -> rt_set_traversal; RT_STAGE_DIRECT levels 1 / 2 are rejected outside the
+ * spatial modes; 1.1 would have been round 2's additions (rt_mgpu_*, rt_measure_valu_peak, the `level` halves of RT_STAGE_DIRECT). */
+#define RT_ABI_VERSION_MAJOR 2u
+#define RT_ABI_VERSION_MINOR 0u
 uint32_t rt_abi_version(void);
 
 #ifdef __cplusplus

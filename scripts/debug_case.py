@@ -22,20 +22,20 @@ st.hdrMultiplier = float(rng.choice([1.0, 0.5, 3.0])); st.debugging_mode = int(r
 if env_kind != 1:
     st.environmentProb = 0.0 if env_kind == 0 else 0.5; st.fireflyClampThreshold = float(rng.choice([5.0, 50.0, 1e4])); st.envMapLuminIntegInv = 0.0
 st.sigLuminDirect = float(rng.choice([0.4, 0.05, 3.0, 1e-7])); st.sigDepthIndirect = float(rng.choice([1.0, 0.2, 2e6]))
-wavefront = bool(rng.integers(0, 2))
-print("case", dict(kind=int(kind), W=W, H=H, env=int(env_kind), depth=st.maxDepth, M=st.RISSampleNum, restir=st.ReSTIRState, mis=st.MIS, dbg=st.debugging_mode, wavefront=wavefront))
+latency = bool(rng.integers(0, 2))
+print("case", dict(kind=int(kind), W=W, H=H, env=int(env_kind), depth=st.maxDepth, M=st.RISSampleNum, restir=st.ReSTIRState, mis=st.MIS, dbg=st.debugging_mode, latency=latency))
 desc = sc.desc(env)
 o = Oracle(0); o.upload_scene(desc); o.resize(W, H)
 outs = {}
 sc.updateCamera(W, H); st.time = 77; sc.updateCamera(W, H); cam = sc.getCamera()
 o.set_camera(cam); o.render_frame(st, 0)
 outs["oracle"] = o.readback(abi.BUF_INDIRECT_RESV0).view(np.uint32).reshape(-1, 19)
-for name, wf in (("fused", False), ("wavefront", True)):
-    r = Renderer().setup(0); r.load_scene(desc); r.update(W, H); r.set_pipeline(wf)
+for name, wf in (("throughput", 1), ("latency", 2)):
+    r = Renderer().setup(0); r.load_scene(desc); r.update(W, H); r.set_traversal(wf)
     r.set_camera(cam); r.run(st, 0)
     outs[name] = r.readback(abi.BUF_INDIRECT_RESV0).view(np.uint32).reshape(-1, 19)
     r.destroy()
-for a, b in (("oracle", "fused"), ("oracle", "wavefront"), ("fused", "wavefront")):
+for a, b in (("oracle", "throughput"), ("oracle", "latency"), ("throughput", "latency")):
     d = np.nonzero((outs[a] != outs[b]).any(1))[0]
     print(a, "vs", b, ":", len(d), "reservoirs differ", d[:5])
     for i in d[:2]:

@@ -14,7 +14,6 @@ def perf_case(name, kind, scale, W, H, max_depth=4, frames=12, warm=4):
     r = Renderer().setup(0)
     t0 = time.time(); r.load_scene(sc.desc(env)); tbuild = time.time() - t0
     r.update(W, H)
-    r.set_pipeline(os.environ.get('RESTIR_PIPELINE', 'fused') == 'wavefront')
     sc.updateCamera(W, H)
     def frame(f):
         st.time = 1000 + f; sc.updateCamera(W, H); r.set_camera(sc.getCamera()); r.run(st, f)

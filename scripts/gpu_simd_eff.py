@@ -9,7 +9,6 @@ for name, kind, md in (("sponza", abi.PROC_SPONZA, 2), ("bistro", abi.PROC_BISTR
     sc, env = make_scene(kind, 1.0, 1, (2048, 1024))
     st = host.default_state(W, H, sc, env); st.maxDepth = md
     r = Renderer().setup(0); r.load_scene(sc.desc(env)); r.update(W, H)
-    r.set_pipeline(os.environ.get('RESTIR_PIPELINE', 'fused') == 'wavefront')
     sc.updateCamera(W, H)
     for f in range(4):
         st.time = 1000 + f; sc.updateCamera(W, H); r.set_camera(sc.getCamera()); r.run(st, f)

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     lib.rt_abi_version.restype = C.c_uint32
-    assert lib.rt_abi_version() >> 16 == 1
+    assert lib.rt_abi_version() >> 16 == 2
 
 
 def test_struct_sizes_match_host_device_h():

@@ -34,17 +34,17 @@ def test_oracle_matches_golden_digests(case):
     _check(case, gen.run_case(gen.oracle_factory, case))
 
 
-def _hip_factory(wavefront):
+def _hip_factory(latency):
     def make(desc, W, H):
         from helpers import RendererBackend
         from restir_amd.renderer import Renderer
-        r = Renderer().setup(0); r.load_scene(desc); r.update(W, H); r.set_pipeline(wavefront)
+        r = Renderer().setup(0); r.load_scene(desc); r.update(W, H); r.set_traversal(2 if latency else 1)
         return RendererBackend(r)
     return make
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("wavefront", [False, True], ids=["fused", "wavefront"])
+@pytest.mark.parametrize("latency", [False, True], ids=["throughput", "latency"])
 @pytest.mark.parametrize("case", sorted(gen.CASES))
-def test_hip_path_matches_golden_digests(case, wavefront):
-    _check(case, gen.run_case(_hip_factory(wavefront), case))
+def test_hip_path_matches_golden_digests(case, latency):
+    _check(case, gen.run_case(_hip_factory(latency), case))

@@ -45,10 +45,10 @@ def run_sweep(cases, seed, first=0):
         if env_kind != 1:
             st.environmentProb = 0.0 if env_kind == 0 else 0.5; st.fireflyClampThreshold = float(rng.choice([5.0, 50.0, 1e4])); st.envMapLuminIntegInv = 0.0
         st.sigLuminDirect = float(rng.choice([0.4, 0.05, 3.0, 1e-7])); st.sigDepthIndirect = float(rng.choice([1.0, 0.2, 2e6]))
-        wavefront = bool(rng.integers(0, 2))
+        latency = bool(rng.integers(0, 2))
         desc = sc.desc(env)
         o = Oracle(0); o.upload_scene(desc); o.resize(W, H)
-        r = Renderer().setup(0); r.load_scene(desc); r.update(W, H); r.set_pipeline(wavefront)
+        r = Renderer().setup(0); r.load_scene(desc); r.update(W, H); r.set_traversal(abi.TRAVERSAL_LATENCY if latency else abi.TRAVERSAL_THROUGHPUT)
         if env_kind == 2:
             ss = abi.SunAndSky(in_use=1, haze=float(rng.uniform(0, 5)), sun_direction=[float(v) for v in rng.normal(size=3)], horizon_height=float(rng.uniform(-0.5, 0.5)))
             o.set_sun_and_sky(ss); r.set_sun_and_sky(ss)
@@ -57,7 +57,7 @@ def run_sweep(cases, seed, first=0):
         vel = rng.normal(scale=0.05, size=3).astype(np.float32) * (rng.integers(0, 2))
         sc.updateCamera(W, H)
         desc_txt = dict(case=ci, kind=int(kind), W=W, H=H, env=int(env_kind), depth=st.maxDepth, M=st.RISSampleNum, restir=st.ReSTIRState, mis=st.MIS, den=st.denoise, mod=st.modulate,
-                        dbg=st.debugging_mode, wavefront=wavefront)
+                        dbg=st.debugging_mode, latency=latency)
         ok = True
         for f in range(3):
             st.time = 77 + f
@@ -97,18 +97,16 @@ def test_regression_sliver_triangle():
     assert run_sweep(385, 302, first=384) == 0
 
 
-KNOBS = ["RESTIR_IND_SUB=0 RESTIR_IND_SBK=3", "RESTIR_IND_SUB=0 RESTIR_IND_SBK=2", "RESTIR_IND_SUB=1 RESTIR_IND_SBK=0",
-         "RESTIR_IND_SUB=0 RESTIR_IND_SBK=0 RESTIR_COOP=64", "RESTIR_OVERLAP=0 RESTIR_COOP=0", "RESTIR_PIPELINE=wavefront RESTIR_OVERLAP=1",
-         # two LDS stack entries: nearly every ray keeps part of its traversal stack in the HBM overflow area; every filter level on each of the three filter kernels
-         "RESTIR_STACK_LDS=2 RESTIR_DENOISE_LDS=4 RESTIR_DENOISE_LDS_IND=4", "RESTIR_STACK_LDS=3 RESTIR_PIPELINE=wavefront",
-         "RESTIR_STACK_LDS=64 RESTIR_DENOISE_LDS=-1 RESTIR_DENOISE_LDS_IND=-1 RESTIR_DENOISE_TILE=4", "RESTIR_DENOISE_LDS=-1 RESTIR_DENOISE_LDS_IND=-1 RESTIR_DENOISE_TILE=-1"]
+KNOBS = ["RESTIR_IND_SUB=0", "RESTIR_IND_SUB=1", "RESTIR_IND_SUB=2 RESTIR_COOP=64", "RESTIR_OVERLAP=0 RESTIR_COOP=0", "RESTIR_OVERLAP=1",
+         # two LDS stack entries: nearly every ray keeps part of its traversal stack in the HBM overflow area
+         "RESTIR_STACK_LDS=2", "RESTIR_STACK_LDS=64"]
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("knobs", KNOBS)
 def test_launch_shape_knobs_do_not_change_the_bits(knobs):
     """The tuning switches of DESIGN.md §12 only change how the work is laid out over waves and streams (tiles per wave, waves per
-    tile, cooperative-tail threshold, stream overlap, kernel organisation, LDS / HBM split of the traversal stack, filter kernel per level).  Small images pick the small-launch shapes on their own,
+    tile, cooperative-tail threshold, stream overlap, LDS / HBM split of the traversal stack).  Small images pick the small-launch shapes on their own,
     so the shapes of a full-size frame are forced here; the library reads some switches once per process, hence a subprocess."""
     import subprocess
     env = dict(os.environ)

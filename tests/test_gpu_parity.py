@@ -11,13 +11,14 @@ from helpers import abi, host, make_scene, frame_buffers, compare_buffers, Rende
 pytestmark = pytest.mark.gpu
 
 
-def _pair(sc, env, W, H, wavefront=True):
+def _pair(sc, env, W, H, latency=True):
     from restir_amd.renderer import Renderer
     from oracle.binding import Oracle
     desc = sc.desc(env)
     o = Oracle(0); o.upload_scene(desc); o.resize(W, H)
     r = Renderer().setup(0); r.load_scene(desc); r.update(W, H)
-    r.set_pipeline(wavefront)   # both kernel organisations must reproduce the oracle bit for bit
+    # both builds of the traced kernels must reproduce the oracle bit for bit (AUTO would pick the latency build for every image this small)
+    r.set_traversal(abi.TRAVERSAL_LATENCY if latency else abi.TRAVERSAL_THROUGHPUT)
     return o, r
 
 
@@ -53,21 +54,21 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("wavefront", [True, False], ids=["wavefront", "fused"])
+@pytest.mark.parametrize("latency", [True, False], ids=["latency", "throughput"])
 @pytest.mark.parametrize("name,kind,scale,W,H,frames,env_size,moving", CASES, ids=[c[0] for c in CASES])
-def test_full_frame_bit_exact(name, kind, scale, W, H, frames, env_size, moving, wavefront):
+def test_full_frame_bit_exact(name, kind, scale, W, H, frames, env_size, moving, latency):
     sc, env = make_scene(kind, scale, 1, env_size)
     st = host.default_state(W, H, sc, env)
     if env is None:
         st.environmentProb = 0.0; st.fireflyClampThreshold = 100.0
-    o, r = _pair(sc, env, W, H, wavefront)
+    o, r = _pair(sc, env, W, H, latency)
     _run(sc, st, o, r, W, H, frames, moving)
     img = r.readback(abi.BUF_DIRECT_RESULT0 + ((frames - 1) & 1)).view(np.float32)
     assert np.isfinite(img).all() and img.max() > 0.01       # not comparing two empty frames
 
 
-@pytest.mark.parametrize("wavefront", [True, False], ids=["wavefront", "fused"])
-def test_gltf_file_scene_bit_exact(wavefront):
+@pytest.mark.parametrize("latency", [True, False], ids=["latency", "throughput"])
+def test_gltf_file_scene_bit_exact(latency):
     """Scene::load path: the hand-authored tests/golden/mini_scene.gltf (TRS hierarchy, PNG textures with nearest / clamp /
     mirror samplers, MASK material, transmission + ior, emissive strength => triangle lights, spot light, file camera)."""
     import os
@@ -76,7 +77,7 @@ def test_gltf_file_scene_bit_exact(wavefront):
     assert sc.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mini_scene.gltf"))
     env = host.HdrSampling(); env.makeSyntheticSky(64, 32, 5e3, 7)
     st = host.default_state(W, H, sc, env)
-    o, r = _pair(sc, env, W, H, wavefront)
+    o, r = _pair(sc, env, W, H, latency)
     _run(sc, st, o, r, W, H, 3, moving=True)
     g = r.readback(abi.BUF_GBUFFER0 + 0).view(np.uint32)
     assert (g != g.flat[0]).any()                            # the camera from the file sees geometry
@@ -87,7 +88,7 @@ def test_back_to_back_frames_vs_oracle():
     W, H = 320, 180
     sc, env = make_scene(abi.PROC_SPONZA, 0.02, 1, (512, 256))
     st = host.default_state(W, H, sc, env)
-    o, r = _pair(sc, env, W, H, wavefront=False)
+    o, r = _pair(sc, env, W, H, latency=False)
     gpu = RendererBackend(r)
     eye, center, up, fov = sc.cameraPose()
     sc.updateCamera(W, H)
@@ -114,9 +115,9 @@ def test_cornell_config2_di_only_512():
     _run(sc, st, o, r, W, H, 8, stages=[(abi.STAGE_DIRECT, 0)], buffers=bufs)
 
 
-@pytest.mark.parametrize("wavefront", [True, False], ids=["wavefront", "fused"])
+@pytest.mark.parametrize("latency", [True, False], ids=["latency", "throughput"])
 @pytest.mark.parametrize("variant", ["restir_none", "ris_only", "no_denoise", "no_modulate", "no_mis_depth2", "debug_normal", "gen_reuse_split", "m16_clamp4", "spatial", "spatiotemporal"])
-def test_state_variants(variant, wavefront):
+def test_state_variants(variant, latency):
     W, H = 160, 96
     sc, env = make_scene(abi.PROC_SPONZA, 0.01, 1, (128, 64))
     st = host.default_state(W, H, sc, env)
@@ -133,7 +134,7 @@ def test_state_variants(variant, wavefront):
     if variant == "gen_reuse_split":
         stages = [(abi.STAGE_DIRECT_GEN, 0), (abi.STAGE_DIRECT_REUSE, 0), (abi.STAGE_INDIRECT, 0)] + \
                  [(abi.STAGE_DENOISE_DIRECT, l) for l in range(4)] + [(abi.STAGE_DENOISE_INDIRECT, l) for l in range(5)] + [(abi.STAGE_COMPOSE, 0)]
-    o, r = _pair(sc, env, W, H, wavefront)
+    o, r = _pair(sc, env, W, H, latency)
     bufs = (lambda f: frame_buffers(f) + [abi.BUF_DIRECT_RESV_TEMP]) if variant.startswith("spatial") or variant == "spatiotemporal" else None
     _run(sc, st, o, r, W, H, 3, moving=True, stages=stages, buffers=bufs)
 
@@ -223,7 +224,7 @@ def test_pick_matches_oracle():
     """rt_pick (SampleExample::screenPicking / nvvk::RayPickerKHR stand-in): same hit record as the oracle for a grid of window positions."""
     W, H = 64, 64
     sc, env = make_scene(abi.PROC_SPONZA, 0.02, 1)
-    o, r = _pair(sc, None, W, H, wavefront=False)
+    o, r = _pair(sc, None, W, H, latency=False)
     sc.updateCamera(W, H)
     cam = sc.getCamera()
     hits = 0
