@@ -25,6 +25,7 @@ struct DevScene {
   const Tri48* tris;
   const TriRef* triRef;
   const AlphaRec* alphaRec;         // indexed by Tri48::alphaIdx
+  const AlphaRec* alphaByTri;       // the same records indexed by TRIANGLE index (zero for opaque triangles): the latency build fetches record and AlphaRec together
   const DevInstance* instances;
   const rt_prim_mesh* primMeshes;   // geoInfo[] (InstanceData rows): vertex/index offsets + materialIndex
   const rt_vertex* vertices;

@@ -104,12 +104,12 @@ typedef hipError_t (*StageLauncher)(hipStream_t, const DevScene&, const DevFrame
 // triangle work, 2 waves per SIMD worth of registers: a row band of a multi-GPU frame or a small image is bound by the dependent accesses of its
 // slowest wave).  RT_TRAVERSAL_AUTO decides by the number of 8x8 tiles of the launch; the thresholds are where the two builds measured equal on
 // the benchmark scene (profiles/r03_lat_ab.txt).  The counting build is a throughput build.  Results are bit-identical either way.
-static int latTilesDirect() { static const int v = getenv("RESTIR_LAT_TILES") ? atoi(getenv("RESTIR_LAT_TILES")) : 9000; return v; }
-static int latTilesIndirect() { static const int v = getenv("RESTIR_LAT_TILES_IND") ? atoi(getenv("RESTIR_LAT_TILES_IND")) : 4500; return v; }
+static int latTilesDirect() { static const int v = getenv("RESTIR_LAT_TILES") ? atoi(getenv("RESTIR_LAT_TILES")) : 0; return v; }
+static int latTilesIndirect() { static const int v = getenv("RESTIR_LAT_TILES_IND") ? atoi(getenv("RESTIR_LAT_TILES_IND")) : 0; return v; }
 static StageLauncher stageLauncher(const rt_ctx* c, const rt_state& st, int stage, int rowBegin, int rowEnd)
 {
   bool lat = false;
-  if(!c->counting && (stage == RT_STAGE_DIRECT || stage == RT_STAGE_DIRECT_GEN || stage == RT_STAGE_INDIRECT)) {
+  if(!c->counting && (stage == RT_STAGE_DIRECT || stage == RT_STAGE_INDIRECT)) {
     if(c->traversal == RT_TRAVERSAL_LATENCY) lat = true;
     else if(c->traversal == RT_TRAVERSAL_AUTO) {
       const bool half = stage == RT_STAGE_INDIRECT;
@@ -461,6 +461,11 @@ int rt_build_accel(rt_ctx* c)
   }
   int rc;
   if((rc = upload(c, c->accelAllocs, alpha.data(), alpha.size(), &c->ds.alphaRec))) return rc;
+  {  // the latency build's copy, addressable without the triangle record (one dependent access less per alpha candidate); 64 B per triangle
+    std::vector<AlphaRec> byTri(bo.tris.size(), AlphaRec{});
+    for(size_t i = 0; i < bo.tris.size(); i++) if(!(bo.tris[i].flags & TRI_OPAQUE)) byTri[i] = alpha[bo.tris[i].alphaIdx];
+    if((rc = upload(c, c->accelAllocs, byTri.data(), byTri.size(), &c->ds.alphaByTri))) return rc;
+  }
   if((rc = upload(c, c->accelAllocs, bo.nodes.data(), bo.nodes.size(), &c->ds.nodes))) return rc;
   if((rc = upload(c, c->accelAllocs, bo.tris.data(), bo.tris.size(), &c->ds.tris))) return rc;
   if((rc = upload(c, c->accelAllocs, bo.triRef.data(), bo.triRef.size(), &c->ds.triRef))) return rc;

@@ -42,6 +42,8 @@ inline unsigned tileGrid(int tilesX, int tilesY)
   const int perXcd = (chunks + 7) / 8;
   return unsigned(8 * perXcd * G);
 }
+// (A column mapping for row bands — XCD x owns a vertical stripe of the band, so that its L2 holds an eighth of the scene under the band — was measured
+// in round 3: the trees of the benchmark street then all belong to two XCDs and the band takes 1.1-1.9x longer, profiles/r03_lat_wide_ab.txt.)
 
 #ifndef RT_COUNT
 #define RT_COUNT 1
@@ -173,8 +175,9 @@ RT_DEV rt_direct_reservoir zeroDirectResv()
   return r;
 }
 
-// the M-candidate RIS loop + visibility of the winner (direct_stage.comp:189-210 == direct_gen.comp:110-132)
-RT_DEV void risCandidates(Ctx& c, const State& state, f3 wo, rt_direct_reservoir& resv, uint32_t& lid)
+// the M-candidate RIS loop (direct_stage.comp:189-200 == direct_gen.comp:110-122); the visibility of the winner (:202-210) is the caller's:
+// returns whether the shadow ray has to be traced (a zero-weight reservoir cannot change — the only effect of the ray is weight := 0 — so its ray is skipped)
+RT_DEV bool risCandidatesNoVisibility(Ctx& c, const State& state, f3 wo, rt_direct_reservoir& resv, uint32_t& lid, Ray& shadowRay, float& shadowDist)
 {
   for(int i = 0; i < c.rtx.RISSampleNum; i++) {
     rt_light_sample ls;
@@ -185,9 +188,14 @@ RT_DEV void risCandidates(Ctx& c, const State& state, f3 wo, rt_direct_reservoir
     if(resvUpdate(resv, ls, weight, rnd(c.seed))) lid = c.lastLightId;
   }
   const rt_light_sample ls = resv.lightSample;
-  Ray shadowRay{OffsetRay(state.position, state.ffnormal), mk3(ls.wi)};
-  // a zero-weight reservoir cannot change here (the only effect of the shadow ray is weight := 0): skip the ray
-  if(resv.weight != 0.0f && c.Occlusion(shadowRay, state.position, ls.dist)) resv.weight = 0.0f;
+  shadowRay = Ray{OffsetRay(state.position, state.ffnormal), mk3(ls.wi)};
+  shadowDist = ((ls.dist - rt_abs(shadowRay.origin.x - state.position.x)) - rt_abs(shadowRay.origin.y - state.position.y)) - rt_abs(shadowRay.origin.z - state.position.z);  // Occlusion, pathtrace.glsl:18-22
+  return resv.weight != 0.0f;
+}
+RT_DEV void risCandidates(Ctx& c, const State& state, f3 wo, rt_direct_reservoir& resv, uint32_t& lid)
+{
+  Ray shadowRay; float shadowDist;
+  if(risCandidatesNoVisibility(c, state, wo, resv, lid, shadowRay, shadowDist) && c.AnyHit(shadowRay, shadowDist)) resv.weight = 0.0f;
 }
 
 

@@ -57,12 +57,212 @@ namespace RT_VARIANT {
 // launch bounds of the two traced kernels, re-measured in round 2 under the final schedule (frames in flight, ms/frame, same box):
 // (direct, indirect) waves per SIMD = (5,5) 3.155, (4,5) 3.121, (4,4) 3.29, (5,4) 3.59, (3,5) 3.16, (4,6) 3.15  =>  (4, 5)
 #ifndef RT_DIRECT_LB
-#if RT_LAT
-#define RT_DIRECT_LB 2
-#else
 #define RT_DIRECT_LB 4
 #endif
+// ReSTIRDirect (direct_stage.comp:150-270) cut at its one shadow ray, so that the ray can be traced by whatever the build uses (the lane's own
+// traversal loop in the throughput build, the workgroup's ray pool in the latency build) while both builds share every line of shading:
+//   directPre   primary hit -> G-buffer, motion vector, M-candidate RIS (or the single DirectLight sample); returns whether a shadow ray is needed
+//   directPost  visibility of the winner, temporal reuse, reservoir store, shading, result store
+struct DirectCont {
+  State state; f3 wo, radiance; i2 motionIdx;
+  rt_direct_reservoir resv; uint32_t lid;
+  float pdf;     // kind 2: pdf of the single light sample (kept in resv.lightSample)
+  int kind;      // 0: radiance is final (miss, emitter, debug view), 1: RIS reservoir, 2: single sample (ReSTIRState none)
+};
+RT_DEV float occlusionDist(const Ray& ray, f3 statePos, float dist)   // Occlusion, pathtrace.glsl:18-22
+{
+  return ((dist - rt_abs(ray.origin.x - statePos.x)) - rt_abs(ray.origin.y - statePos.y)) - rt_abs(ray.origin.z - statePos.z);
+}
+RT_DEV bool directPre(Ctx& c, const DevFrame& F, const rt_state& st, i2 px, const Ray& r, DirectCont& K, Ray& shadowRay, float& shadowDist)
+{
+  const size_t index = size_t(px.y) * st.size.x + px.x;
+  K.kind = 0; K.radiance = mk3(0.0f);
+  if(c.hit.t >= RT_INFINITY) {  // :155-159
+    F.thisG[index] = make_uint4(rt_f2u(RT_INFINITY), 0u, 0u, RT_INVALID_MAT_ID);
+    storeMotion(F, px, i2{0, 0});
+    K.radiance = c.EnvRadiance(r.direction);
+    return false;
+  }
+  State& state = K.state;
+  state = c.GetState(r.direction);
+  c.GetMaterials(state, r);
+  K.motionIdx = createMotionIndex(c, state.position);
+  const uint4 gInfo = encodeGeometryInfo(state, c.hit.t);
+  storeMotion(F, px, K.motionIdx);
+  F.thisG[index] = gInfo;
+  if(st.debugging_mode > RT_DBG_INDIRECT_STAGE) { K.radiance = c.DebugInfo(state); return false; }
+  if(state.isEmitter) { K.radiance = state.mat.emission; return false; }
+  K.wo = -r.direction;
+  state.mat.albedo = mk3(1.0f);
+  K.resv = zeroDirectResv();
+  K.lid = 0xffffffffu;
+  if(st.ReSTIRState == RT_RESTIR_NONE) {  // DirectLight, pathtrace.glsl:205-220
+    K.kind = 2;
+    rt_light_sample ls;
+    K.pdf = c.SampleDirectLightNoVisibility(state.position, ls);
+    K.resv.lightSample = ls;
+    if(Ctx::IsPdfInvalid(K.pdf)) return false;
+    shadowRay = Ray{OffsetRay(state.position, state.ffnormal), mk3(ls.wi)};
+    shadowDist = occlusionDist(shadowRay, state.position, ls.dist);
+    return true;
+  }
+  K.kind = 1;
+  return risCandidatesNoVisibility(c, state, K.wo, K.resv, K.lid, shadowRay, shadowDist);
+}
+RT_DEV void directPost(Ctx& c, const DevFrame& F, const rt_state& st, const rt_scene_camera& cam, i2 px, DirectCont& K, bool occluded)
+{
+  const size_t index = size_t(px.y) * st.size.x + px.x;
+  const bool spatial = st.ReSTIRState == RT_RESTIR_SPATIAL || st.ReSTIRState == RT_RESTIR_SPATIOTEMPORAL;
+  bool deferred = false;
+  f3 radiance = K.radiance;
+  if(K.kind != 0) {
+    State& state = K.state;
+    const f3 wo = K.wo;
+    f3 direct = mk3(0.0f);
+    if(K.kind == 2) {
+      const rt_light_sample ls = K.resv.lightSample;
+      if(!Ctx::IsPdfInvalid(K.pdf) && !occluded)
+        direct = mk3(ls.Li) * metallicWorkflowBSDF(state.mat, state.ffnormal, wo, mk3(ls.wi)) * rt_max(dot(state.ffnormal, mk3(ls.wi)), 0.0f) / K.pdf;
+    } else {
+      rt_direct_reservoir& resv = K.resv;
+      uint32_t lid = K.lid;
+      if(occluded) resv.weight = 0.0f;
+      if(st.ReSTIRState == RT_RESTIR_TEMPORAL || st.ReSTIRState == RT_RESTIR_SPATIOTEMPORAL) {
+        const float reprojDepth = length(mk3(cam.lastPosition) - state.position);
+        rt_direct_reservoir temporal; uint32_t tlid = 0xffffffffu;
+        if(findTemporalNeighborDirect(F, st, state.normal, reprojDepth, state.matID, K.motionIdx, temporal, tlid)) {
+          if(!resvInvalidW(temporal.weight)) { if(resvMerge(resv, temporal, rnd(c.seed))) lid = tlid; }
+        }
+      }
+      rt_direct_reservoir tempResv = resv;
+      if(resvInvalidW(tempResv.weight)) { tempResv.num = 0; tempResv.weight = 0.f; }
+      resvClamp(tempResv, st.RISSampleNum * st.reservoirClamp);
+      F.thisDirectResv[index] = tempResv;  // saveNewReservoir
+      F.thisLightId[index] = lid;
+      if(spatial) {
+        // Spatial / spatiotemporal reuse (:224-255) reads the reservoirs its neighbours cache here.  The reference orders
+        // that with workgroup barriers only (neighbours in other workgroups race); this build finishes the pixel in a
+        // second kernel (k_direct_spatial) once every pixel of the launch has cached its reservoir.
+        if(resvInvalidW(resv.weight)) { resv.num = 0; resv.weight = 0.f; }  // resvCheckValidity(resv) :231
+        F.tempDirectResv[index] = resv;                                      // cacheTempReservoir :234
+        SurfRec sr;
+        sr.position = toR(state.position); sr.normal = toR(state.normal); sr.ffnormal = toR(state.ffnormal); sr.emission = toR(state.mat.emission);
+        sr.roughness = state.mat.roughness; sr.metallic = state.mat.metallic; sr.matID = state.matID; sr.seed = c.seed;
+        F.surf[index] = sr;
+        deferred = true;
+      } else {
+        const rt_light_sample ls = resv.lightSample;
+        if(!resvInvalidW(resv.weight)) {
+          f3 LiBsdf = mk3(ls.Li) * metallicWorkflowBSDF(state.mat, state.ffnormal, wo, mk3(ls.wi));
+          direct = LiBsdf / resvToScalar(LiBsdf) * resv.weight / float(resv.num);
+        }
+      }
+    }
+    if(rt_isnan(direct.x) || rt_isnan(direct.y) || rt_isnan(direct.z)) direct = mk3(0.0f);
+    radiance = HDRToLDR(c.clampRadiance(state.mat.emission + direct));
+  }
+  if(spatial) F.status[index] = deferred ? 1u : 0u;
+  if(!deferred) {
+    const f3 pixelColor = c.clampRadiance(radiance);
+    storeImg(F.thisDirectResult, F, px, mk4(pixelColor, 1.0f));  // :286
+  }
+}
+
+#if RT_LAT
+// ---- latency build: a workgroup of NW waves per 8x8 tile.  Wave 0 owns the 64 pixels (everything that is not traversal runs there, one lane per pixel,
+// exactly the code of the throughput build); rays go through the workgroup's LDS pool and every wave traces them eight lanes per ray (tracePoolWide).
+struct WideLds { uint2* stacks; float4* pool; unsigned char* list; uint32_t* ctrl; };   // ctrl: [0] rays listed, [1] cursor, [2] wave 0 has finished
+RT_DEV WideLds wideLds(uint2* base, int stackEntries, int nWaves)
+{
+  WideLds L;
+  L.stacks = base;
+  L.pool = reinterpret_cast<float4*>(base + size_t(nWaves) * stackEntries * WIDE_RAYS);
+  L.list = reinterpret_cast<unsigned char*>(L.pool + 128 * POOL_SLOT_F4);
+  L.ctrl = reinterpret_cast<uint32_t*>(L.list + 128);
+  return L;
+}
+inline size_t wideLdsBytes(int stackEntries, int nWaves) { return size_t(nWaves) * stackEntries * WIDE_RAYS * sizeof(uint2) + 128 * 32 + 128 + 16; }
+// wave 0, all 64 lanes: list the slots its lanes filled (slot 2 * lane: closest-hit ray, 2 * lane + 1: any-hit ray)
+RT_DEV void poolPublish(const WideLds& L, bool hasC, bool hasS)
+{
+  const int lane = int(threadIdx.x) & 63;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const unsigned long long mC = __ballot(hasC ? 1 : 0), mS = __ballot(hasS ? 1 : 0);
+  const int nC = __popcll(mC);
+  if(hasC) L.list[__popcll(mC & lt)] = (unsigned char)(lane * 2);
+  if(hasS) L.list[nC + __popcll(mS & lt)] = (unsigned char)((lane * 2 + 1) | 0x80);
+  if(lane == 0) { L.ctrl[0] = uint32_t(nC + __popcll(mS)); L.ctrl[1] = 0u; L.ctrl[2] = 0u; }
+}
+// every wave of the workgroup
+RT_DEV void groupTrace(const DevScene& S, const WideLds& L, TravCounters& tc)
+{
+  __syncthreads();
+  const int wave = int(threadIdx.x) >> 6;
+  tracePoolWide(S, L.pool, L.list, int(L.ctrl[0]), &L.ctrl[1], L.stacks + size_t(wave) * S.stackEntries * WIDE_RAYS, tc);
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(512, 2) void k_direct_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY)
+{
+  extern __shared__ uint2 s_stack[];
+  const TileCoord tile = tileOf(tilesX, tilesY);
+  if(!tile.valid) return;
+  const int wave = int(threadIdx.x) >> 6, lane = int(threadIdx.x) & 63;
+  const WideLds L = wideLds(s_stack, S.stackEntries, int(blockDim.x) >> 6);
+  const i2 px{tile.x * 8 + (lane & 7), rowBegin + tile.y * 8 + (lane >> 3)};
+  const bool mine = wave == 0 && !(px.x >= st.size.x || px.y >= rowEnd);
+#if RT_WAVEPROF
+  const uint64_t p0 = clock64(), w0 = wall_clock64();
+  uint64_t p1 = 0, p2 = 0, p3 = 0, p4 = 0;
 #endif
+  Ctx c(S, st, cam, nullptr);
+  Ray r{mk3(0.0f), mk3(0.0f)};
+  if(mine) {
+    c.imageCoords = px;
+    c.seed = tea(uint32_t(st.size.x) * uint32_t(px.y) + uint32_t(px.x), st.time);  // :279
+    r = c.raySpawn(px, i2{st.size.x, st.size.y});
+    c.nClosest++;
+    poolPut(L.pool, lane * 2, r.origin, r.direction, RT_INFINITY, c.seed);
+  }
+  if(wave == 0) poolPublish(L, mine, false);
+#if RT_WAVEPROF
+  p1 = clock64();
+#endif
+  groupTrace(S, L, c.tc);
+#if RT_WAVEPROF
+  p2 = clock64();
+#endif
+  DirectCont K;
+  Ray shadowRay{mk3(0.0f), mk3(0.0f)};
+  float shadowDist = 0.0f;
+  bool wantShadow = false;
+  if(mine) {
+    c.hit = poolGet(L.pool, lane * 2);
+    wantShadow = directPre(c, F, st, px, r, K, shadowRay, shadowDist);
+    if(wantShadow) { c.nAny++; poolPut(L.pool, lane * 2 + 1, shadowRay.origin, shadowRay.direction, shadowDist, c.seed); }
+  }
+  if(wave == 0) poolPublish(L, false, wantShadow);
+#if RT_WAVEPROF
+  p3 = clock64();
+#endif
+  groupTrace(S, L, c.tc);
+#if RT_WAVEPROF
+  p4 = clock64();
+#endif
+  if(mine) directPost(c, F, st, cam, px, K, wantShadow && poolGet(L.pool, lane * 2 + 1).gid != 0xffffffffu);
+#if RT_WAVEPROF
+  {  // record: 0 x | 1 y | 2 workgroup cycles | 3 primary trace | 4 shadow trace | 5 node-only rounds (max over waves) | 6 rounds with triangles | 7 raygen | 8 cyc node rounds | 9 cyc tri rounds | 10 pre | 11 post | 15 ticks
+    uint32_t* rec = F.waveProf + size_t(blockIdx.x) * 16;
+    const uint64_t p5 = clock64();
+    if(wave == 0 && lane == 0) {
+      rec[0] = uint32_t(tile.x); rec[1] = uint32_t(tile.y); rec[2] = uint32_t(p5 - p0); rec[3] = uint32_t(p2 - p1); rec[4] = uint32_t(p4 - p3);
+      rec[7] = uint32_t(p1 - p0); rec[10] = uint32_t(p3 - p2); rec[11] = uint32_t(p5 - p4); rec[15] = uint32_t(wall_clock64() - w0);
+    }
+    if(lane == 0) { atomicMax(&rec[5], c.tc.rN); atomicMax(&rec[6], c.tc.rT); atomicMax(&rec[8], c.tc.cN); atomicMax(&rec[9], c.tc.cT); }
+  }
+#endif
+}
+#else
 __global__ __launch_bounds__(64, RT_DIRECT_LB) void k_direct_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY)
 {
   extern __shared__ uint2 s_stack[];
@@ -77,82 +277,21 @@ __global__ __launch_bounds__(64, RT_DIRECT_LB) void k_direct_stage(DevScene S, D
 
   Ctx c(S, st, cam, s_stack + lane);
   c.imageCoords = px;
-  const size_t index = size_t(px.y) * st.size.x + px.x;
   c.seed = tea(uint32_t(st.size.x) * uint32_t(px.y) + uint32_t(px.x), st.time);  // :279
   const Ray r = c.raySpawn(px, i2{st.size.x, st.size.y});
-
-  f3 radiance;
-  const bool spatial = st.ReSTIRState == RT_RESTIR_SPATIAL || st.ReSTIRState == RT_RESTIR_SPATIOTEMPORAL;
-  bool deferred = false;
   c.ClosestHit(r);
-  if(c.hit.t >= RT_INFINITY) {  // :155-159
-    F.thisG[index] = make_uint4(rt_f2u(RT_INFINITY), 0u, 0u, RT_INVALID_MAT_ID);
-    storeMotion(F, px, i2{0, 0});
-    radiance = c.EnvRadiance(r.direction);
-  } else {
-    State state = c.GetState(r.direction);
-    c.GetMaterials(state, r);
-    const i2 motionIdx = createMotionIndex(c, state.position);
-    const uint4 gInfo = encodeGeometryInfo(state, c.hit.t);
-    storeMotion(F, px, motionIdx);
-    F.thisG[index] = gInfo;
-
-    if(st.debugging_mode > RT_DBG_INDIRECT_STAGE) radiance = c.DebugInfo(state);
-    else if(state.isEmitter) radiance = state.mat.emission;
-    else {
-      const f3 wo = -r.direction;
-      f3 direct = mk3(0.0f);
-      state.mat.albedo = mk3(1.0f);
-      if(st.ReSTIRState == RT_RESTIR_NONE) direct = c.DirectLight(state, wo);
-      else {
-        rt_direct_reservoir resv = zeroDirectResv();
-        uint32_t lid = 0xffffffffu;
-        risCandidates(c, state, wo, resv, lid);
-        if(st.ReSTIRState == RT_RESTIR_TEMPORAL || st.ReSTIRState == RT_RESTIR_SPATIOTEMPORAL) {
-          const float reprojDepth = length(mk3(cam.lastPosition) - state.position);
-          rt_direct_reservoir temporal; uint32_t tlid = 0xffffffffu;
-          if(findTemporalNeighborDirect(F, st, state.normal, reprojDepth, state.matID, motionIdx, temporal, tlid)) {
-            if(!resvInvalidW(temporal.weight)) { if(resvMerge(resv, temporal, rnd(c.seed))) lid = tlid; }
-          }
-        }
-        rt_direct_reservoir tempResv = resv;
-        if(resvInvalidW(tempResv.weight)) { tempResv.num = 0; tempResv.weight = 0.f; }
-        resvClamp(tempResv, st.RISSampleNum * st.reservoirClamp);
-        F.thisDirectResv[index] = tempResv;  // saveNewReservoir
-        F.thisLightId[index] = lid;
-        if(spatial) {
-          // Spatial / spatiotemporal reuse (:224-255) reads the reservoirs its neighbours cache here.  The reference orders
-          // that with workgroup barriers only (neighbours in other workgroups race); this build finishes the pixel in a
-          // second kernel (k_direct_spatial) once every pixel of the launch has cached its reservoir.
-          if(resvInvalidW(resv.weight)) { resv.num = 0; resv.weight = 0.f; }  // resvCheckValidity(resv) :231
-          F.tempDirectResv[index] = resv;                                      // cacheTempReservoir :234
-          SurfRec sr;
-          sr.position = toR(state.position); sr.normal = toR(state.normal); sr.ffnormal = toR(state.ffnormal); sr.emission = toR(state.mat.emission);
-          sr.roughness = state.mat.roughness; sr.metallic = state.mat.metallic; sr.matID = state.matID; sr.seed = c.seed;
-          F.surf[index] = sr;
-          deferred = true;
-        } else {
-          const rt_light_sample ls = resv.lightSample;
-          if(!resvInvalidW(resv.weight)) {
-            f3 LiBsdf = mk3(ls.Li) * metallicWorkflowBSDF(state.mat, state.ffnormal, wo, mk3(ls.wi));
-            direct = LiBsdf / resvToScalar(LiBsdf) * resv.weight / float(resv.num);
-          }
-        }
-      }
-      if(rt_isnan(direct.x) || rt_isnan(direct.y) || rt_isnan(direct.z)) direct = mk3(0.0f);
-      radiance = HDRToLDR(c.clampRadiance(state.mat.emission + direct));
-    }
-  }
-  if(spatial) F.status[index] = deferred ? 1u : 0u;
-  if(!deferred) {
-    const f3 pixelColor = c.clampRadiance(radiance);
-    storeImg(F.thisDirectResult, F, px, mk4(pixelColor, 1.0f));  // :286
-  }
+  DirectCont K;
+  Ray shadowRay{mk3(0.0f), mk3(0.0f)};
+  float shadowDist = 0.0f;
+  const bool wantShadow = directPre(c, F, st, px, r, K, shadowRay, shadowDist);
+  const bool occluded = wantShadow && c.AnyHit(shadowRay, shadowDist);
+  directPost(c, F, st, cam, px, K, occluded);
   flushCounters(F, c);
 #if RT_WAVEPROF
   waveProfFlush(F, c, tile.x, tile.y, prof_c0, prof_w0);
 #endif
 }
+#endif
 
 #if !RT_LAT
 // Second half of direct_stage.comp's ReSTIRDirect for the spatial modes (:86-121, 236-262): two rounds of five neighbour
@@ -235,6 +374,7 @@ __global__ __launch_bounds__(64) void k_direct_spatial(DevScene S, DevFrame F, r
 // ------------------------------------------------------------------------------------------------------------
 // direct_gen.comp / direct_reuse.comp
 // ------------------------------------------------------------------------------------------------------------
+#if !RT_LAT
 __global__ __launch_bounds__(64) void k_direct_gen(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY)
 {
   extern __shared__ uint2 s_stack[];
@@ -274,7 +414,6 @@ __global__ __launch_bounds__(64) void k_direct_gen(DevScene S, DevFrame F, rt_st
   flushCounters(F, c);
 }
 
-#if !RT_LAT
 __global__ __launch_bounds__(64) void k_direct_reuse(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY)
 {
   const TileCoord tile = tileOf(tilesX, tilesY);
@@ -399,6 +538,7 @@ RT_DEV void restirIndirectFinish(Ctx& c, const DevFrame& F, const rt_state& st, 
   storeImg(F.denoiseIndA, F, px, mk4(pixelColor, 1.0f));
 }
 
+#if !RT_LAT
 // ---- single-bounce tiles, K tiles per wave ----------------------------------------------------------------------------------
 // 75 % of the tiles stop after one bounce + one NEE shadow ray (TILED_MULTIBOUNCE, :283-288): per path one closest-hit ray,
 // then at most one any-hit ray.  With one tile per wave the ray pool holds fewer rays than the wave has lanes (sky pixels,
@@ -511,17 +651,22 @@ RT_DEV void indirectSingleBounceTiles(const DevScene& S, const DevFrame& F, cons
   flushCounters(F, c);
 }
 
+#endif  // !RT_LAT
+
 // 5 waves/SIMD (96 VGPRs, a few more spills) instead of 4: the stage alone is no faster, but with frames in flight its waves
 // share the SIMDs with the next frame's direct stage and the frame is 2.7 % shorter (3, 4, 6 measured: 3.96 / 3.47 / 3.42 vs 3.37 ms)
 #ifndef RT_INDIRECT_LB
-#if RT_LAT
-#define RT_INDIRECT_LB 2
-#else
 #define RT_INDIRECT_LB 5
 #endif
-#endif
+#if RT_LAT
+// latency build: a workgroup of NW waves per half-res tile; wave 0 runs the paths of the 64 pixels (the body below), the other waves only serve the
+// workgroup's ray pool: after every path vertex wave 0 lists the vertex's rays, all waves trace them eight lanes per ray, wave 0 goes on shading
+__global__ __launch_bounds__(512, 2) void k_indirect_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY, int cap,
+                                                       const uint32_t* lists, const uint32_t* counts, int subShift, int sbK, int genericBlocks)
+#else
 __global__ __launch_bounds__(64, RT_INDIRECT_LB) void k_indirect_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY, int cap,
                                                           const uint32_t* lists, const uint32_t* counts, int subShift, int sbK, int genericBlocks)
+#endif
 {
   // subShift > 0 (small launches: row bands of a multi-GPU frame, small images): a tile is split over 2 or 4 waves that own
   // 32 / 16 of its pixels each; the other lanes of each wave have no path and only serve the wave's ray pool.  With fewer
@@ -536,6 +681,7 @@ __global__ __launch_bounds__(64, RT_INDIRECT_LB) void k_indirect_stage(DevScene 
   {
     const int L = int(blockIdx.x), xcd = L & 7;
     const int nf = int(counts[xcd * 2]), nb = int(counts[xcd * 2 + 1]);
+#if !RT_LAT
     if(sbK > 0 && L >= genericBlocks) {  // single-bounce tiles of this XCD, sbK per wave (from the back of its list)
       const int w = (L - genericBlocks) >> 3, first = w * sbK;
       if(first >= nb) return;
@@ -546,18 +692,36 @@ __global__ __launch_bounds__(64, RT_INDIRECT_LB) void k_indirect_stage(DevScene 
       else indirectSingleBounceTiles<2>(S, F, st, cam, rowBegin, rowEnd, tilesX, t, n, s_stack);  // (4 per wave was measured: slower, spills)
       return;
     }
+#endif
     const int k = (L >> 3) >> subShift;
     tile.valid = sbK > 0 ? (k < nf) : (k < nf + nb);
     const uint32_t t = tile.valid ? lists[size_t(xcd) * cap + (k < nf ? k : cap - 1 - (k - nf))] : 0u;
     tile.y = int(t) / tilesX; tile.x = int(t) - tile.y * tilesX;
   }
   if(!tile.valid) return;
+#if RT_LAT
+  const WideLds WL = wideLds(s_stack, S.stackEntries, int(blockDim.x) >> 6);
+  if((int(threadIdx.x) >> 6) != 0) {   // helper waves: trace whatever wave 0 lists until it says it is done
+    TravCounters htc{};
+    for(;;) {
+      __syncthreads();
+      if(WL.ctrl[2] != 0u) break;
+      tracePoolWide(S, WL.pool, WL.list, int(WL.ctrl[0]), &WL.ctrl[1], WL.stacks + size_t(int(threadIdx.x) >> 6) * S.stackEntries * WIDE_RAYS, htc);
+      __syncthreads();
+    }
+    return;
+  }
+#endif
   const int lane = int(threadIdx.x);
   const i2 indSize{st.size.x / 2, st.size.y / 2};
   const int rowsPerPart = 8 >> subShift;
   const bool hasPixel = (lane >> 3) < rowsPerPart;
   const i2 px{tile.x * 8 + (lane & 7), rowBegin + tile.y * 8 + part * rowsPerPart + (lane >> 3)};
+#if RT_LAT
+  Ctx c(S, st, cam, nullptr);
+#else
   Ctx c(S, st, cam, s_stack + lane);
+#endif
   c.imageCoords = px;
   c.seed = tea(uint32_t(indSize.x) * uint32_t(px.y) + uint32_t(px.x), st.time);  // :280
   // TILED_MULTIBOUNCE (:283-288): invocation 0 of the workgroup draws the tile flag from its own stream (and so advances
@@ -570,7 +734,11 @@ __global__ __launch_bounds__(64, RT_INDIRECT_LB) void k_indirect_stage(DevScene 
   }
   const bool multiBounce = __builtin_amdgcn_readfirstlane(mb) != 0;
   // Lanes without a pixel / without a surface stay in the kernel: they trace rays of the other lanes (tracePool).
+#if RT_LAT
+  float4* pool = WL.pool;
+#else
   float4* pool = reinterpret_cast<float4*>(s_stack + size_t(S.stackEntries) * 64);
+#endif
   const bool inImage = hasPixel && !(px.x >= indSize.x || px.y >= indSize.y || px.y >= rowEnd);
   Ray ray = c.raySpawn(px, indSize);
 
@@ -632,7 +800,12 @@ __global__ __launch_bounds__(64, RT_INDIRECT_LB) void k_indirect_stage(DevScene 
       }
     }
     if(__ballot((hasShadow || hasBounce) ? 1 : 0) == 0ull) break;  // wave-uniform
+#if RT_LAT
+    poolPublish(WL, hasBounce, hasShadow);
+    groupTrace(S, WL, c.tc);
+#else
     tracePool(S, pool, hasBounce, hasShadow, c.stack, c.tc);
+#endif
     if(hasShadow && poolGet(pool, lane * 2 + 1).gid == 0xffffffffu) gi.L = toR(mk3(gi.L) + pendingAdd);  // not occluded
     if(hasBounce) {
       c.hit = poolGet(pool, lane * 2);
@@ -666,6 +839,10 @@ __global__ __launch_bounds__(64, RT_INDIRECT_LB) void k_indirect_stage(DevScene 
     }
     // Russian roulette (:218-224) is compiled out in the reference (`#ifndef RR`, pathtrace.glsl:2)
   }
+#if RT_LAT
+  if(lane == 0) WL.ctrl[2] = 1u;   // release the helper waves
+  __syncthreads();
+#endif
 #if RT_WAVEPROF
   waveProfFlush(F, c, tile.x | (multiBounce ? 0x10000 : 0), tile.y, prof_c0, prof_w0);
 #endif
@@ -999,11 +1176,17 @@ hipError_t launchStage(hipStream_t stream, const DevScene& Sin, const DevFrame& 
                        int rowBegin, int rowEnd)
 {
 #if RT_LAT
-  // only the traced kernels exist in this build
-  if(stage != RT_STAGE_DIRECT && stage != RT_STAGE_DIRECT_GEN && stage != RT_STAGE_INDIRECT) return rt::RT_FORWARD::launchStage(stream, Sin, F, st, cam, stage, level, rowBegin, rowEnd);
+  // only two kernels exist in this build
+  if(stage != RT_STAGE_DIRECT && stage != RT_STAGE_INDIRECT) return rt::RT_FORWARD::launchStage(stream, Sin, F, st, cam, stage, level, rowBegin, rowEnd);
 #endif
   DevScene S = Sin;
+#if RT_LAT
+  S.stackEntries = S.stackTotal;   // one column per RAY (8 per wave): the whole stack fits in LDS
+  static const int nwEnv = getenv("RESTIR_LAT_WAVES") ? std::max(1, std::min(8, atoi(getenv("RESTIR_LAT_WAVES")))) : 8;
+  const int nWaves = nwEnv;        // waves per tile workgroup
+#else
   S.stackEntries = F.stackLds > 0 ? std::min(F.stackLds, S.stackTotal) : S.stackTotal;   // LDS part of the traversal stack for this launch
+#endif
   if(stage == RT_STAGE_INDIRECT) S.stackOvf = Sin.stackOvfInd;   // a direct-kind kernel of the next frame can be in flight beside it
   const bool needOvf = S.stackTotal > S.stackEntries;
   const bool half = (stage == RT_STAGE_INDIRECT || stage == RT_STAGE_DENOISE_INDIRECT);
@@ -1023,24 +1206,30 @@ hipError_t launchStage(hipStream_t stream, const DevScene& Sin, const DevFrame& 
       // `level` selects the halves of the stage for hosts that must exchange the cached reservoirs of neighbouring rows in between
       // (row-tiled multi-GPU frames with spatial reuse): 0 = the whole stage, 1 = k_direct_stage only, 2 = k_direct_spatial only
       if(level < 0 || level > 2 || (level != 0 && !spatial)) return hipErrorInvalidValue;
+#if RT_LAT
+      if(level != 2) hipLaunchKernelGGL(k_direct_stage, grid, dim3(64 * nWaves), wideLdsBytes(S.stackEntries, nWaves), stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY);
+      if(level != 1 && spatial) return rt::RT_FORWARD::launchStage(stream, Sin, F, st, cam, stage, 2, rowBegin, rowEnd);
+#else
       if(needOvf && grid.x * 64u > S.stackOvfThreads) return hipErrorInvalidValue;
       if(level != 2) hipLaunchKernelGGL(k_direct_stage, grid, block, lds, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY);
-      if(level != 1 && spatial) {
-#if RT_LAT
-        return rt::RT_FORWARD::launchStage(stream, Sin, F, st, cam, stage, 2, rowBegin, rowEnd);
-#else
-        hipLaunchKernelGGL(k_direct_spatial, grid, block, 0, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY);
+      if(level != 1 && spatial) hipLaunchKernelGGL(k_direct_spatial, grid, block, 0, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY);
 #endif
-      }
       break;
+#if !RT_LAT
     case RT_STAGE_DIRECT_GEN:
       if(needOvf && grid.x * 64u > S.stackOvfThreads) return hipErrorInvalidValue;
       hipLaunchKernelGGL(k_direct_gen, grid, block, lds, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY);
       break;
+#endif
     case RT_STAGE_INDIRECT: {
       // per-XCD tile lists: capacity = the tiles one XCD can own under the striped mapping
       const int cap = int(tileGrid(tilesX, tilesY) / 8);
       hipLaunchKernelGGL(k_ind_tile_order, dim3(8), dim3(256), 0, stream, st, rowBegin, tilesX, tilesY, cap, F.tileOrder, F.qcount + 192);
+#if RT_LAT
+      // one workgroup per tile, multi-bounce tiles first (same lists)
+      hipLaunchKernelGGL(k_indirect_stage, grid, dim3(64 * nWaves), wideLdsBytes(S.stackEntries, nWaves), stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY, cap,
+                         (const uint32_t*)F.tileOrder, (const uint32_t*)(F.qcount + 192), 0, 0, int(grid.x));
+#else
       // under ~2 waves per SIMD (1024 SIMDs) the launch is latency bound: split tiles over more waves
       static const int subEnv = getenv("RESTIR_IND_SUB") ? atoi(getenv("RESTIR_IND_SUB")) : -1;
       const int nTiles = tilesX * tilesY;
@@ -1054,6 +1243,7 @@ hipError_t launchStage(hipStream_t stream, const DevScene& Sin, const DevFrame& 
       if(needOvf && (genericBlocks + sbBlocks) * 64u > S.stackOvfThreads) return hipErrorInvalidValue;
       hipLaunchKernelGGL(k_indirect_stage, dim3(genericBlocks + sbBlocks), block, lds + poolBytes, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY, cap,
                          (const uint32_t*)F.tileOrder, (const uint32_t*)(F.qcount + 192), subShift, sbK, int(genericBlocks));
+#endif
       break;
     }
 #if !RT_LAT

@@ -519,96 +519,6 @@ RT_DEV bool travRoundMasked(const DevScene& S, Trav& T, bool live, unsigned long
   return live && (travHasTris(T) || travHasNodes(T));
 }
 
-// ---- latency-mode round (RT_LAT = 1: the traced kernels of SMALL launches, csrc/stages_lat.hip) -----------------------------------------------------
-// A row band of a multi-GPU frame (or a small image) puts about one wave on a SIMD: nothing hides a memory access, and the launch takes what its
-// slowest wave takes — measured on the horizon bands of the benchmark frame (profiles/r03a_wave_profile_baseline.txt): 3000 cycles per node round, 5500
-// per triangle round (record -> AlphaRec -> texels: three dependent accesses whenever one lane of the wave meets an unresolved alpha candidate), and
-// 544 majority-vote rounds for a lane maximum of 337 steps.  Issue slots and registers are free in that regime, dependent accesses are what costs.
-// So this round does for EVERY live ray, every round:
-//   1. pick the next node and issue its five loads (nothing waits for them yet),
-//   2. work off ALL pending triangles of the current leaf group, two records per lane and iteration in one burst; the candidates that need the
-//      texture resolve together afterwards (their AlphaRecs in one burst, then all texels in one burst),
-//   3. test the node's children with the bound the triangles just tightened.
-// A wave then runs as many rounds as its slowest ray visits nodes, with one memory latency per round for node + triangle records.  Verdicts are
-// functions of (ray, triangle) and the closest hit is a minimum over (t, id): the order of the steps does not change a bit of the result.
-#ifndef RT_LAT
-#define RT_LAT 0
-#endif
-#if RT_LAT
-RT_DEV void latAccept(Trav& T, bool ANY, float t, float u, float v, uint32_t gid)
-{
-  T.hit.t = t; T.hit.gid = gid; T.hit.u = u; T.hit.v = v;
-  T.found = true;
-  if(ANY) { T.tgroup.y = 0u; T.ngroup.y = 0u; T.sp = 0; }  // first accepted hit terminates the query
-}
-RT_DEV bool latCloser(const Trav& T, bool ANY, float t, uint32_t gid) { return ANY || t < T.hit.t || (t == T.hit.t && gid < T.hit.gid); }
-
-template <int MODE>
-RT_DEV void travTriBurst(const DevScene& S, Trav& T, TravCounters& tc)
-{
-  const bool ANY = MODE == 2 ? T.isAny : MODE == 1;
-  uint32_t bits = T.tgroup.y;
-  const uint32_t b0 = 31u - uint32_t(__clz(int(bits)));
-  bits &= ~(1u << b0);
-  const bool has1 = bits != 0u;
-  const uint32_t b1 = has1 ? 31u - uint32_t(__clz(int(bits))) : b0;   // no second triangle: the same record again (same cache line, result unused)
-  bits &= ~(1u << b1);
-  T.tgroup.y = bits;
-  const TriRegs Q0 = triLoad(S, T.tgroup.x + b0), Q1 = triLoad(S, T.tgroup.x + b1);
-  tc.tris += has1 ? 2u : 1u;
-  float t0, u0, v0, t1 = 0.f, u1 = 0.f, v1 = 0.f; uint32_t g0, g1 = 0u, a0, a1 = 0u;
-  const int s0 = triCandidateGeom(S, Q0, T.o, T.d, ANY, T.tmax, T.hit.t, T.hit.gid, T.seed, t0, u0, v0, g0, a0, tc);
-  if(s0 == 1) latAccept(T, ANY, t0, u0, v0, g0);
-  int s1 = 0;
-  if(has1 && !(ANY && T.found)) {
-    s1 = triCandidateGeom(S, Q1, T.o, T.d, ANY, T.tmax, T.hit.t, T.hit.gid, T.seed, t1, u1, v1, g1, a1, tc);
-    if(s1 == 1) latAccept(T, ANY, t1, u1, v1, g1);
-  }
-  bool q0 = s0 == 2, q1 = s1 == 2;
-  if(ANY && T.found) { q0 = false; q1 = false; }
-  if(q0 || q1) {
-    const uint8_t* safe = reinterpret_cast<const uint8_t*>(S.alphaRec);
-    const AlphaRegs A0 = alphaLoad(S, q0 ? a0 : 0u), A1 = alphaLoad(S, q1 ? a1 : 0u);   // record 0 is a dummy without a texture
-    const AlphaFetch F0 = alphaAddr(A0, u0, v0, safe), F1 = alphaAddr(A1, u1, v1, safe);
-    const uint8_t x00 = *F0.p00, x10 = *F0.p10, x01 = *F0.p01, x11 = *F0.p11, y00 = *F1.p00, y10 = *F1.p10, y01 = *F1.p01, y11 = *F1.p11;
-    if(q0 && latCloser(T, ANY, t0, g0) && alphaFinish(A0, F0, x00, x10, x01, x11, g0, T.seed)) latAccept(T, ANY, t0, u0, v0, g0);
-    if(q1 && !(ANY && T.found) && latCloser(T, ANY, t1, g1) && alphaFinish(A1, F1, y00, y10, y01, y11, g1, T.seed)) latAccept(T, ANY, t1, u1, v1, g1);
-  }
-}
-
-template <int MODE>
-RT_DEV bool travRoundLat(const DevScene& S, Trav& T, bool live, uint2* stack, TravCounters& tc)
-{
-  const bool ANY = MODE == 2 ? T.isAny : MODE == 1;
-  tc.rounds++; tc.live += live ? 1u : 0u;
-#if RT_WAVEPROF
-  const uint64_t c0 = clock64();
-#endif
-  // 1. the node this ray visits next: fetched now, tested after the triangles
-  const bool sel = live && travHasNodes(T);
-  NodeRegs N{};
-  if(sel) { N = nodeLoad(S, travNodeSelect(S, T, stack)); tc.nodes++; }
-  // 2. every pending triangle of every ray
-  bool wantTri = live && travHasTris(T);
-#if RT_WAVEPROF
-  uint32_t it = 0;
-#endif
-  while(__ballot(wantTri ? 1 : 0) != 0ull) {
-    if(wantTri) travTriBurst<MODE>(S, T, tc);
-    wantTri = live && travHasTris(T);
-#if RT_WAVEPROF
-    it++;
-#endif
-  }
-  // 3. the node's children against the tightened bound (an any-hit ray that found its hit is done)
-  if(sel && !(ANY && T.found)) travNodeTest(T, N);
-#if RT_WAVEPROF
-  { const uint32_t dc = uint32_t(clock64() - c0); tc.rN++; tc.cN += dc; tc.rT += it; }
-#endif
-  return live && (travHasTris(T) || travHasNodes(T));
-}
-#endif  // RT_LAT
-
 template <int ANY>
 RT_DEV bool traceRay(const DevScene& S, f3 o, f3 d, float tmax, uint32_t raySeed, uint2* stack, RayHit& hit, TravCounters& tc)
 {
@@ -618,11 +528,7 @@ RT_DEV bool traceRay(const DevScene& S, f3 o, f3 d, float tmax, uint32_t raySeed
   // (travRound with its ballots shared between the vote and the loop condition: two per round instead of three)
   unsigned long long liveMask = __ballot(live ? 1 : 0);
   while(liveMask != 0ull) {
-#if RT_LAT
-    live = travRoundLat<ANY>(S, T, live, stack, tc);
-#else
     live = travRoundMasked<ANY>(S, T, live, liveMask, stack, tc);
-#endif
     liveMask = __ballot(live ? 1 : 0);
   }
   hit = T.hit;
@@ -686,11 +592,7 @@ RT_DEV void tracePool(const DevScene& S, float4* pool, bool hasC, bool hasS, uin
       if(next >= n) break;
       continue;
     }
-#if RT_LAT
-    const bool still = travRoundLat<2>(S, T, live, stack, tc);
-#else
     const bool still = travRoundMasked<2>(S, T, live, liveMask, stack, tc);
-#endif
     if(live && !still) pool[mySlot * POOL_SLOT_F4] = make_float4(T.hit.t, rt_u2f(T.hit.gid), T.hit.u, T.hit.v);
     live = still;
   }
@@ -737,15 +639,205 @@ RT_DEV void tracePoolTiles(const DevScene& S, float4* pool, uint32_t have /* bit
       if(next >= n) break;
       continue;
     }
-#if RT_LAT
-    const bool still = travRoundLat<ANY>(S, T, live, stack, tc);
-#else
     const bool still = travRoundMasked<ANY>(S, T, live, liveMask, stack, tc);
-#endif
     if(live && !still) pool[mySlot * POOL_SLOT_F4] = make_float4(T.hit.t, rt_u2f(T.hit.gid), T.hit.u, T.hit.v);
     live = still;
   }
   waveLdsSync();
 }
+
+// ---- latency-mode traversal: eight lanes per ray (RT_LAT = 1: the traced kernels of SMALL launches, csrc/stages_lat.hip) ------------------------------
+// A row band of a multi-GPU frame (or a small image) puts about one wave on a SIMD, and its launch takes what its slowest wave takes.  Measured on the
+// horizon bands of the benchmark frame (profiles/r03a_wave_profile_baseline.txt, profiles/r03_lat_narrow_band_ab.txt): a wave64 instruction costs its
+// wave ~4 cycles however empty the SIMD is, so a ray's chain is (node steps + triangle steps) x (memory latency + the step's OWN instruction time), and
+// with one ray per lane a node step is 230 instructions, a triangle step 170 per triangle — while 1000 SIMDs idle.  Here a ray owns EIGHT lanes:
+//   * node step: all eight lanes fetch the node (one request), lane j decodes and slab-tests child j, the hit bits are OR-ed with three DPP moves
+//     (~70 instructions instead of 230);
+//   * triangle step: lane j tests the j-th pending triangle of the leaf group (8 at a time, each with its own alpha chain), the closest accepted candidate
+//     is the minimum of (t, id) over the group (three DPP exchange steps);
+//   * the ray's state is replicated in its eight lanes, its stack is one column in LDS.
+// A wave carries 8 rays; the waves of a workgroup share an LDS ray pool and pull rays group by group as theirs finish (tracePoolWide).  Verdicts are functions
+// of (ray, triangle) and the closest hit is a minimum over (t, id), so the result is bit-identical to the one-lane-per-ray traversal.
+#ifndef RT_LAT
+#define RT_LAT 0
+#endif
+#if RT_LAT
+constexpr int WIDE_G = 8;            // lanes per ray
+constexpr int WIDE_RAYS = 64 / WIDE_G;  // rays per wave = stack columns per wave
+// DPP controls (gfx9): quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror (lane i <-> 7 - i inside each group of eight)
+#define RT_DPP_XOR1 0xB1
+#define RT_DPP_XOR2 0x4E
+#define RT_DPP_HALF_MIRROR 0x141
+template <int CTRL> RT_DEV uint32_t dppU(uint32_t v) { return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), CTRL, 0xf, 0xf, true)); }
+template <int CTRL> RT_DEV float dppF(float v) { return rt_u2f(dppU<CTRL>(rt_f2u(v))); }
+// OR over the eight lanes of a group (all eight must be active)
+RT_DEV uint32_t groupOr(uint32_t v)
+{
+  v |= dppU<RT_DPP_XOR1>(v);
+  v |= dppU<RT_DPP_XOR2>(v);
+  v |= dppU<RT_DPP_HALF_MIRROR>(v);
+  return v;
+}
+struct WideCand { float t; uint32_t gid; float u, v; };   // t = +inf (IEEE): no candidate
+template <int CTRL> RT_DEV void candMinStep(WideCand& c)
+{
+  const float ot = dppF<CTRL>(c.t); const uint32_t og = dppU<CTRL>(c.gid); const float ou = dppF<CTRL>(c.u), ov = dppF<CTRL>(c.v);
+  const bool take = ot < c.t || (ot == c.t && og < c.gid);
+  c.t = take ? ot : c.t; c.gid = take ? og : c.gid; c.u = take ? ou : c.u; c.v = take ? ov : c.v;
+}
+// lexicographic minimum of (t, gid) over the group, with its (u, v)
+RT_DEV void groupMinCand(WideCand& c) { candMinStep<RT_DPP_XOR1>(c); candMinStep<RT_DPP_XOR2>(c); candMinStep<RT_DPP_HALF_MIRROR>(c); }
+
+// the ray's stack: one 8-byte column per ray, stride WIDE_RAYS entries (every lane of the group reads the same address; lane 0 of the group writes)
+RT_DEV uint2 stackPopW(Trav& T, const uint2* stack) { --T.sp; return stack[T.sp * WIDE_RAYS]; }
+RT_DEV void stackPushW(Trav& T, uint2* stack, uint2 g, int j) { if(j == 0) stack[T.sp * WIDE_RAYS] = g; T.sp++; }
+RT_DEV uint32_t travNodeSelectW(Trav& T, uint2* stack, int j)
+{
+  uint2 ngroup = T.ngroup;
+  if(ngroup.y <= 0x00FFFFFFu) ngroup = stackPopW(T, stack);
+  const uint32_t hits = ngroup.y;
+  const uint32_t bit = 31u - uint32_t(__clz(int(hits)));
+  ngroup.y &= ~(1u << bit);
+  if(ngroup.y > 0x00FFFFFFu) stackPushW(T, stack, ngroup, j);
+  const uint32_t slot = (bit - 24u) ^ T.octinv;
+  const uint32_t rel = uint32_t(__popc(hits & ~(0xFFFFFFFFu << slot) & 0xFFu));
+  T.ngroup.y = 0u;
+  return ngroup.x + rel;
+}
+RT_DEV uint32_t byteOf(uint32_t lo, uint32_t hi, int j) { return ((j < 4 ? lo : hi) >> (8 * (j & 3))) & 0xffu; }
+// lane j of the group tests child j of the fetched node (the arithmetic of travNodeTest for that child)
+RT_DEV void travNodeTestW(Trav& T, const NodeRegs& N, int j)
+{
+  const uint4 n0 = N.n0, n1 = N.n1, n2 = N.n2, n3 = N.n3, n4 = N.n4;
+  const bool nx = T.d.x < 0.0f, ny = T.d.y < 0.0f, nz = T.d.z < 0.0f;
+  const float adjx = rt_u2f((n0.w & 0xffu) << 23) * T.idx;
+  const float adjy = rt_u2f(((n0.w >> 8) & 0xffu) << 23) * T.idy;
+  const float adjz = rt_u2f(((n0.w >> 16) & 0xffu) << 23) * T.idz;
+  const float orgx = (rt_u2f(n0.x) - T.o.x) * T.idx, orgy = (rt_u2f(n0.y) - T.o.y) * T.idy, orgz = (rt_u2f(n0.z) - T.o.z) * T.idz;
+  const uint32_t imask = n0.w >> 24;
+  const uint32_t meta = byteOf(n1.z, n1.w, j);
+  const uint32_t isInner = (meta & (meta << 1)) & 0x10u;
+  const uint32_t bitIndex = (meta ^ (isInner ? T.octinv : 0u)) & 0x1Fu;
+  const uint32_t childBits = (meta >> 5) & 0x07u;
+  const float qlx = float(byteOf(n2.x, n2.y, j)), qly = float(byteOf(n2.z, n2.w, j)), qlz = float(byteOf(n3.x, n3.y, j));
+  const float qhx = float(byteOf(n3.z, n3.w, j)), qhy = float(byteOf(n4.x, n4.y, j)), qhz = float(byteOf(n4.z, n4.w, j));
+  const float tlx = __builtin_fmaf(nx ? qhx : qlx, adjx, orgx), thx = __builtin_fmaf(nx ? qlx : qhx, adjx, orgx);
+  const float tly = __builtin_fmaf(ny ? qhy : qly, adjy, orgy), thy = __builtin_fmaf(ny ? qly : qhy, adjy, orgy);
+  const float tlz = __builtin_fmaf(nz ? qhz : qlz, adjz, orgz), thz = __builtin_fmaf(nz ? qlz : qhz, adjz, orgz);
+  const float tn = fmaxf(fmaxf(tlx, tly), fmaxf(tlz, 0.0f));
+  const float tf = fminf(fminf(thx, thy), fminf(thz, T.hit.t));
+  const uint32_t hitmask = groupOr((tn <= tf) ? (childBits << bitIndex) : 0u);
+  T.ngroup = make_uint2(n1.x, (hitmask & 0xFF000000u) | imask);
+  T.tgroup = make_uint2(n1.y, hitmask & 0x00FFFFFFu);
+}
+// lane j tests the j-th pending triangle (list order: highest bit first); up to eight per step, the rest stay pending
+template <int MODE>
+RT_DEV void travTriW(const DevScene& S, Trav& T, int j, TravCounters& tc)
+{
+  const bool ANY = MODE == 2 ? T.isAny : MODE == 1;
+  uint32_t rem = T.tgroup.y;
+  int mine = -1;
+#pragma unroll
+  for(int k = 0; k < WIDE_G; k++) {
+    if(rem != 0u) {
+      const int b = 31 - __clz(int(rem));
+      if(k == j) mine = b;
+      rem &= ~(1u << b);
+    }
+  }
+  T.tgroup.y = rem;
+  WideCand c; c.t = __builtin_huge_valf(); c.gid = 0xffffffffu; c.u = 0.0f; c.v = 0.0f;
+  bool ok = false;
+  if(mine >= 0) {
+    float t, u, v; uint32_t gid, alphaIdx;
+    const uint32_t ti = T.tgroup.x + uint32_t(mine);
+    const TriRegs Q = triLoad(S, ti);
+    const uint4* ap = reinterpret_cast<const uint4*>(S.alphaByTri + ti);   // fetched with the record, whether needed or not: no second dependent access
+    AlphaRegs A; A.r0 = ap[0]; A.r1 = ap[1]; A.r2 = ap[2]; A.r3 = ap[3];
+    const int s = triCandidateGeom(S, Q, T.o, T.d, ANY, T.tmax, T.hit.t, T.hit.gid, T.seed, t, u, v, gid, alphaIdx, tc);
+    ok = s == 1;
+    if(s == 2) {
+      const AlphaFetch Fh = alphaAddr(A, u, v, reinterpret_cast<const uint8_t*>(S.alphaRec));
+      uint8_t a00 = 0, a10 = 0, a01 = 0, a11 = 0;
+      if(Fh.kind == 1) a00 = *Fh.p00;
+      else if(Fh.kind == 2) { a00 = *Fh.p00; a10 = *Fh.p10; a01 = *Fh.p01; a11 = *Fh.p11; }
+      ok = alphaFinish(A, Fh, a00, a10, a01, a11, gid, T.seed);
+    }
+    if(ok) { c.t = t; c.gid = gid; c.u = u; c.v = v; }
+  }
+  // (all eight lanes of the group are back together here)
+  groupMinCand(c);
+  const bool any = c.t < __builtin_huge_valf();   // an accepted candidate has a finite t
+  if(any && (ANY || c.t < T.hit.t || (c.t == T.hit.t && c.gid < T.hit.gid))) {
+    T.hit.t = c.t; T.hit.gid = c.gid; T.hit.u = c.u; T.hit.v = c.v;
+    T.found = true;
+    if(ANY) { T.tgroup.y = 0u; T.ngroup.y = 0u; T.sp = 0; }
+  }
+  (void)ok;
+}
+// one round of a wave: every group advances its ray — a triangle step if the ray has pending triangles, a node step otherwise; node fetches are issued
+// before the triangle work of the other groups
+template <int MODE>
+RT_DEV bool travRoundW(const DevScene& S, Trav& T, bool live, int j, uint2* stack, TravCounters& tc)
+{
+  const bool wantTri = live && travHasTris(T);
+  const bool wantNode = live && !wantTri;
+  NodeRegs N{};
+  if(wantNode) N = nodeLoad(S, travNodeSelectW(T, stack, j));
+  if(wantTri) travTriW<MODE>(S, T, j, tc);
+  if(wantNode) travNodeTestW(T, N, j);
+  return live && (travHasTris(T) || travHasNodes(T));
+}
+
+// ---- workgroup-wide ray pool ------------------------------------------------------------------------------------------------------------------------
+// Rays wait in LDS slots (poolPut: ray in, hit out, 32 B), `list` holds the n occupied slot ids (kind of the ray in bit 7: any-hit), *next is the shared cursor.
+// EVERY wave of the workgroup calls this between two workgroup barriers; a wave serves up to eight rays at a time and refills group by group.
+RT_DEV void tracePoolWide(const DevScene& S, float4* pool, const unsigned char* list, int n, uint32_t* next, uint2* waveStack, TravCounters& tc)
+{
+  const int lane = int(threadIdx.x) & 63, j = lane & (WIDE_G - 1), r = lane >> 3;
+  uint2* stack = waveStack + r;
+  const unsigned long long leaders = 0x0101010101010101ull;
+  const unsigned long long below = (1ull << (lane & ~(WIDE_G - 1))) - 1ull;   // lanes of lower groups
+  bool live = false, exhausted = n == 0;
+  int mySlot = 0;
+  Trav T;
+  T.isAny = false;
+  for(;;) {
+    unsigned long long liveMask = __ballot(live ? 1 : 0);
+    const unsigned long long idle = ~liveMask & leaders;
+    if(!exhausted && idle != 0ull) {
+      const int nIdle = __popcll(idle);
+      uint32_t base = 0u;
+      if(lane == 0) base = atomicAdd(next, uint32_t(nIdle));
+      base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
+      const int item = int(base) + __popcll(idle & below);
+      if(!live && item < n) {
+        const uint32_t e = list[item];
+        mySlot = int(e & 0x7fu);
+        const float4 a = pool[mySlot * POOL_SLOT_F4], b = pool[mySlot * POOL_SLOT_F4 + 1];
+        T.isAny = (e & 0x80u) != 0u;
+        live = travInit<2>(T, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), b.z, rt_f2u(b.w));
+        if(!live && j == 0) pool[mySlot * POOL_SLOT_F4] = make_float4(T.hit.t, rt_u2f(T.hit.gid), T.hit.u, T.hit.v);
+      }
+      if(int(base) + nIdle >= n) exhausted = true;
+      liveMask = __ballot(live ? 1 : 0);
+    }
+    if(liveMask == 0ull) {
+      if(exhausted) break;
+      continue;
+    }
+#if RT_WAVEPROF
+    const uint64_t pc0 = clock64();
+    const bool anyTri = __ballot((live && travHasTris(T)) ? 1 : 0) != 0ull;
+#endif
+    const bool still = travRoundW<2>(S, T, live, j, stack, tc);
+#if RT_WAVEPROF
+    { const uint32_t dc = uint32_t(clock64() - pc0); if(anyTri) { tc.rT++; tc.cT += dc; } else { tc.rN++; tc.cN += dc; } }
+#endif
+    if(live && !still && j == 0) pool[mySlot * POOL_SLOT_F4] = make_float4(T.hit.t, rt_u2f(T.hit.gid), T.hit.u, T.hit.v);
+    live = still;
+  }
+}
+#endif  // RT_LAT
 
 }  // namespace rt

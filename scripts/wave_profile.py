@@ -45,6 +45,25 @@ def timed(fn, n=5):
     r.sync(); return (time.perf_counter() - t0) / n * 1e3
 
 
+def report_wide(name, rec, ms):
+    rec = rec[rec[:, 2] > 0]
+    if len(rec) == 0:
+        print(name, "no records"); return
+    cyc = rec[:, 2].astype(np.float64)
+    ghz = np.median(cyc / np.maximum(1, rec[:, 15]) * 0.1)
+    order = np.argsort(-cyc)
+    us = lambda c: c / ghz / 1e3
+    print(f"== {name} (wide build): launch {ms:.3f} ms, {len(rec)} workgroups, clock {ghz:.2f} GHz, slowest workgroup {us(cyc[order[0]]):.1f} us")
+    print("   slowest workgroups: tile | total us | raygen | primary trace | pre-shadow shading | shadow trace | post | rounds node-only/with-tris (slowest wave) | cycles per round")
+    for i in order[:12]:
+        q = rec[i].astype(np.float64)
+        print(f"   ({int(q[0]):4d},{int(q[1]):3d}) | {us(q[2]):7.1f} | {us(q[7]):5.1f} | {us(q[3]):7.1f} | {us(q[10]):6.1f} | {us(q[4]):7.1f} | {us(q[11]):5.1f} | {int(q[5]):4d}/{int(q[6]):4d} | {q[8] / max(1, q[5]):6.0f}/{q[9] / max(1, q[6]):6.0f}")
+    m = rec.astype(np.float64).mean(axis=0)
+    print(f"   mean workgroup: total {us(m[2]):.1f} us = raygen {us(m[7]):.1f} + primary {us(m[3]):.1f} + pre {us(m[10]):.1f} + shadow {us(m[4]):.1f} + post {us(m[11]):.1f}")
+    pct = np.percentile(cyc, [50, 90, 99, 100])
+    print(f"   workgroup time percentiles (us): p50 {us(pct[0]):.1f} p90 {us(pct[1]):.1f} p99 {us(pct[2]):.1f} max {us(pct[3]):.1f}; sum over workgroups / 512 concurrent = {us(cyc.sum()) / 512 / 1e3:.3f} ms")
+
+
 def report(name, rec, ms):
     rec = rec[rec[:, 2] > 0]
     if len(rec) == 0:
@@ -76,4 +95,4 @@ for (y0, y1) in bands:
         ms = timed(lambda: r.run_stage(st, f, stage, 0, a, b))
         prof()
         r.run_stage(st, f, stage, 0, a, b); r.sync()
-        report(f"{nm} rows {a}..{b}", prof(), ms)
+        (report_wide if (os.environ.get("RESTIR_LAT") == "1" and nm == "direct") else report)(f"{nm} rows {a}..{b}", prof(), ms)
