@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--equal-bands", action="store_true", help="N > 1 (and --emulate-world): equal-height row bands instead of cost-weighted ones")
     ap.add_argument("--band-rounds", type=int, default=8, help="N > 1: planning rounds of the cost-weighted band heights before the warm-up")
     ap.add_argument("--cpu-rows", type=int, default=256, help="height of the row band the CPU baseline renders")
+    ap.add_argument("--no-period", action="store_true", help="--emulate-world: skip the frames-in-flight period pass")
+    ap.add_argument("--period-rounds", type=int, default=4, help="--emulate-world: re-planning rounds of the band heights on the measured per-rank periods")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -343,10 +345,18 @@ def main():
         dist.destroy_process_group()
 
 
+# xGMI model for the emulation (the link time of a pull is not measurable on one device): one link per neighbour, 153.6 GB/s bidirectional per link
+# (task brief / AMD MI355X platform figure) = 76.8 GB/s per direction, of which a DMA copy reaches ~85 %; plus a fixed cost per hipMemcpyPeerAsync
+XGMI_GBS_PER_DIRECTION = 76.8 * 0.85
+XGMI_COPY_LATENCY_US = 8.0
+HALO_KINDS = ["history", "filter", "spatial", "moved", "gather", "fallback"]
+
+
 def emulate_world(args, abi, host, scene, env, st, desc, single, W, H, device):
-    """Per-rank compute of the N-way row-tiled frame on ONE GPU: the native multi-GPU context with every rank on this device and
-    the ranks taking turns (rt_mgpu_set_serialize), so each rank's HIP-event times are those of a GPU to itself.  Exchanges run
-    as device-to-device copies: their volume is reported, their xGMI time is not measured here.  NOT a benchmark result — the
+    """Per-rank compute of the N-way row-tiled frame on ONE GPU with the native multi-GPU context (every rank on this device).
+      serial   the ranks take turns (rt_mgpu_set_serialize): per-rank traced + filter time of a GPU to itself, barrier schedule — the critical path of ONE frame
+      period   frames in flight (rt_mgpu's default schedule), one rank at a time (rt_mgpu_set_solo): wall clock per frame of that rank — the rate an N-GPU node sustains
+    Exchanges run as device-to-device copies: their volume is reported per purpose and priced with the xGMI model above.  NOT a benchmark result — the
     driver measures real scaling; this is the load-balance / critical-path instrument DESIGN.md §7 quotes."""
     from restir_amd.renderer import MultiGpuRenderer
     n = args.emulate_world
@@ -356,7 +366,7 @@ def emulate_world(args, abi, host, scene, env, st, desc, single, W, H, device):
         st.time = 1000 + f
         scene.updateCamera(W, H)
         return scene.getCamera()
-    # single-GPU reference on the same frames: serial sum of kernels (the quantity the per-rank times are comparable with)
+    # single-GPU references on the same frames: serial sum of kernels and the frames-in-flight rate
     single.set_overlap(0)
     for f in range(args.warmup):
         single.set_camera(cam(f)); single.run(st, f)
@@ -365,30 +375,103 @@ def emulate_world(args, abi, host, scene, env, st, desc, single, W, H, device):
         single.set_camera(cam(f)); single.run(st, f)
     c = single.counters()
     one = sum(c.stageMs[i] for i in range(5)) / max(1, c.framesTimed)
+    single.set_overlap(2)
+    f0 = args.warmup + args.steps
+    for f in range(f0, f0 + 8):
+        single.set_camera(cam(f)); single.run(st, f)
+    single.sync(); t0 = time.perf_counter()
+    for f in range(f0 + 8, f0 + 8 + args.steps):
+        single.set_camera(cam(f)); single.run(st, f)
+    single.sync(); one_flight = (time.perf_counter() - t0) / args.steps * 1e3
     single.destroy()
     m = MultiGpuRenderer().setup([device] * n)
     m.load_scene(desc); m.update(W, H)
-    m.set_serialize(True); m.set_balance(not args.equal_bands)
+    m.set_serialize(True); m.set_balance(0 if args.equal_bands else 1)
     scene2 = host.Scene().makeProcedural(abi.PROC_BISTRO_EXT, args.scale, 1)
     scene2.updateCamera(W, H)
-    acc = np.zeros((n, 2)); halo = 0; bands = None
-    for f in range(args.warmup + args.steps):
+    acc = np.zeros((n, 2)); halo = 0; kinds = np.zeros(6); bands = None
+    f = 0
+    def frame():
+        nonlocal f
         st.time = 1000 + f
         scene2.updateCamera(W, H)
         m.set_camera(scene2.getCamera()); m.run(st, f)
-        if f >= args.warmup:
+        f += 1
+    for k in range(args.warmup + args.steps):
+        frame()
+        if k >= args.warmup:
             s = m.stats()
             acc += np.array([[s.tracedMs[r], s.filterMs[r]] for r in range(n)])
-            halo += s.haloBytes
+            halo += s.haloBytes; kinds += np.array([s.haloBytesKind[i] for i in range(6)])
             bands = [(s.bandBegin[r], s.bandEnd[r]) for r in range(n)]
     acc /= args.steps
     tot = acc.sum(axis=1)
+    kinds /= args.steps
     out = {"metric": "per-rank ms/frame of the N-way row-tiled frame, ranks emulated one at a time on ONE GPU (not a benchmark result)",
            "n_ranks": n, "steps": args.steps, "warmup": args.warmup, "balance": "equal bands" if args.equal_bands else "cost-weighted bands",
-           "single_gpu_serial_ms": round(one, 4), "rank_ms": [round(float(x), 4) for x in tot], "rank_traced_ms": [round(float(x), 4) for x in acc[:, 0]],
+           "size": [W, H], "single_gpu_serial_ms": round(one, 4), "single_gpu_frames_in_flight_ms": round(one_flight, 4),
+           "rank_ms": [round(float(x), 4) for x in tot], "rank_traced_ms": [round(float(x), 4) for x in acc[:, 0]],
            "rank_filter_ms": [round(float(x), 4) for x in acc[:, 1]], "bands_last_frame": bands, "slowest_rank_ms": round(float(tot.max()), 4),
            "max_over_min": round(float(tot.max() / max(1e-6, tot.min())), 3), "projected_speedup_compute_only": round(one / float(tot.max()), 2),
-           "halo_bytes_per_frame": int(halo / args.steps), "fallbacks": m.stats().historyFallbacks}
+           "halo_bytes_per_frame": int(halo / args.steps), "halo_bytes_per_frame_by_kind": {HALO_KINDS[i]: int(kinds[i]) for i in range(6)},
+           "fallbacks": m.stats().historyFallbacks}
+    # ---- frames in flight per rank: the PERIOD of every rank alone on the GPU, on the partition found above -------------------------------------------
+    if not args.no_period:
+        m.set_balance(2); m.set_serialize(False); m.set_pipeline(True)
+        only = [int(x) for x in os.environ["RESTIR_EMULATE_RANKS"].split(",")] if os.environ.get("RESTIR_EMULATE_RANKS") else range(n)
+
+        def solo_period(r, k):
+            m.set_solo(r)
+            for _ in range(6):
+                frame()
+            m.sync(); t0 = time.perf_counter()
+            for _ in range(k):
+                frame()
+            m.sync(); return (time.perf_counter() - t0) / k * 1e3
+
+        # The partition above equalises the SUM of a rank's stage times; with frames in flight a rank's period is closer to the longest of them.  A few
+        # rounds of {measure every rank's period alone, spread it over the rank's 16-row stripes, re-plan} equalise the periods instead.
+        cur = [b[0] for b in bands] + [bands[-1][1]]
+        stripes = (H + 15) // 16
+        cost = np.ones(stripes)
+        history = []
+        for rnd in range(0 if os.environ.get("RESTIR_EMULATE_RANKS") else args.period_rounds):
+            per = [solo_period(r, max(8, args.steps // 3)) for r in range(n)]
+            history.append({"bands": cur, "period_ms": [round(float(x), 3) for x in per]})
+            for r in range(n):
+                a, b = cur[r] // 16, (cur[r + 1] + 15) // 16
+                cost[a:b] = 0.5 * cost[a:b] + 0.5 * per[r] / max(1, b - a) if rnd else per[r] / max(1, b - a)
+            cur = MultiGpuRenderer.plan_bands(H, n, cost, cur, 4)
+            m.set_solo(-1); m.set_bands(cur)
+            for _ in range(3):
+                frame()      # the rows that moved travel with the history pulls
+        if history:
+            out["period_balancing_rounds"] = history
+            out["bands_period_balanced"] = [(cur[r], cur[r + 1]) for r in range(n)]
+        periods, pk = [], np.zeros(6)
+        for r in only:
+            periods.append(solo_period(r, args.steps))
+            s = m.stats()
+            mine = np.array([s.haloBytesRankKind[r][i] for i in range(6)], dtype=np.float64)
+            if mine[:4].sum() >= pk[:4].sum():
+                pk = mine
+            if r == 0:
+                out["rank0_bytes_by_kind"] = {HALO_KINDS[i]: int(mine[i]) for i in range(6)}
+            out.setdefault("rank_bytes_steady", []).append(int(mine[:4].sum()))
+        m.set_solo(-1)
+        out["rank_period_ms"] = [round(float(x), 4) for x in periods]
+        out["slowest_rank_period_ms"] = round(float(max(periods)), 4)
+        out["projected_speedup_period_vs_single_gpu_frames_in_flight"] = round(one_flight / float(max(periods)), 2)
+        out["projected_speedup_period_vs_single_gpu_serial"] = round(one / float(max(periods)), 2)
+        # modelled xGMI time of the steady-state pulls of the busiest rank (history before its direct stage, filter halos before its filters; two
+        # neighbour links used one after the other on the rank's stream: the pessimistic end)
+        worst = {k: float(pk[i]) for i, k in enumerate(HALO_KINDS)}
+        out["xgmi_model"] = {"GBs_per_direction": XGMI_GBS_PER_DIRECTION, "copy_latency_us": XGMI_COPY_LATENCY_US,
+                              "worst_rank_bytes_by_kind": {k: int(v) for k, v in worst.items()},
+                              "modelled_ms": {k: round(v / (XGMI_GBS_PER_DIRECTION * 1e9) * 1e3 + (XGMI_COPY_LATENCY_US * 1e-3 * (6 if v > 0 else 0)), 4) for k, v in worst.items()}}
+        mm = out["xgmi_model"]["modelled_ms"]
+        out["xgmi_model"]["on_frame_path_ms"] = round(mm["history"] + mm["filter"] + mm["moved"], 4)
+        out["slowest_rank_period_with_modelled_xgmi_ms"] = round(float(max(periods)) + out["xgmi_model"]["on_frame_path_ms"], 4)
     print(json.dumps(out), flush=True)
     m.destroy()
     return None

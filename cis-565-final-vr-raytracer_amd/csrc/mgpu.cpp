@@ -19,11 +19,26 @@
 //      indirect colour from the owners; then the filters on regions that start wider than the band and shrink per level
 //      (direct +32/+24/+16/+0, indirect +64/+56/+48/+32/+0 rows: the overlap is recomputed instead of exchanged 9 times); compose
 //   4. rank 0 pulls the two result images' bands (the display rank of SURVEY §8e(3))
+//
+// FRAMES IN FLIGHT (rt_mgpu_set_pipeline, the default): the schedule of rt_render_frame's overlap mode 2 (src/renderer.cpp:154-206 is the reference
+// order it preserves) per rank — three streams: main = direct(f), ind = indirect(f), side = filters + compose — with every cross-rank dependency a HIP
+// event another rank's stream waits for (hipStreamWaitEvent), no host barrier between the steps and none between the ranks:
+//   main(f): waits D(f-1) of the ranks it pulls history rows from, and I(f-2) / Done(f-2) / G(f-2) of everybody who still reads what it overwrites
+//   ind(f) : waits its own D(f) and the neighbours' I(f-1) (indirect-reservoir history rows)
+//   side   : second half of frame f-1 (indirect filter halo pull, 5 levels, compose -> Done(f-1); rank 0's copy stream gathers the result bands -> G(f-1)),
+//            then the direct filters of frame f after the neighbours' D(f); a level that overwrites rows a neighbour pulls waits for that pull (X / XI events)
+// rt_mgpu_render_frame only queues the frame for the rank threads (at most two frames ahead) and returns.  The host side of a rank blocks in two places per
+// frame, on ITS OWN streams only: reading the history-miss flag of its direct stage and, one call later, of its indirect stage; a miss is handled by the rank
+// alone (it pulls the full history from the owners — nobody overwrites it before this rank's D / I event — and re-runs its stage).  Host-side counters
+// (`issued`) only make sure an event has been RECORDED before another thread makes a stream wait for it.  The spatial-reuse modes, whose direct stage
+// exchanges rows in the middle, and the measurement mode rt_mgpu_set_serialize run the barrier schedule above.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -32,11 +47,17 @@
 
 namespace {
 
-constexpr int HIST_HALO = 32;                       // full-res rows of last-frame history around the band
+// full-res rows of last-frame history around the band: adaptive (rt_mgpu::histHalo) — HIST_HALO_MIN while no temporal lookup leaves band + halo, doubled
+// (up to HIST_HALO_MAX) for the frames after one did, halved again after HIST_HALO_CALM frames without; a lookup outside is always caught (exact fallback)
+constexpr int HIST_HALO_MIN = 16, HIST_HALO_MAX = 64, HIST_HALO_CALM = 16;
 constexpr int DIRECT_GROW[4] = {32, 24, 16, 0};     // rows added to the band for A-Trous level l's output (multiples of 8)
 constexpr int INDIRECT_GROW[5] = {64, 56, 48, 32, 0};
-constexpr int HALO_DIRECT_COLOR = 40, HALO_INDIRECT_COLOR = 72, HALO_GBUFFER = 144;
+constexpr int HALO_DIRECT_COLOR = 40, HALO_INDIRECT_COLOR = 72;
+// G-buffer rows the nine filter passes read beyond the band: the direct chain reaches DIRECT_GROW[0] + 2 rows (every row), the indirect chain
+// INDIRECT_GROW[0] + 2 half-res rows = 132 full-res rows, of which it reads the even ones only (loadThisGeometry(2q), denoise_common.glsl:42-55)
+constexpr int HALO_GBUFFER_FULL = 40, HALO_GBUFFER = 144;
 constexpr int MAX_RANKS = RT_MGPU_MAX_RANKS;
+constexpr int RING = 8;                             // per-frame events are reused every RING frames (a rank is never more than 3 frames from its peers)
 
 struct Barrier {   // reusable, for a fixed number of threads
   std::mutex m; std::condition_variable cv; int n = 0, count = 0; uint64_t gen = 0;
@@ -50,15 +71,47 @@ struct Barrier {   // reusable, for a fixed number of threads
   }
 };
 
+// what a rank thread needs to render one frame: a copy, because rt_mgpu_render_frame returns before the frame is issued (frames in flight)
+struct FrameCmd {
+  rt_state st{}; int frames = 0; rt_scene_camera cam{};
+  int bands[MAX_RANKS + 1] = {}, prev[MAX_RANKS + 1] = {};
+  bool haveHistory = false, gather = true;
+  int histHalo = HIST_HALO_MIN;
+  bool samePartition = false;   // bands == prev: rows the previous frame's filter halo brought need no second pull
+  int64_t seq = 0;      // frames since the pipeline was (re)started
+  int solo = -1;        // measurement: only this rank renders (the others publish their flags and skip)
+};
+struct Cmd {
+  enum Kind { UPLOAD, RESIZE, FRAME, FRAMEP, DRAIN, QUIT } kind = QUIT;
+  FrameCmd f;
+};
+enum HaloKind { HK_HISTORY = 0, HK_FILTER = 1, HK_SPATIAL = 2, HK_MOVED = 3, HK_GATHER = 4, HK_FALLBACK = 5, HK_COUNT = 6 };
+
 struct Rank {
   int id = 0, dev = 0;
   rt_ctx* ctx = nullptr;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev[4] = {};   // start, traced, filters-begin, end
+  hipStream_t stream = nullptr;                                       // barrier schedule: everything; pipelined schedule: "main"
+  hipStream_t sInd = nullptr, sSide = nullptr, sCopy = nullptr;
+  hipEvent_t ev[4] = {};   // barrier schedule timing: start, traced, filters-begin, end
+  // pipelined schedule: one event per frame slot; issued[k] = the latest frame sequence number whose event k has been RECORDED (host-side only)
+  enum { E_D = 0, E_I, E_DONE, E_G, E_X, E_XI, E_KINDS };
+  hipEvent_t evp[E_KINDS][RING] = {};
+  std::atomic<int64_t> issued[E_KINDS];
+  hipEvent_t tm[RING][8] = {};                                       // timing: direct begin/end, indirect begin/end, direct filters begin/end, second half begin/end
+  void* gptr[RING] = {};                                              // this rank's physical G-buffer of frame seq (the boundary ids rotate)
+  bool havePrev = false; FrameCmd prevCmd;                           // frame whose second half is still to be issued
+  int64_t aIssued = -1;                                               // frame sequence number whose direct stage has been issued (look-ahead)
+  int rotatedFor = -1;                                                // `frames` value the rotating buffer ids currently name
+  int mode = -1;                                                      // rt_set_overlap value of the ctx (0: barrier schedule, 2: frames in flight)
   std::thread th;
+  std::mutex qm; std::condition_variable qcv; std::deque<Cmd> q;
   int rc = RT_OK;
   float tracedMs = 0, filterMs = 0;
-  uint64_t pulled = 0;
+  uint64_t pulled[HK_COUNT] = {};        // bytes pulled for the frame being issued (barrier schedule) / by frame parity (pulledBy, frames in flight)
+  uint64_t pulledBy[2][HK_COUNT] = {};
+  uint64_t lastPulled[HK_COUNT] = {};    // ... of the latest COMPLETE frame: what rt_mgpu_get_stats reports
+  int accSlot = -1;                      // >= 0: pullRowsOn accounts to pulledBy[accSlot]
+  Rank() { for(auto& a : issued) a.store(-1); }
 };
 
 }  // namespace
@@ -71,13 +124,19 @@ struct rt_mgpu {
   int W = 0, H = 0;
   std::vector<int> bands, prevBands;   // n + 1 row boundaries (multiples of 16, last = H)
   std::vector<float> stripeCost;       // smoothed cost per 16-row stripe
-  bool haveHistory = false, balance = true, serialize = false, gatherResults = true;
-  // per-frame command
-  rt_state st{}; int frames = 0; rt_scene_camera cam{}; const rt_scene_desc* desc = nullptr;
-  enum Cmd { NONE, UPLOAD, RESIZE, FRAME, SYNC, QUIT } cmd = NONE;
-  Barrier start, done, step;
+  bool haveHistory = false, balance = true, serialize = false, gatherResults = true, pipeline = true;
+  int solo = -1;
+  int64_t seq = 0; int lastFrames = -2; bool pipeActive = false;
+  int histHalo = HIST_HALO_MIN; uint32_t fallbacksSeen = 0; int calmFrames = 0; bool lastDenoise = false;
+  rt_scene_camera cam{}; const rt_scene_desc* desc = nullptr;
+  // completion of posted commands
+  std::mutex pm; std::condition_variable pcv; int pending = 0;
+  Barrier step;
   int missFlags[MAX_RANKS] = {};
   std::mutex turn;                     // serialize mode: one rank's kernels at a time
+  std::mutex buildTurn;                // one multi-threaded host BVH8 build at a time
+  std::atomic<bool> abort{false};
+  std::atomic<uint32_t> fallbacks{0};
   std::string err;
   rt_mgpu_stats stats{};
   std::mutex errLock;
@@ -85,6 +144,7 @@ struct rt_mgpu {
   {
     std::lock_guard<std::mutex> l(errLock);
     if(err.empty()) err = std::string("rt_mgpu rank ") + std::to_string(rank) + ": " + what + " failed (" + std::to_string(rc) + "): " + (detail ? detail : "");
+    abort = true;
   }
 };
 
@@ -93,13 +153,6 @@ namespace {
 bool halfRows(int buf)
 {
   return buf == RT_BUF_INDIRECT_RESV0 || buf == RT_BUF_INDIRECT_RESV1 || buf == RT_BUF_INDIRECT_RESV_TEMP || buf == RT_BUF_DENOISE_IND_A || buf == RT_BUF_DENOISE_IND_B;
-}
-// row pitch of `buf` in its own ctx; the half-res filter temporaries live in the top-left quarter of full-pitch images
-size_t pitchOf(rt_ctx* c, int buf)
-{
-  void* p; size_t bytes, pitch;
-  if(rt_device_ptr(c, buf, &p, &bytes, &pitch) != RT_OK) return 0;
-  return pitch;
 }
 
 #define MG_CHECK(call, what)                                                             \
@@ -113,8 +166,11 @@ size_t pitchOf(rt_ctx* c, int buf)
     if(e_ != hipSuccess) { M.fail(R.id, int(e_), what, hipGetErrorString(e_)); R.rc = RT_ERR_HIP; } \
   } while(0)
 
-// copy rows [a, b) of `buf` into rank R's copy from the ranks that own them under `part` (full-res boundaries)
-void pullRows(rt_mgpu& M, Rank& R, int buf, int a, int b, const std::vector<int>& part)
+// copy rows [a, b) of `buf` into rank R's copy from the ranks that own them under `part` (full-res boundaries), on `strm`.  gslot >= 0: `buf` is a
+// G-buffer and both sides address the physical buffer of that frame slot (the ids rotate with frames in flight).
+// evenOnly: only the even rows of [a, b) (the half-resolution filters read G(2q)); widthBytes > 0: only the first widthBytes of every row (the half-res filter
+// temporaries live in the left half of full-pitch images).
+void pullRowsOn(rt_mgpu& M, Rank& R, hipStream_t strm, int buf, int a, int b, const int* part, int kind, int gslot = -1, bool evenOnly = false, size_t widthBytes = 0)
 {
   const bool half = halfRows(buf);
   const int limit = half ? M.H / 2 : M.H;
@@ -122,6 +178,7 @@ void pullRows(rt_mgpu& M, Rank& R, int buf, int a, int b, const std::vector<int>
   if(b <= a) return;
   void* dst = nullptr; size_t bytes = 0, pitch = 0;
   MG_CHECK(rt_device_ptr(R.ctx, buf, &dst, &bytes, &pitch), "rt_device_ptr");
+  if(gslot >= 0) dst = R.gptr[gslot];
   for(int q = 0; q < M.n; q++) {
     if(q == R.id) continue;
     int lo = half ? part[q] / 2 : part[q], hi = half ? part[q + 1] / 2 : part[q + 1];
@@ -131,64 +188,100 @@ void pullRows(rt_mgpu& M, Rank& R, int buf, int a, int b, const std::vector<int>
     void* src = nullptr; size_t sb = 0, sp = 0;
     Rank& Q = M.ranks[q];
     if(rt_device_ptr(Q.ctx, buf, &src, &sb, &sp) != RT_OK || sp != pitch) { M.fail(R.id, RT_ERR_INVALID_ARG, "peer rt_device_ptr", ""); R.rc = RT_ERR_INVALID_ARG; return; }
+    if(gslot >= 0) src = Q.gptr[gslot];
+    if(!dst || !src) continue;   // (frame slot never rendered on that rank: nothing to pull)
+    if(evenOnly || (widthBytes > 0 && widthBytes < pitch)) {
+      if(evenOnly) lo = (lo + 1) & ~1;
+      const int rows = evenOnly ? (hi - lo + 1) / 2 : hi - lo;
+      if(rows <= 0) continue;
+      const size_t off = size_t(lo) * pitch, stride = evenOnly ? 2 * pitch : pitch, w = widthBytes > 0 ? std::min(widthBytes, pitch) : pitch;
+      // (unified addressing + peer access: a 2-D device-to-device copy may cross devices)
+      MG_HIP(hipMemcpy2DAsync(static_cast<char*>(dst) + off, stride, static_cast<char*>(src) + off, stride, w, size_t(rows), Q.dev == R.dev ? hipMemcpyDeviceToDevice : hipMemcpyDefault, strm), "hipMemcpy2DAsync");
+      (R.accSlot >= 0 ? R.pulledBy[R.accSlot] : R.pulled)[kind] += w * size_t(rows);
+      continue;
+    }
     const size_t off = size_t(lo) * pitch, len = size_t(hi - lo) * pitch;
-    if(Q.dev == R.dev) MG_HIP(hipMemcpyAsync(static_cast<char*>(dst) + off, static_cast<char*>(src) + off, len, hipMemcpyDeviceToDevice, R.stream), "hipMemcpyAsync");
-    else MG_HIP(hipMemcpyPeerAsync(static_cast<char*>(dst) + off, R.dev, static_cast<char*>(src) + off, Q.dev, len, R.stream), "hipMemcpyPeerAsync");
-    R.pulled += len;
+    if(Q.dev == R.dev) MG_HIP(hipMemcpyAsync(static_cast<char*>(dst) + off, static_cast<char*>(src) + off, len, hipMemcpyDeviceToDevice, strm), "hipMemcpyAsync");
+    else MG_HIP(hipMemcpyPeerAsync(static_cast<char*>(dst) + off, R.dev, static_cast<char*>(src) + off, Q.dev, len, strm), "hipMemcpyPeerAsync");
+    (R.accSlot >= 0 ? R.pulledBy[R.accSlot] : R.pulled)[kind] += len;
   }
 }
-
-void runStage(rt_mgpu& M, Rank& R, int stage, int level, int r0, int r1, int limit)
+void pullRows(rt_mgpu& M, Rank& R, int buf, int a, int b, const std::vector<int>& part, int kind) { pullRowsOn(M, R, R.stream, buf, a, b, part.data(), kind); }
+// the filter halos of one frame: G-buffer (every row next to the band, even rows further out) and noisy direct colour
+void pullFilterHaloDirect(rt_mgpu& M, Rank& R, hipStream_t strm, int cur, int y0, int y1, const int* part, int gslot)
 {
-  r0 = std::max(0, r0); r1 = std::min(limit, r1);
-  if(r1 > r0) MG_CHECK(rt_run_stage(R.ctx, &M.st, M.frames, stage, level, r0, r1), "rt_run_stage");
+  pullRowsOn(M, R, strm, RT_BUF_GBUFFER0 + cur, y0 - HALO_GBUFFER_FULL, y1 + HALO_GBUFFER_FULL, part, HK_FILTER, gslot);
+  pullRowsOn(M, R, strm, RT_BUF_GBUFFER0 + cur, y0 - HALO_GBUFFER, y0 - HALO_GBUFFER_FULL, part, HK_FILTER, gslot, true);
+  pullRowsOn(M, R, strm, RT_BUF_GBUFFER0 + cur, y1 + HALO_GBUFFER_FULL, y1 + HALO_GBUFFER, part, HK_FILTER, gslot, true);
+  pullRowsOn(M, R, strm, RT_BUF_DIRECT_RESULT0 + cur, y0 - HALO_DIRECT_COLOR, y1 + HALO_DIRECT_COLOR, part, HK_FILTER);
+}
+void pullFilterHaloIndirect(rt_mgpu& M, Rank& R, hipStream_t strm, int h0, int h1, const int* part)
+{
+  pullRowsOn(M, R, strm, RT_BUF_DENOISE_IND_A, h0 - HALO_INDIRECT_COLOR, h1 + HALO_INDIRECT_COLOR, part, HK_FILTER, -1, false, size_t(M.W / 2) * 16);
 }
 
+void runStage(rt_mgpu& M, Rank& R, const rt_state& st, int frames, int stage, int level, int r0, int r1, int limit)
+{
+  r0 = std::max(0, r0); r1 = std::min(limit, r1);
+  if(r1 > r0) MG_CHECK(rt_run_stage(R.ctx, &st, frames, stage, level, r0, r1), "rt_run_stage");
+}
+
+// ==================================================================================================================================================
+// barrier schedule
+// ==================================================================================================================================================
 // direct stage on the band, indirect stage on its half-res rows.  With spatial reuse the direct stage runs in two halves around an
 // exchange: every pixel caches its reservoir (level 1), the ranks pull the rows next to their band from RT_BUF_DIRECT_RESV_TEMP — the
 // neighbour picks of direct_stage.comp:86-107 reach one pixel up / down — and then merge and shade (level 2).  Contains one barrier in
 // the spatial modes (uniform over ranks: the mode comes from the shared RtxState).
-void tracedStages(rt_mgpu& M, Rank& R, int y0, int y1, int h0, int h1)
+void tracedStages(rt_mgpu& M, Rank& R, const FrameCmd& c, int y0, int y1, int h0, int h1)
 {
-  const bool spatial = M.n > 1 && (M.st.ReSTIRState == RT_RESTIR_SPATIAL || M.st.ReSTIRState == RT_RESTIR_SPATIOTEMPORAL);
-  if(!spatial) runStage(M, R, RT_STAGE_DIRECT, 0, y0, y1, M.H);
+  const std::vector<int> bands(c.bands, c.bands + M.n + 1);
+  const bool spatial = M.n > 1 && (c.st.ReSTIRState == RT_RESTIR_SPATIAL || c.st.ReSTIRState == RT_RESTIR_SPATIOTEMPORAL);
+  if(!spatial) runStage(M, R, c.st, c.frames, RT_STAGE_DIRECT, 0, y0, y1, M.H);
   else {
-    runStage(M, R, RT_STAGE_DIRECT, 1, y0, y1, M.H);
+    runStage(M, R, c.st, c.frames, RT_STAGE_DIRECT, 1, y0, y1, M.H);
     MG_HIP(hipStreamSynchronize(R.stream), "sync");
     M.step.wait();
-    pullRows(M, R, RT_BUF_DIRECT_RESV_TEMP, y0 - 2, y0, M.bands);
-    pullRows(M, R, RT_BUF_DIRECT_RESV_TEMP, y1, y1 + 2, M.bands);
-    runStage(M, R, RT_STAGE_DIRECT, 2, y0, y1, M.H);
+    pullRows(M, R, RT_BUF_DIRECT_RESV_TEMP, y0 - 2, y0, bands, HK_SPATIAL);
+    pullRows(M, R, RT_BUF_DIRECT_RESV_TEMP, y1, y1 + 2, bands, HK_SPATIAL);
+    runStage(M, R, c.st, c.frames, RT_STAGE_DIRECT, 2, y0, y1, M.H);
   }
-  runStage(M, R, RT_STAGE_INDIRECT, 0, h0, h1, M.H / 2);
+  runStage(M, R, c.st, c.frames, RT_STAGE_INDIRECT, 0, h0, h1, M.H / 2);
 }
 
-void frameOnRank(rt_mgpu& M, Rank& R)
+void frameOnRank(rt_mgpu& M, Rank& R, const FrameCmd& c)
 {
-  const int f = M.frames, cur = f & 1, last = cur ^ 1, H = M.H, Hh = H / 2;
-  const int y0 = M.bands[R.id], y1 = M.bands[R.id + 1];
+  const int f = c.frames, cur = f & 1, last = cur ^ 1, H = M.H, Hh = H / 2;
+  const std::vector<int> bands(c.bands, c.bands + M.n + 1), prevBands(c.prev, c.prev + M.n + 1);
+  const int y0 = bands[R.id], y1 = bands[R.id + 1];
   const int h0 = std::min(y0 / 2, Hh), h1 = std::min(y1 / 2, Hh);
   const bool multi = M.n > 1;
-  R.pulled = 0;
-  MG_CHECK(rt_set_camera(R.ctx, &M.cam), "rt_set_camera");
+  for(auto& p : R.pulled) p = 0;
+  R.accSlot = -1;
+  if(R.mode != 0) { MG_CHECK(rt_set_overlap(R.ctx, 0), "rt_set_overlap"); R.mode = 0; }   // launches run alone: the whole traversal stack in LDS
+  MG_CHECK(rt_set_stream(R.ctx, R.stream), "rt_set_stream");
+  MG_CHECK(rt_set_camera(R.ctx, &c.cam), "rt_set_camera");
   // ---- 1. history rows for the band + halo, from last frame's owners ----
-  if(multi && M.haveHistory) {
-    for(int buf : {RT_BUF_GBUFFER0 + last, RT_BUF_DIRECT_RESV0 + last, RT_BUF_LIGHT_ID0 + last}) pullRows(M, R, buf, y0 - HIST_HALO, y1 + HIST_HALO, M.prevBands);
-    pullRows(M, R, RT_BUF_INDIRECT_RESV0 + last, h0 - HIST_HALO / 2, h1 + HIST_HALO / 2, M.prevBands);
+  if(multi && c.haveHistory) {
+    const int HIST_HALO = c.histHalo;
+    // (the G-buffer rows next to the band arrived with last frame's filter halo when the partition did not move)
+    if(!(c.samePartition && HIST_HALO <= HALO_GBUFFER_FULL)) pullRows(M, R, RT_BUF_GBUFFER0 + last, y0 - HIST_HALO, y1 + HIST_HALO, prevBands, HK_HISTORY);
+    for(int buf : {RT_BUF_DIRECT_RESV0 + last, RT_BUF_LIGHT_ID0 + last}) pullRows(M, R, buf, y0 - HIST_HALO, y1 + HIST_HALO, prevBands, HK_HISTORY);
+    pullRows(M, R, RT_BUF_INDIRECT_RESV0 + last, h0 - HIST_HALO / 2, h1 + HIST_HALO / 2, prevBands, HK_HISTORY);
     // rows that changed owner also bring the OTHER parity of the reservoir buffers along: pixels that return early (miss, emitter,
     // debug view) leave their slot untouched (reference quirk), so a slot of this frame's buffer can keep the value of
     // two frames ago.  Nothing is copied while the partition stands still (pullRows only copies rows other ranks owned).
-    for(int buf : {RT_BUF_DIRECT_RESV0 + cur, RT_BUF_LIGHT_ID0 + cur, int(RT_BUF_DIRECT_RESV_TEMP)}) pullRows(M, R, buf, y0, y1, M.prevBands);
-    pullRows(M, R, RT_BUF_INDIRECT_RESV0 + cur, h0, h1, M.prevBands);
+    for(int buf : {RT_BUF_DIRECT_RESV0 + cur, RT_BUF_LIGHT_ID0 + cur, int(RT_BUF_DIRECT_RESV_TEMP)}) pullRows(M, R, buf, y0, y1, prevBands, HK_MOVED);
+    pullRows(M, R, RT_BUF_INDIRECT_RESV0 + cur, h0, h1, prevBands, HK_MOVED);
   }
-  MG_CHECK(rt_set_history_rows(R.ctx, multi ? std::max(0, y0 - HIST_HALO) : 0, multi ? std::min(H, y1 + HIST_HALO) : H), "rt_set_history_rows");
+  MG_CHECK(rt_set_history_rows(R.ctx, multi ? std::max(0, y0 - c.histHalo) : 0, multi ? std::min(H, y1 + c.histHalo) : H), "rt_set_history_rows");
   // ---- 2. ray-traced stages ----
   {
-    const bool spatialSplit = multi && (M.st.ReSTIRState == RT_RESTIR_SPATIAL || M.st.ReSTIRState == RT_RESTIR_SPATIOTEMPORAL);
+    const bool spatialSplit = multi && (c.st.ReSTIRState == RT_RESTIR_SPATIAL || c.st.ReSTIRState == RT_RESTIR_SPATIOTEMPORAL);
     std::unique_lock<std::mutex> turn(M.turn, std::defer_lock);
     if(M.serialize && !spatialSplit) { turn.lock(); MG_HIP(hipStreamSynchronize(R.stream), "sync"); }   // (the split stage has a barrier inside: ranks cannot take turns)
     MG_HIP(hipEventRecord(R.ev[0], R.stream), "hipEventRecord");
-    tracedStages(M, R, y0, y1, h0, h1);
+    tracedStages(M, R, c, y0, y1, h0, h1);
     MG_HIP(hipEventRecord(R.ev[1], R.stream), "hipEventRecord");
     int miss = 0;
     if(multi) MG_CHECK(rt_history_miss(R.ctx, &miss), "rt_history_miss");   // waits for the stream
@@ -199,23 +292,22 @@ void frameOnRank(rt_mgpu& M, Rank& R)
   bool any = false;
   for(int q = 0; q < M.n; q++) any = any || M.missFlags[q] != 0;
   if(any) {  // exact fallback: the whole history, then the two stages again
-    for(int buf : {RT_BUF_GBUFFER0 + last, RT_BUF_DIRECT_RESV0 + last, RT_BUF_LIGHT_ID0 + last}) pullRows(M, R, buf, 0, H, M.prevBands);
-    pullRows(M, R, RT_BUF_INDIRECT_RESV0 + last, 0, Hh, M.prevBands);
+    for(int buf : {RT_BUF_GBUFFER0 + last, RT_BUF_DIRECT_RESV0 + last, RT_BUF_LIGHT_ID0 + last}) pullRows(M, R, buf, 0, H, prevBands, HK_FALLBACK);
+    pullRows(M, R, RT_BUF_INDIRECT_RESV0 + last, 0, Hh, prevBands, HK_FALLBACK);
     MG_CHECK(rt_set_history_rows(R.ctx, 0, H), "rt_set_history_rows");
-    const bool spatialSplit = M.st.ReSTIRState == RT_RESTIR_SPATIAL || M.st.ReSTIRState == RT_RESTIR_SPATIOTEMPORAL;
+    const bool spatialSplit = c.st.ReSTIRState == RT_RESTIR_SPATIAL || c.st.ReSTIRState == RT_RESTIR_SPATIOTEMPORAL;
     std::unique_lock<std::mutex> turn(M.turn, std::defer_lock);
     if(M.serialize && !spatialSplit) turn.lock();
-    tracedStages(M, R, y0, y1, h0, h1);
+    tracedStages(M, R, c, y0, y1, h0, h1);
     int miss = 0;
     MG_CHECK(rt_history_miss(R.ctx, &miss), "rt_history_miss");   // clears the flag, waits for the stream
-    if(R.id == 0) M.stats.historyFallbacks++;
+    if(R.id == 0) M.fallbacks++;
   }
   M.step.wait();   // every rank's G-buffer / reservoirs / noisy colours of this frame are complete
   // ---- 3. one exchange for the nine filter passes, filters, compose ----
-  if(multi && M.st.denoise > 0) {
-    pullRows(M, R, RT_BUF_GBUFFER0 + cur, y0 - HALO_GBUFFER, y1 + HALO_GBUFFER, M.bands);
-    pullRows(M, R, RT_BUF_DIRECT_RESULT0 + cur, y0 - HALO_DIRECT_COLOR, y1 + HALO_DIRECT_COLOR, M.bands);
-    pullRows(M, R, RT_BUF_DENOISE_IND_A, h0 - HALO_INDIRECT_COLOR, h1 + HALO_INDIRECT_COLOR, M.bands);
+  if(multi && c.st.denoise > 0) {
+    pullFilterHaloDirect(M, R, R.stream, cur, y0, y1, bands.data(), -1);
+    pullFilterHaloIndirect(M, R, R.stream, h0, h1, bands.data());
     MG_HIP(hipStreamSynchronize(R.stream), "sync");
   }
   M.step.wait();   // nobody overwrites a source row (level 3 / compose write the result image) before every pull has landed
@@ -223,24 +315,265 @@ void frameOnRank(rt_mgpu& M, Rank& R)
     std::unique_lock<std::mutex> turn(M.turn, std::defer_lock);
     if(M.serialize) turn.lock();
     MG_HIP(hipEventRecord(R.ev[2], R.stream), "hipEventRecord");
-    if(M.st.denoise > 0) {
-      for(int l = 0; l < 4; l++) { const int g = multi ? DIRECT_GROW[l] : 0; runStage(M, R, RT_STAGE_DENOISE_DIRECT, l, y0 - g, y1 + g, H); }
-      for(int l = 0; l < 5; l++) { const int g = multi ? INDIRECT_GROW[l] : 0; runStage(M, R, RT_STAGE_DENOISE_INDIRECT, l, h0 - g, h1 + g, Hh); }
+    if(c.st.denoise > 0) {
+      for(int l = 0; l < 4; l++) { const int g = multi ? DIRECT_GROW[l] : 0; runStage(M, R, c.st, f, RT_STAGE_DENOISE_DIRECT, l, y0 - g, y1 + g, H); }
+      for(int l = 0; l < 5; l++) { const int g = multi ? INDIRECT_GROW[l] : 0; runStage(M, R, c.st, f, RT_STAGE_DENOISE_INDIRECT, l, h0 - g, h1 + g, Hh); }
     }
-    runStage(M, R, RT_STAGE_COMPOSE, 0, y0, y1, H);
+    runStage(M, R, c.st, f, RT_STAGE_COMPOSE, 0, y0, y1, H);
     MG_HIP(hipEventRecord(R.ev[3], R.stream), "hipEventRecord");
     MG_HIP(hipStreamSynchronize(R.stream), "sync");
   }
   M.step.wait();
   // ---- 4. result bands to the display rank ----
-  if(multi && R.id == 0 && M.gatherResults) {
-    pullRows(M, R, RT_BUF_DIRECT_RESULT0 + cur, 0, H, M.bands);
-    pullRows(M, R, RT_BUF_INDIRECT_RESULT0 + cur, 0, H, M.bands);
+  if(multi && R.id == 0 && c.gather) {
+    pullRows(M, R, RT_BUF_DIRECT_RESULT0 + cur, 0, H, bands, HK_GATHER);
+    pullRows(M, R, RT_BUF_INDIRECT_RESULT0 + cur, 0, H, bands, HK_GATHER);
     MG_HIP(hipStreamSynchronize(R.stream), "sync");
   }
   float ms = 0.f;
   if(hipEventElapsedTime(&ms, R.ev[0], R.ev[1]) == hipSuccess) R.tracedMs = ms;
   if(hipEventElapsedTime(&ms, R.ev[2], R.ev[3]) == hipSuccess) R.filterMs = ms;
+  for(int k = 0; k < HK_COUNT; k++) R.lastPulled[k] = R.pulled[k];
+}
+
+// ==================================================================================================================================================
+// frames in flight
+// ==================================================================================================================================================
+// host side: wait until rank q has RECORDED event `kind` of frame `want` (a stream may only be made to wait for a recorded event)
+void hostWaitIssued(rt_mgpu& M, Rank& Q, int kind, int64_t want)
+{
+  if(want < 0) return;
+  int spins = 0;
+  while(Q.issued[kind].load(std::memory_order_acquire) < want && !M.abort.load()) {
+    if(++spins < 200) std::this_thread::yield();
+    else std::this_thread::sleep_for(std::chrono::microseconds(20));
+  }
+}
+void recordIssued(rt_mgpu& M, Rank& R, int kind, int64_t seq, hipStream_t strm)
+{
+  MG_HIP(hipEventRecord(R.evp[kind][seq % RING], strm), "hipEventRecord");
+  R.issued[kind].store(seq, std::memory_order_release);
+}
+// make `strm` wait for event `kind` of frame `seq` on every rank (self included if `self`)
+void waitAll(rt_mgpu& M, Rank& R, hipStream_t strm, int kind, int64_t seq, bool self)
+{
+  if(seq < 0) return;
+  for(int q = 0; q < M.n; q++) {
+    if(q == R.id && !self) continue;
+    Rank& Q = M.ranks[q];
+    if(q != R.id) hostWaitIssued(M, Q, kind, seq);
+    MG_HIP(hipStreamWaitEvent(strm, Q.evp[kind][seq % RING], 0), "hipStreamWaitEvent");
+  }
+}
+void syncRank(rt_mgpu& M, Rank& R)
+{
+  MG_HIP(hipStreamSynchronize(R.stream), "sync"); MG_HIP(hipStreamSynchronize(R.sInd), "sync");
+  MG_HIP(hipStreamSynchronize(R.sSide), "sync"); MG_HIP(hipStreamSynchronize(R.sCopy), "sync");
+}
+void harvestTiming(Rank& R, int64_t seq)
+{
+  if(seq < 0) return;
+  hipEvent_t* t = R.tm[seq % RING];
+  float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+  if(hipEventElapsedTime(&a, t[0], t[1]) == hipSuccess && hipEventElapsedTime(&b, t[2], t[3]) == hipSuccess) R.tracedMs = a + b;
+  if(hipEventElapsedTime(&c, t[4], t[5]) == hipSuccess && hipEventElapsedTime(&d, t[6], t[7]) == hipSuccess) R.filterMs = c + d;
+}
+
+// second half of frame p = prevCmd: validate its indirect stage, then (side stream) the indirect filter halo, 5 levels, compose; rank 0 gathers
+void finishPrev(rt_mgpu& M, Rank& R, int rotatedFrames /* frames value the G-buffer ids were last rotated for, or -1 */)
+{
+  if(!R.havePrev) return;
+  R.havePrev = false;
+  const FrameCmd& c = R.prevCmd;
+  const int64_t p = c.seq; const int slot = int(p % RING);
+  const int f = c.frames, cur = f & 1, last = cur ^ 1, H = M.H, Hh = H / 2;
+  const int y0 = c.bands[R.id], y1 = c.bands[R.id + 1], h0 = std::min(y0 / 2, Hh), h1 = std::min(y1 / 2, Hh);
+  const bool multi = M.n > 1;
+  const int accWas = R.accSlot;
+  R.accSlot = int(p & 1);
+  MG_CHECK(rt_set_camera(R.ctx, &c.cam), "rt_set_camera");   // the deferred launches belong to frame p: its camera, not the next frame's
+  // ---- validate indirect(p) ----
+  MG_CHECK(rt_set_stream(R.ctx, R.sInd), "rt_set_stream");
+  int miss = 0;
+  MG_CHECK(rt_history_miss_stage(R.ctx, RT_STAGE_INDIRECT, &miss), "rt_history_miss_stage");   // waits for the ind stream only
+  if(miss && multi && c.haveHistory) {
+    // exact fallback, by this rank alone: the owners keep G(p-1) and the indirect reservoirs of p-1 until they have seen this rank's I(p)
+    syncRank(M, R);
+    if(rotatedFrames >= 0 && rotatedFrames != f) MG_CHECK(rt_rotate_buffers(R.ctx, rotatedFrames), "rt_rotate_buffers");   // undo: the ids name frame p's buffers again
+    pullRowsOn(M, R, R.sInd, RT_BUF_GBUFFER0 + last, 0, H, c.prev, HK_FALLBACK, p >= 1 ? int((p - 1) % RING) : -1);
+    pullRowsOn(M, R, R.sInd, RT_BUF_INDIRECT_RESV0 + last, 0, Hh, c.prev, HK_FALLBACK);
+    MG_CHECK(rt_set_history_rows(R.ctx, 0, H), "rt_set_history_rows");
+    runStage(M, R, c.st, f, RT_STAGE_INDIRECT, 0, h0, h1, Hh);
+    MG_CHECK(rt_history_miss_stage(R.ctx, RT_STAGE_INDIRECT, &miss), "rt_history_miss_stage");   // clears the flag, waits
+    if(rotatedFrames >= 0 && rotatedFrames != f) MG_CHECK(rt_rotate_buffers(R.ctx, rotatedFrames), "rt_rotate_buffers");   // redo
+    M.fallbacks++;
+  }
+  MG_HIP(hipEventRecord(R.tm[slot][3], R.sInd), "hipEventRecord");
+  recordIssued(M, R, Rank::E_I, p, R.sInd);
+  // ---- side stream: indirect filters + compose ----
+  MG_CHECK(rt_set_stream(R.ctx, R.sSide), "rt_set_stream");
+  waitAll(M, R, R.sSide, Rank::E_I, p, true);
+  MG_HIP(hipEventRecord(R.tm[slot][6], R.sSide), "hipEventRecord");
+  if(multi && c.st.denoise > 0) pullFilterHaloIndirect(M, R, R.sSide, h0, h1, c.bands);
+  recordIssued(M, R, Rank::E_XI, p, R.sSide);
+  if(c.st.denoise > 0) {
+    runStage(M, R, c.st, f, RT_STAGE_DENOISE_INDIRECT, 0, h0 - (multi ? INDIRECT_GROW[0] : 0), h1 + (multi ? INDIRECT_GROW[0] : 0), Hh);   // IndA -> IndB
+    if(multi) waitAll(M, R, R.sSide, Rank::E_XI, p, false);   // level 1 writes IndA: every neighbour has its copy of this band's noisy rows
+    for(int l = 1; l < 5; l++) { const int g = multi ? INDIRECT_GROW[l] : 0; runStage(M, R, c.st, f, RT_STAGE_DENOISE_INDIRECT, l, h0 - g, h1 + g, Hh); }
+  }
+  runStage(M, R, c.st, f, RT_STAGE_COMPOSE, 0, y0, y1, H);
+  MG_HIP(hipEventRecord(R.tm[slot][7], R.sSide), "hipEventRecord");
+  recordIssued(M, R, Rank::E_DONE, p, R.sSide);
+  // ---- display rank: result bands on the copy stream, off every other stream's path ----
+  if(R.id == 0) {
+    if(multi && c.gather) {
+      waitAll(M, R, R.sCopy, Rank::E_DONE, p, true);
+      pullRowsOn(M, R, R.sCopy, RT_BUF_DIRECT_RESULT0 + cur, 0, H, c.bands, HK_GATHER);
+      pullRowsOn(M, R, R.sCopy, RT_BUF_INDIRECT_RESULT0 + cur, 0, H, c.bands, HK_GATHER);
+    }
+    recordIssued(M, R, Rank::E_G, p, R.sCopy);
+  }
+  for(int k = 0; k < HK_COUNT; k++) R.lastPulled[k] = R.pulledBy[p & 1][k];
+  R.accSlot = accWas;
+}
+
+// ---- A. direct(f) on the main stream ------------------------------------------------------------------------------------------------------------
+void pipeDirect(rt_mgpu& M, Rank& R, const FrameCmd& c)
+{
+  const int64_t s = c.seq; const int slot = int(s % RING);
+  const int f = c.frames, cur = f & 1, last = cur ^ 1, H = M.H;
+  const int y0 = c.bands[R.id], y1 = c.bands[R.id + 1];
+  const bool multi = M.n > 1;
+  R.aIssued = s;
+  if(R.mode != 2) { MG_CHECK(rt_set_overlap(R.ctx, 2), "rt_set_overlap"); R.mode = 2; }   // short LDS traversal stacks: kernels of two frames share the CUs
+  R.accSlot = int(s & 1);
+  for(auto& p : R.pulledBy[s & 1]) p = 0;
+  harvestTiming(R, s - 3);
+  MG_CHECK(rt_rotate_buffers(R.ctx, f), "rt_rotate_buffers");   // G-buffer x3, motion x2: direct(f) must not overwrite what indirect(f-1) still reads
+  R.rotatedFor = f;
+  { void* p = nullptr; size_t b = 0, pitch = 0; MG_CHECK(rt_device_ptr(R.ctx, RT_BUF_GBUFFER0 + cur, &p, &b, &pitch), "rt_device_ptr"); R.gptr[slot] = p; }
+  waitAll(M, R, R.stream, Rank::E_D, s - 1, false);     // history rows come from the neighbours' direct(f-1); they have also pulled what direct(f) overwrites
+  waitAll(M, R, R.stream, Rank::E_I, s - 2, true);      // G(f-3) / motion(f-2): read by indirect(f-2), here and (history rows) next door
+  waitAll(M, R, R.stream, Rank::E_DONE, s - 2, true);   // result image / filter scratch of f-2
+  if(multi && c.gather && s >= 2) { hostWaitIssued(M, M.ranks[0], Rank::E_G, s - 2); MG_HIP(hipStreamWaitEvent(R.stream, M.ranks[0].evp[Rank::E_G][(s - 2) % RING], 0), "hipStreamWaitEvent"); }
+  MG_CHECK(rt_set_stream(R.ctx, R.stream), "rt_set_stream");
+  MG_CHECK(rt_set_camera(R.ctx, &c.cam), "rt_set_camera");
+  if(multi && c.haveHistory) {
+    const int gs = s >= 1 ? int((s - 1) % RING) : -1;   // (first frame after a restart: everything is drained, the boundary ids name last frame's buffers on every rank)
+    const int HIST_HALO = c.histHalo;
+    if(!(c.samePartition && HIST_HALO <= HALO_GBUFFER_FULL)) pullRowsOn(M, R, R.stream, RT_BUF_GBUFFER0 + last, y0 - HIST_HALO, y1 + HIST_HALO, c.prev, HK_HISTORY, gs);
+    for(int buf : {RT_BUF_DIRECT_RESV0 + last, RT_BUF_LIGHT_ID0 + last}) pullRowsOn(M, R, R.stream, buf, y0 - HIST_HALO, y1 + HIST_HALO, c.prev, HK_HISTORY);
+    for(int buf : {RT_BUF_DIRECT_RESV0 + cur, RT_BUF_LIGHT_ID0 + cur, int(RT_BUF_DIRECT_RESV_TEMP)}) pullRowsOn(M, R, R.stream, buf, y0, y1, c.prev, HK_MOVED);
+  }
+  MG_CHECK(rt_set_history_rows(R.ctx, multi ? std::max(0, y0 - c.histHalo) : 0, multi ? std::min(H, y1 + c.histHalo) : H), "rt_set_history_rows");
+  MG_HIP(hipEventRecord(R.tm[slot][0], R.stream), "hipEventRecord");
+  runStage(M, R, c.st, f, RT_STAGE_DIRECT, 0, y0, y1, H);
+  MG_HIP(hipEventRecord(R.tm[slot][1], R.stream), "hipEventRecord");
+}
+
+// ---- C. validate direct(f): the host waits for ITS OWN main stream; a miss is repaired by this rank alone -------------------------------------------------
+void pipeValidateDirect(rt_mgpu& M, Rank& R, const FrameCmd& c)
+{
+  const int64_t s = c.seq;
+  const int f = c.frames, last = (f & 1) ^ 1, H = M.H;
+  const int y0 = c.bands[R.id], y1 = c.bands[R.id + 1];
+  const bool multi = M.n > 1;
+  R.accSlot = int(s & 1);
+  MG_CHECK(rt_set_stream(R.ctx, R.stream), "rt_set_stream");
+  MG_CHECK(rt_set_camera(R.ctx, &c.cam), "rt_set_camera");
+  int miss = 0;
+  MG_CHECK(rt_history_miss_stage(R.ctx, RT_STAGE_DIRECT, &miss), "rt_history_miss_stage");
+  if(miss && multi && c.haveHistory) {
+    const int gs = s >= 1 ? int((s - 1) % RING) : -1;
+    pullRowsOn(M, R, R.stream, RT_BUF_GBUFFER0 + last, 0, H, c.prev, HK_FALLBACK, gs);
+    for(int buf : {RT_BUF_DIRECT_RESV0 + last, RT_BUF_LIGHT_ID0 + last}) pullRowsOn(M, R, R.stream, buf, 0, H, c.prev, HK_FALLBACK);
+    MG_CHECK(rt_set_history_rows(R.ctx, 0, H), "rt_set_history_rows");
+    runStage(M, R, c.st, f, RT_STAGE_DIRECT, 0, y0, y1, H);
+    MG_CHECK(rt_history_miss_stage(R.ctx, RT_STAGE_DIRECT, &miss), "rt_history_miss_stage");   // clears, waits
+    M.fallbacks++;
+  }
+  recordIssued(M, R, Rank::E_D, s, R.stream);
+}
+
+// ---- D. indirect(f) on the ind stream, E. direct filters of frame f on the side stream (after the second half of f-1) ------------------------------------
+void pipeIndirectAndDirectFilters(rt_mgpu& M, Rank& R, const FrameCmd& c)
+{
+  const int64_t s = c.seq; const int slot = int(s % RING);
+  const int f = c.frames, cur = f & 1, last = cur ^ 1, H = M.H, Hh = H / 2;
+  const int y0 = c.bands[R.id], y1 = c.bands[R.id + 1], h0 = std::min(y0 / 2, Hh), h1 = std::min(y1 / 2, Hh);
+  const bool multi = M.n > 1;
+  R.accSlot = int(s & 1);
+  MG_CHECK(rt_set_camera(R.ctx, &c.cam), "rt_set_camera");
+  // if the next frame's direct stage has already been issued (look-ahead), the boundary ids of the rotating buffers name ITS buffers: name this frame's again
+  const bool ahead = R.rotatedFor != f;
+  if(ahead) MG_CHECK(rt_rotate_buffers(R.ctx, R.rotatedFor), "rt_rotate_buffers");
+  MG_HIP(hipStreamWaitEvent(R.sInd, R.evp[Rank::E_D][slot], 0), "hipStreamWaitEvent");
+  waitAll(M, R, R.sInd, Rank::E_I, s - 1, false);       // the neighbours' indirect reservoirs of f-1
+  waitAll(M, R, R.sInd, Rank::E_XI, s - 1, false);      // the noisy-indirect scratch of f-1: pulled next door ...
+  if(s >= 1) MG_HIP(hipStreamWaitEvent(R.sInd, R.evp[Rank::E_DONE][(s - 1) % RING], 0), "hipStreamWaitEvent");   // ... and filtered here
+  MG_CHECK(rt_set_stream(R.ctx, R.sInd), "rt_set_stream");
+  if(multi && c.haveHistory) {
+    pullRowsOn(M, R, R.sInd, RT_BUF_INDIRECT_RESV0 + last, h0 - c.histHalo / 2, h1 + c.histHalo / 2, c.prev, HK_HISTORY);
+    pullRowsOn(M, R, R.sInd, RT_BUF_INDIRECT_RESV0 + cur, h0, h1, c.prev, HK_MOVED);
+  }
+  MG_CHECK(rt_set_history_rows(R.ctx, multi ? std::max(0, y0 - c.histHalo) : 0, multi ? std::min(H, y1 + c.histHalo) : H), "rt_set_history_rows");
+  MG_HIP(hipEventRecord(R.tm[slot][2], R.sInd), "hipEventRecord");
+  runStage(M, R, c.st, f, RT_STAGE_INDIRECT, 0, h0, h1, Hh);
+  MG_CHECK(rt_set_stream(R.ctx, R.sSide), "rt_set_stream");
+  waitAll(M, R, R.sSide, Rank::E_D, s, true);
+  MG_HIP(hipEventRecord(R.tm[slot][4], R.sSide), "hipEventRecord");
+  if(multi && c.st.denoise > 0) {
+    pullFilterHaloDirect(M, R, R.sSide, cur, y0, y1, c.bands, slot);
+  }
+  recordIssued(M, R, Rank::E_X, s, R.sSide);
+  if(c.st.denoise > 0) {
+    for(int l = 0; l < 3; l++) { const int g = multi ? DIRECT_GROW[l] : 0; runStage(M, R, c.st, f, RT_STAGE_DENOISE_DIRECT, l, y0 - g, y1 + g, H); }
+    if(multi) waitAll(M, R, R.sSide, Rank::E_X, s, false);   // level 3 writes the result image: every neighbour has its copy of this band's noisy rows
+    runStage(M, R, c.st, f, RT_STAGE_DENOISE_DIRECT, 3, y0, y1, H);
+  } else if(multi) waitAll(M, R, R.sSide, Rank::E_X, s, false);
+  MG_HIP(hipEventRecord(R.tm[slot][5], R.sSide), "hipEventRecord");
+  if(ahead) MG_CHECK(rt_rotate_buffers(R.ctx, R.rotatedFor), "rt_rotate_buffers");
+  R.prevCmd = c; R.havePrev = true;
+}
+
+// look-ahead only when it cannot block this rank's host thread: every event pipeDirect(next) waits for has been recorded
+bool peersReadyForDirect(rt_mgpu& M, Rank& R, const FrameCmd& next)
+{
+  const int64_t s = next.seq;
+  for(int q = 0; q < M.n; q++) {
+    if(q == R.id) continue;
+    Rank& Q = M.ranks[q];
+    if(Q.issued[Rank::E_D].load(std::memory_order_acquire) < s - 1 || Q.issued[Rank::E_I].load(std::memory_order_acquire) < s - 2 ||
+       Q.issued[Rank::E_DONE].load(std::memory_order_acquire) < s - 2) return false;
+  }
+  if(M.n > 1 && next.gather && M.ranks[0].issued[Rank::E_G].load(std::memory_order_acquire) < s - 2) return false;
+  return true;
+}
+
+// One frame of the frames-in-flight schedule.  `next`: the frame after this one if the application has already queued it — its direct stage is then issued
+// as soon as this frame's direct stage is validated, BEFORE this frame's indirect stage and filters, so the main stream never waits for the host.
+void framePipelined(rt_mgpu& M, Rank& R, const FrameCmd& c, const FrameCmd* next)
+{
+  const int64_t s = c.seq;
+  if(c.solo >= 0 && c.solo != R.id) {   // measurement: this rank sits the frame out; its flags must not hold the others back
+    R.havePrev = false;
+    for(auto& a : R.issued) a.store(s, std::memory_order_release);
+    return;
+  }
+  if(R.aIssued != s) pipeDirect(M, R, c);
+  // second half of frame f-1, issued while direct(f) runs (the ids of the rotating buffers name frame f's: finishPrev undoes that for a re-run only)
+  finishPrev(M, R, R.rotatedFor);
+  pipeValidateDirect(M, R, c);
+  static const int ahead = getenv("RESTIR_MGPU_AHEAD") ? atoi(getenv("RESTIR_MGPU_AHEAD")) : 1;
+  if(ahead && next && next->seq == s + 1 && !(next->solo >= 0 && next->solo != R.id) && peersReadyForDirect(M, R, *next)) pipeDirect(M, R, *next);
+  pipeIndirectAndDirectFilters(M, R, c);
+}
+
+void drainRank(rt_mgpu& M, Rank& R)
+{
+  finishPrev(M, R, -1);
+  syncRank(M, R);
+  if(R.ctx) { MG_CHECK(rt_set_stream(R.ctx, R.stream), "rt_set_stream"); MG_CHECK(rt_sync(R.ctx), "rt_sync"); }
 }
 
 void worker(rt_mgpu* Mp, int id)
@@ -249,31 +582,89 @@ void worker(rt_mgpu* Mp, int id)
   Rank& R = M.ranks[id];
   (void)hipSetDevice(R.dev);
   for(;;) {
-    M.start.wait();
-    const rt_mgpu::Cmd cmd = M.cmd;
-    if(cmd == rt_mgpu::QUIT) break;
-    R.rc = RT_OK;
-    switch(cmd) {
-      case rt_mgpu::UPLOAD:
+    Cmd cmd;
+    {
+      std::unique_lock<std::mutex> l(R.qm);
+      R.qcv.wait(l, [&] { return !R.q.empty(); });
+      cmd = R.q.front();
+    }
+    if(cmd.kind == Cmd::QUIT) break;
+    switch(cmd.kind) {
+      case Cmd::UPLOAD:
         MG_CHECK(rt_upload_scene(R.ctx, M.desc), "rt_upload_scene");
-        if(R.rc == RT_OK) MG_CHECK(rt_build_accel(R.ctx), "rt_build_accel");
+        if(R.rc == RT_OK) { std::lock_guard<std::mutex> one(M.buildTurn); MG_CHECK(rt_build_accel(R.ctx), "rt_build_accel"); }   // the host build is multi-threaded itself
         break;
-      case rt_mgpu::RESIZE: MG_CHECK(rt_resize(R.ctx, M.W, M.H), "rt_resize"); break;
-      case rt_mgpu::FRAME: frameOnRank(M, R); break;
-      case rt_mgpu::SYNC: MG_CHECK(rt_sync(R.ctx), "rt_sync"); break;
+      case Cmd::RESIZE: MG_CHECK(rt_resize(R.ctx, M.W, M.H), "rt_resize"); break;
+      case Cmd::FRAME: frameOnRank(M, R, cmd.f); break;
+      case Cmd::FRAMEP: {
+        Cmd nextCmd; bool haveNext = false;
+        {
+          std::lock_guard<std::mutex> l(R.qm);
+          if(R.q.size() >= 2 && R.q[1].kind == Cmd::FRAMEP) { nextCmd = R.q[1]; haveNext = true; }
+        }
+        framePipelined(M, R, cmd.f, haveNext ? &nextCmd.f : nullptr);
+        break;
+      }
+      case Cmd::DRAIN: drainRank(M, R); break;
       default: break;
     }
-    M.done.wait();
+    {
+      std::lock_guard<std::mutex> l(R.qm);
+      R.q.pop_front();
+    }
+    R.qcv.notify_all();
+    {
+      std::lock_guard<std::mutex> l(M.pm);
+      M.pending--;
+    }
+    M.pcv.notify_all();
   }
 }
 
-int dispatch(rt_mgpu* M, rt_mgpu::Cmd cmd)
+void post(rt_mgpu* M, const Cmd& cmd, size_t maxQueued)
 {
-  M->cmd = cmd;
-  M->start.wait();
-  M->done.wait();
+  for(Rank& R : M->ranks) {
+    std::unique_lock<std::mutex> l(R.qm);
+    R.qcv.wait(l, [&] { return R.q.size() < maxQueued; });
+    R.q.push_back(cmd);
+    { std::lock_guard<std::mutex> p(M->pm); M->pending++; }
+    l.unlock();
+    R.qcv.notify_all();
+  }
+}
+void waitIdle(rt_mgpu* M)
+{
+  std::unique_lock<std::mutex> l(M->pm);
+  M->pcv.wait(l, [&] { return M->pending == 0; });
+}
+int firstError(rt_mgpu* M)
+{
   for(const Rank& R : M->ranks) if(R.rc != RT_OK) return R.rc;
   return RT_OK;
+}
+// run `kind` on every rank and wait for it
+int dispatch(rt_mgpu* M, Cmd::Kind kind, const FrameCmd* f = nullptr)
+{
+  Cmd c; c.kind = kind; if(f) c.f = *f;
+  post(M, c, 1u << 20);
+  waitIdle(M);
+  return firstError(M);
+}
+// finish every frame in flight (their deferred second halves included)
+int drainAll(rt_mgpu* M)
+{
+  if(!M->pipeActive) { waitIdle(M); return firstError(M); }
+  M->pipeActive = false;
+  return dispatch(M, Cmd::DRAIN);
+}
+struct DeviceGuard {   // entry points called on the application's thread leave its current device alone
+  int dev = -1;
+  DeviceGuard() { if(hipGetDevice(&dev) != hipSuccess) dev = -1; }
+  ~DeviceGuard() { if(dev >= 0) (void)hipSetDevice(dev); }
+};
+void beginCall(rt_mgpu* M)
+{
+  if(firstError(M) == RT_OK && !M->abort.load()) { std::lock_guard<std::mutex> l(M->errLock); M->err.clear(); }
 }
 
 void equalBands(rt_mgpu* M)
@@ -299,6 +690,17 @@ void rebalance(rt_mgpu* M)
   std::vector<int> nb(size_t(n) + 1, 0);
   rt_mgpu_plan_bands(M->H, n, M->stripeCost.data(), M->bands.data(), 2, nb.data());
   M->bands = nb;
+}
+
+void destroyRank(Rank& R)
+{
+  (void)hipSetDevice(R.dev);
+  if(R.ctx) rt_destroy(R.ctx);
+  for(auto& e : R.ev) if(e) (void)hipEventDestroy(e);
+  for(auto& k : R.evp) for(auto& e : k) if(e) (void)hipEventDestroy(e);
+  for(auto& k : R.tm) for(auto& e : k) if(e) (void)hipEventDestroy(e);
+  for(hipStream_t s : {R.stream, R.sInd, R.sSide, R.sCopy}) if(s) (void)hipStreamDestroy(s);
+  R.ctx = nullptr;
 }
 
 }  // namespace
@@ -335,19 +737,32 @@ int rt_mgpu_plan_bands(int height, int numRanks, const float* stripeCost, const 
 int rt_mgpu_create(rt_mgpu** out, int numRanks, const int* devices)
 {
   if(!out || numRanks < 1 || numRanks > MAX_RANKS) return RT_ERR_INVALID_ARG;
+  DeviceGuard guard;
   rt_mgpu* M = new(std::nothrow) rt_mgpu();
   if(!M) return RT_ERR_OOM;
   M->n = numRanks;
-  M->ranks.resize(size_t(numRanks));
+  M->ranks = std::vector<Rank>(size_t(numRanks));
+  auto bail = [&](int rc) { for(Rank& R : M->ranks) destroyRank(R); delete M; return rc; };
   for(int r = 0; r < numRanks; r++) {
     Rank& R = M->ranks[size_t(r)];
     R.id = r; R.dev = devices ? devices[r] : r;
     int rc = rt_create(&R.ctx, R.dev);
-    if(rc != RT_OK) { for(int q = 0; q < r; q++) rt_destroy(M->ranks[size_t(q)].ctx); delete M; return rc; }
+    if(rc != RT_OK) return bail(rc);
     (void)hipSetDevice(R.dev);
-    bool ok = hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking) == hipSuccess;
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    // stream priorities (RESTIR_MGPU_PRIO: 0 none, 1 indirect stream high, 2 main stream high (default)).  Measured per-rank periods of the 8-way 1080p
+    // benchmark frame (profiles/r03_mgpu_period_ab.txt): slowest rank 1.91 / 1.80 / 1.63 ms for 0 / 1 / 2 — the direct stage of frame f+1 is what the
+    // next frame of EVERY rank waits for
+    static const int prio = getenv("RESTIR_MGPU_PRIO") ? atoi(getenv("RESTIR_MGPU_PRIO")) : 2;
+    const bool can = hi < lo;
+    bool ok = (can && prio == 2 ? hipStreamCreateWithPriority(&R.stream, hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking)) == hipSuccess;
+    ok = ok && (can && prio == 1 ? hipStreamCreateWithPriority(&R.sInd, hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(&R.sInd, hipStreamNonBlocking)) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&R.sSide, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&R.sCopy, hipStreamNonBlocking) == hipSuccess;
     for(auto& e : R.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
-    if(!ok) { for(int q = 0; q <= r; q++) rt_destroy(M->ranks[size_t(q)].ctx); delete M; return RT_ERR_HIP; }
+    for(auto& k : R.evp) for(auto& e : k) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    for(auto& k : R.tm) for(auto& e : k) ok = ok && hipEventCreate(&e) == hipSuccess;
+    if(!ok) return bail(RT_ERR_HIP);
     rt_set_stream(R.ctx, R.stream);
     rt_set_overlap(R.ctx, 0);   // stages are issued one by one through rt_run_stage
   }
@@ -359,7 +774,8 @@ int rt_mgpu_create(rt_mgpu** out, int numRanks, const int* devices)
       int can = 0;
       if(hipDeviceCanAccessPeer(&can, da, db) == hipSuccess && can) { (void)hipSetDevice(da); (void)hipDeviceEnablePeerAccess(db, 0); (void)hipGetLastError(); }
     }
-  M->start.init(numRanks + 1); M->done.init(numRanks + 1); M->step.init(numRanks);
+  M->step.init(numRanks);
+  if(const char* e = getenv("RESTIR_MGPU_PIPELINE")) M->pipeline = atoi(e) != 0;
   for(int r = 0; r < numRanks; r++) M->ranks[size_t(r)].th = std::thread(worker, M, r);
   *out = M;
   return RT_OK;
@@ -368,14 +784,13 @@ int rt_mgpu_create(rt_mgpu** out, int numRanks, const int* devices)
 int rt_mgpu_destroy(rt_mgpu* M)
 {
   if(!M) return RT_ERR_INVALID_ARG;
-  M->cmd = rt_mgpu::QUIT;
-  M->start.wait();
+  DeviceGuard guard;
+  (void)drainAll(M);
+  Cmd quit; quit.kind = Cmd::QUIT;
+  for(Rank& R : M->ranks) { { std::lock_guard<std::mutex> l(R.qm); R.q.push_back(quit); } R.qcv.notify_all(); }
   for(Rank& R : M->ranks) {
     if(R.th.joinable()) R.th.join();
-    (void)hipSetDevice(R.dev);
-    rt_destroy(R.ctx);
-    for(auto& e : R.ev) if(e) (void)hipEventDestroy(e);
-    if(R.stream) (void)hipStreamDestroy(R.stream);
+    destroyRank(R);
   }
   delete M;
   return RT_OK;
@@ -384,8 +799,11 @@ int rt_mgpu_destroy(rt_mgpu* M)
 int rt_mgpu_upload_scene(rt_mgpu* M, const rt_scene_desc* d)
 {
   if(!M || !d) return RT_ERR_INVALID_ARG;
+  DeviceGuard guard;
+  beginCall(M);
+  (void)drainAll(M);
   M->desc = d;
-  const int rc = dispatch(M, rt_mgpu::UPLOAD);
+  const int rc = dispatch(M, Cmd::UPLOAD);
   M->desc = nullptr; M->haveHistory = false;
   return rc;
 }
@@ -394,12 +812,16 @@ int rt_mgpu_resize(rt_mgpu* M, int w, int h)
 {
   if(!M || w <= 0 || h <= 0) return RT_ERR_INVALID_ARG;
   if((h + 15) / 16 < M->n) { M->err = "rt_mgpu_resize: fewer 16-row stripes than ranks"; return RT_ERR_INVALID_ARG; }
+  DeviceGuard guard;
+  beginCall(M);
+  (void)drainAll(M);
   M->W = w; M->H = h;
-  const int rc = dispatch(M, rt_mgpu::RESIZE);
+  const int rc = dispatch(M, Cmd::RESIZE);
   equalBands(M);
   M->prevBands = M->bands;
   M->stripeCost.clear();
   M->haveHistory = false;
+  for(Rank& R : M->ranks) for(auto& g : R.gptr) g = nullptr;
   return rc;
 }
 
@@ -414,16 +836,46 @@ int rt_mgpu_render_frame(rt_mgpu* M, const rt_state* st, int frames)
 {
   if(!M || !st) return RT_ERR_INVALID_ARG;
   if(M->W == 0) { M->err = "rt_mgpu_render_frame: rt_mgpu_resize has not been called"; return RT_ERR_NO_TARGET; }
-  M->st = *st; M->frames = frames;
-  const int rc = dispatch(M, rt_mgpu::FRAME);
-  // statistics of this frame, then the partition of the next one
+  DeviceGuard guard;
+  beginCall(M);
+  const bool spatial = st->ReSTIRState == RT_RESTIR_SPATIAL || st->ReSTIRState == RT_RESTIR_SPATIOTEMPORAL;
+  const bool pipe = M->pipeline && !M->serialize && !(spatial && M->n > 1);
+  // the frames in flight assume consecutive frames (ping-pong parity, rotating G-buffers): anything else restarts the pipeline
+  if(M->pipeActive && (!pipe || frames != M->lastFrames + 1)) { const int rc = drainAll(M); if(rc != RT_OK) return rc; }
+  FrameCmd c;
+  c.st = *st; c.frames = frames; c.cam = M->cam; c.haveHistory = M->haveHistory; c.gather = M->gatherResults; c.solo = M->solo;
+  for(int r = 0; r <= M->n; r++) { c.bands[r] = M->bands[size_t(r)]; c.prev[r] = M->prevBands[size_t(r)]; }
+  {  // history halo of this frame (see HIST_HALO_MIN): widened after a fallback, narrowed again after a calm stretch
+    const uint32_t fb = M->fallbacks.load();
+    if(fb != M->fallbacksSeen) { M->fallbacksSeen = fb; M->calmFrames = 0; M->histHalo = std::min(HIST_HALO_MAX, M->histHalo * 2); }
+    else if(++M->calmFrames >= HIST_HALO_CALM) { M->calmFrames = 0; M->histHalo = std::max(HIST_HALO_MIN, M->histHalo / 2); }
+    c.histHalo = M->histHalo;
+    c.samePartition = M->haveHistory && M->lastDenoise && M->bands == M->prevBands;
+    M->lastDenoise = st->denoise > 0;
+  }
+  int rc = RT_OK;
+  if(pipe) {
+    if(!M->pipeActive) { M->seq = 0; for(Rank& R : M->ranks) { for(auto& a : R.issued) a.store(-1); R.havePrev = false; R.aIssued = -1; } M->pipeActive = true; }
+    c.seq = M->seq++;
+    Cmd cmd; cmd.kind = Cmd::FRAMEP; cmd.f = c;
+    post(M, cmd, 2);               // at most two frames queued per rank: the call returns while the frame is being issued
+    rc = firstError(M);
+  } else {
+    rc = dispatch(M, Cmd::FRAME, &c);
+  }
+  M->lastFrames = frames;
+  // statistics of the latest finished frame, then the partition of the next one
   rt_mgpu_stats& S = M->stats;
-  S.numRanks = M->n; S.frames++;
+  S.numRanks = M->n;
+  if(rc != RT_OK) return rc;
+  S.frames++;
   S.haloBytes = 0;
+  for(auto& k : S.haloBytesKind) k = 0;
+  S.historyFallbacks = M->fallbacks.load();
   for(int r = 0; r < M->n; r++) {
     S.bandBegin[r] = M->bands[size_t(r)]; S.bandEnd[r] = M->bands[size_t(r) + 1];
     S.tracedMs[r] = M->ranks[size_t(r)].tracedMs; S.filterMs[r] = M->ranks[size_t(r)].filterMs;
-    S.haloBytes += M->ranks[size_t(r)].pulled;
+    for(int k = 0; k < HK_COUNT; k++) { S.haloBytes += M->ranks[size_t(r)].lastPulled[k]; S.haloBytesKind[k] += M->ranks[size_t(r)].lastPulled[k]; S.haloBytesRankKind[r][k] = M->ranks[size_t(r)].lastPulled[k]; }
   }
   M->prevBands = M->bands;
   M->haveHistory = true;
@@ -431,17 +883,58 @@ int rt_mgpu_render_frame(rt_mgpu* M, const rt_state* st, int frames)
   return rc;
 }
 
-int rt_mgpu_sync(rt_mgpu* M) { return M ? dispatch(M, rt_mgpu::SYNC) : RT_ERR_INVALID_ARG; }
+int rt_mgpu_sync(rt_mgpu* M)
+{
+  if(!M) return RT_ERR_INVALID_ARG;
+  DeviceGuard guard;
+  beginCall(M);
+  int rc = drainAll(M);
+  if(rc == RT_OK) rc = dispatch(M, Cmd::DRAIN);
+  return rc;
+}
 
 int rt_mgpu_set_balance(rt_mgpu* M, int mode)
 {
-  if(!M) return RT_ERR_INVALID_ARG;
-  M->balance = mode != 0;
-  if(!M->balance && M->H) { equalBands(M); /* the next frame pulls what moved through the history exchange */ }
+  if(!M || mode < 0 || mode > 2) return RT_ERR_INVALID_ARG;
+  M->balance = mode == 1;
+  if(mode == 0 && M->H) { equalBands(M); /* the next frame pulls what moved through the history exchange */ }
+  return RT_OK;   // mode 2: keep the partition as it is now
+}
+// explicit partition (n + 1 boundaries, multiples of 16, first 0, last the image height); implies "freeze" (rt_mgpu_set_balance(m, 2)).  The rows that change
+// owner travel with the next frame's history pulls.
+int rt_mgpu_set_bands(rt_mgpu* M, const int* bands)
+{
+  if(!M || !bands || M->H == 0) return RT_ERR_INVALID_ARG;
+  if(bands[0] != 0 || bands[M->n] != M->H) return RT_ERR_INVALID_ARG;
+  for(int r = 0; r < M->n; r++) if(bands[r + 1] <= bands[r] || (bands[r] & 15)) return RT_ERR_INVALID_ARG;
+  M->bands.assign(bands, bands + M->n + 1);
+  M->balance = false;
   return RT_OK;
 }
 int rt_mgpu_set_serialize(rt_mgpu* M, int on) { if(!M) return RT_ERR_INVALID_ARG; M->serialize = on != 0; return RT_OK; }
-int rt_mgpu_get_stats(rt_mgpu* M, rt_mgpu_stats* out) { if(!M || !out) return RT_ERR_INVALID_ARG; *out = M->stats; return RT_OK; }
+int rt_mgpu_set_pipeline(rt_mgpu* M, int on) { if(!M) return RT_ERR_INVALID_ARG; M->pipeline = on != 0; return RT_OK; }
+int rt_mgpu_set_gather(rt_mgpu* M, int on) { if(!M) return RT_ERR_INVALID_ARG; M->gatherResults = on != 0; return RT_OK; }
+int rt_mgpu_set_solo(rt_mgpu* M, int rank) { if(!M || rank >= M->n) return RT_ERR_INVALID_ARG; M->solo = rank < 0 ? -1 : rank; return RT_OK; }
+int rt_mgpu_get_stats(rt_mgpu* M, rt_mgpu_stats* out)
+{
+  if(!M || !out) return RT_ERR_INVALID_ARG;
+  {   // the numbers of the latest complete frame (finishes what is in flight)
+    DeviceGuard guard;
+    const bool wasActive = M->pipeActive;
+    (void)drainAll(M);
+    rt_mgpu_stats& S = M->stats;
+    S.haloBytes = 0; for(auto& k : S.haloBytesKind) k = 0;
+    S.historyFallbacks = M->fallbacks.load();
+    for(int r = 0; r < M->n; r++) {
+      Rank& R = M->ranks[size_t(r)];
+      if(wasActive) harvestTiming(R, M->seq - 1);
+      S.tracedMs[r] = R.tracedMs; S.filterMs[r] = R.filterMs;
+      for(int k = 0; k < HK_COUNT; k++) { S.haloBytes += R.lastPulled[k]; S.haloBytesKind[k] += R.lastPulled[k]; S.haloBytesRankKind[r][k] = R.lastPulled[k]; }
+    }
+  }
+  *out = M->stats;
+  return RT_OK;
+}
 const char* rt_mgpu_last_error(rt_mgpu* M) { return (M && !M->err.empty()) ? M->err.c_str() : ""; }
 
 // Assemble a buffer of the LAST rendered frame from the ranks that own its rows (caller-side layout == rt_readback's).
@@ -449,6 +942,9 @@ int rt_mgpu_readback(rt_mgpu* M, int buffer, void* dst, size_t bytes)
 {
   if(!M || !dst || buffer < 0 || buffer >= RT_BUF_COUNT) return RT_ERR_INVALID_ARG;
   if(M->W == 0) return RT_ERR_NO_TARGET;
+  DeviceGuard guard;
+  beginCall(M);
+  { const int rc = drainAll(M); if(rc != RT_OK) return rc; }
   const size_t want = rt_buffer_bytes(M->ranks[0].ctx, buffer);
   if(bytes != want) { M->err = "rt_mgpu_readback: size mismatch"; return RT_ERR_INVALID_ARG; }
   const bool indTemp = buffer == RT_BUF_DENOISE_IND_A || buffer == RT_BUF_DENOISE_IND_B;

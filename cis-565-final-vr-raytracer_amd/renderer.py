@@ -17,7 +17,7 @@ ABI_SYMBOLS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "r
                "rt_render_frame", "rt_run_stage", "rt_readback", "rt_upload_history", "rt_buffer_bytes", "rt_device_ptr",
                "rt_set_counting", "rt_get_counters", "rt_sync", "rt_last_error", "rt_abi_version", "rt_set_traversal", "rt_set_history_rows", "rt_history_miss", "rt_set_overlap", "rt_tonemap", "rt_set_sun_and_sky", "rt_pick", "rt_history_miss_stage", "rt_rotate_buffers", "rt_measure_valu_peak",
                "rt_mgpu_create", "rt_mgpu_destroy", "rt_mgpu_upload_scene", "rt_mgpu_resize", "rt_mgpu_set_camera", "rt_mgpu_render_frame", "rt_mgpu_readback",
-               "rt_mgpu_sync", "rt_mgpu_set_balance", "rt_mgpu_set_serialize", "rt_mgpu_get_stats", "rt_mgpu_last_error", "rt_mgpu_plan_bands"]
+               "rt_mgpu_sync", "rt_mgpu_set_balance", "rt_mgpu_set_serialize", "rt_mgpu_set_pipeline", "rt_mgpu_set_gather", "rt_mgpu_set_solo", "rt_mgpu_set_bands", "rt_mgpu_get_stats", "rt_mgpu_last_error", "rt_mgpu_plan_bands"]
 
 
 def hip_lib():
@@ -73,6 +73,10 @@ def hip_lib():
         L.rt_mgpu_readback.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         L.rt_mgpu_set_balance.argtypes = [C.c_void_p, C.c_int]
         L.rt_mgpu_set_serialize.argtypes = [C.c_void_p, C.c_int]
+        L.rt_mgpu_set_pipeline.argtypes = [C.c_void_p, C.c_int]
+        L.rt_mgpu_set_gather.argtypes = [C.c_void_p, C.c_int]
+        L.rt_mgpu_set_solo.argtypes = [C.c_void_p, C.c_int]
+        L.rt_mgpu_set_bands.argtypes = [C.c_void_p, C.c_void_p]
         L.rt_mgpu_get_stats.argtypes = [C.c_void_p, C.c_void_p]
         L.rt_mgpu_last_error.argtypes = [C.c_void_p]; L.rt_mgpu_last_error.restype = C.c_char_p
         L.rt_mgpu_plan_bands.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
@@ -233,7 +237,7 @@ class Renderer:
 
 class MgpuStats(C.Structure):  # rt_mgpu_stats
     _fields_ = [("numRanks", C.c_int32), ("frames", C.c_uint32), ("historyFallbacks", C.c_uint32), ("pad", C.c_uint32), ("haloBytes", C.c_uint64),
-                ("bandBegin", C.c_int32 * 16), ("bandEnd", C.c_int32 * 16), ("tracedMs", C.c_float * 16), ("filterMs", C.c_float * 16)]
+                ("bandBegin", C.c_int32 * 16), ("bandEnd", C.c_int32 * 16), ("tracedMs", C.c_float * 16), ("filterMs", C.c_float * 16), ("haloBytesKind", C.c_uint64 * 6), ("haloBytesRankKind", (C.c_uint64 * 6) * 16)]
 
 
 class MultiGpuRenderer:
@@ -274,8 +278,23 @@ class MultiGpuRenderer:
     def set_camera(self, cam): self._chk(hip_lib().rt_mgpu_set_camera(self._h, C.byref(cam)), "rt_mgpu_set_camera")
     def run(self, state, frames): self._chk(hip_lib().rt_mgpu_render_frame(self._h, C.byref(state), frames), "rt_mgpu_render_frame")
     def sync(self): self._chk(hip_lib().rt_mgpu_sync(self._h), "rt_mgpu_sync")
-    def set_balance(self, on): self._chk(hip_lib().rt_mgpu_set_balance(self._h, 1 if on else 0), "rt_mgpu_set_balance")
+    def set_balance(self, on): self._chk(hip_lib().rt_mgpu_set_balance(self._h, int(on)), "rt_mgpu_set_balance")   # True / 1: cost weighted, False / 0: equal, 2: freeze
     def set_serialize(self, on): self._chk(hip_lib().rt_mgpu_set_serialize(self._h, 1 if on else 0), "rt_mgpu_set_serialize")
+    def set_pipeline(self, on): self._chk(hip_lib().rt_mgpu_set_pipeline(self._h, 1 if on else 0), "rt_mgpu_set_pipeline")
+    def set_gather(self, on): self._chk(hip_lib().rt_mgpu_set_gather(self._h, 1 if on else 0), "rt_mgpu_set_gather")
+    def set_solo(self, rank): self._chk(hip_lib().rt_mgpu_set_solo(self._h, int(rank)), "rt_mgpu_set_solo")
+    def set_bands(self, bands):
+        arr = (C.c_int * len(bands))(*[int(b) for b in bands])
+        self._chk(hip_lib().rt_mgpu_set_bands(self._h, arr), "rt_mgpu_set_bands")
+    @staticmethod
+    def plan_bands(height, ranks, stripe_cost, prev=None, max_move=-1):
+        cost = (C.c_float * len(stripe_cost))(*[float(x) for x in stripe_cost])
+        pb = (C.c_int * (ranks + 1))(*prev) if prev is not None else None
+        out = (C.c_int * (ranks + 1))()
+        rc = hip_lib().rt_mgpu_plan_bands(height, ranks, cost, pb, max_move, out)
+        if rc != 0:
+            raise RtError(f"rt_mgpu_plan_bands failed ({rc})")
+        return list(out)
     def stats(self):
         s = MgpuStats()
         self._chk(hip_lib().rt_mgpu_get_stats(self._h, C.byref(s)), "rt_mgpu_get_stats")

@@ -414,8 +414,12 @@ int rt_set_overlap(rt_ctx* ctx, int mode);
  * one rt_ctx and one HIP stream per device; halos and history rows move with hipMemcpyPeerAsync over xGMI; band heights
  * are cost weighted from the ranks' measured stage times.  Call order == the single-GPU context's:
  *     rt_mgpu_create -> rt_mgpu_upload_scene (upload + BVH8 build on every device) -> rt_mgpu_resize
- *     per frame: rt_mgpu_set_camera, rt_mgpu_render_frame (returns when the frame is complete on every device)
+ *     per frame: rt_mgpu_set_camera, rt_mgpu_render_frame
  *     rt_mgpu_readback assembles a buffer of the last frame from the ranks that own its rows (same layout as rt_readback).
+ * Frames in flight (default, rt_mgpu_set_pipeline): rt_mgpu_render_frame QUEUES the frame (at most two ahead) and returns; every rank runs the three-stream
+ * schedule of rt_render_frame and every cross-rank dependency is a HIP event another rank's stream waits for — no host barrier per frame.  Frames must be
+ * consecutive (`frames` + 1 per call); rt_mgpu_sync / rt_mgpu_readback / rt_mgpu_get_stats finish what is in flight first.  With rt_mgpu_set_pipeline(0),
+ * in the spatial-reuse modes and under rt_mgpu_set_serialize the call returns when the frame is complete on every device (barrier schedule).
  * Every output is bit-identical to the single-GPU frame, in every ReSTIRState (the spatial-reuse modes run the direct stage in two
  * halves around an exchange of the cached reservoirs' boundary rows).  `devices` may name the same device more than once (used by the
  * tests on a one-GPU machine).  The caller's thread discipline is the reference's: one thread issues the calls.
@@ -432,6 +436,8 @@ typedef struct {
   int32_t bandBegin[RT_MGPU_MAX_RANKS], bandEnd[RT_MGPU_MAX_RANKS]; /* full-res row range of every rank in the last frame */
   float tracedMs[RT_MGPU_MAX_RANKS];             /* direct + indirect stage of the last frame, HIP events on the rank's stream */
   float filterMs[RT_MGPU_MAX_RANKS];             /* 4 + 5 A-Trous passes + compose */
+  uint64_t haloBytesKind[6];                     /* haloBytes by purpose: history rows | filter halos | spatial-reuse rows | rows that changed owner | display gather | fallback pulls */
+  uint64_t haloBytesRankKind[RT_MGPU_MAX_RANKS][6]; /* the same per rank (bytes that rank pulled for its latest complete frame) */
 } rt_mgpu_stats;
 int rt_mgpu_create(rt_mgpu** out, int numRanks, const int* devices /* NULL: devices 0..numRanks-1 */);
 int rt_mgpu_destroy(rt_mgpu* m);
@@ -441,8 +447,12 @@ int rt_mgpu_set_camera(rt_mgpu* m, const rt_scene_camera* cam);
 int rt_mgpu_render_frame(rt_mgpu* m, const rt_state* state, int frames);
 int rt_mgpu_readback(rt_mgpu* m, int buffer, void* dst, size_t bytes);
 int rt_mgpu_sync(rt_mgpu* m);
-int rt_mgpu_set_balance(rt_mgpu* m, int mode);    /* 1 (default): cost-weighted band heights; 0: equal heights */
+int rt_mgpu_set_balance(rt_mgpu* m, int mode);    /* 1 (default): cost-weighted band heights; 0: equal heights; 2: freeze the current partition */
+int rt_mgpu_set_bands(rt_mgpu* m, const int* bands /* numRanks + 1 row boundaries, multiples of 16, 0 .. height */);   /* explicit partition; freezes it */
 int rt_mgpu_set_serialize(rt_mgpu* m, int on);    /* measurement aid when several ranks share ONE device: ranks take turns on the GPU */
+int rt_mgpu_set_pipeline(rt_mgpu* m, int on);     /* 1 (default): frames in flight per rank, event-ordered pulls; 0: barrier schedule */
+int rt_mgpu_set_gather(rt_mgpu* m, int on);       /* 1 (default): rank 0 pulls the result bands every frame (display rank); 0: results stay with their owners */
+int rt_mgpu_set_solo(rt_mgpu* m, int rank);       /* measurement aid: only `rank` renders (its pulls read the idle ranks' stale rows): the PERIOD of one rank on a GPU to itself; -1 = off */
 int rt_mgpu_get_stats(rt_mgpu* m, rt_mgpu_stats* out);
 /* The partition rule on its own (pure host arithmetic): boundaries (numRanks + 1 rows, multiples of 16) that equalise the summed cost of the
  * 16-row stripes; with prevBands a boundary moves at most maxMoveStripes stripes (< 0: unlimited); every rank keeps >= one stripe. */

@@ -32,6 +32,7 @@ def _cams(sc, W, H, n, speed):
 @pytest.mark.parametrize("world,balance,speed,restir", [(3, True, 0.04, 3), (4, False, 0.04, 3), (8, True, 0.04, 3), (3, True, 1.5, 3), (3, True, 0.04, 4), (5, True, 0.04, 2)],
                          ids=["3-balanced", "4-equal", "8-balanced", "3-fast-camera-fallback", "3-spatiotemporal", "5-spatial"])
 def test_mgpu_equals_single_gpu(world, balance, speed, restir):
+    """Every frame read back and compared (the read-back finishes what is in flight, so this is the frame-at-a-time use of the context)."""
     from restir_amd.renderer import Renderer, MultiGpuRenderer
     W, H, frames = 480, 272, 5
     sc, env = make_scene(abi.PROC_BISTRO_EXT, 0.02, 1, (256, 128))
@@ -61,6 +62,41 @@ def test_mgpu_equals_single_gpu(world, balance, speed, restir):
     assert s.numRanks == world and s.frames == frames and s.haloBytes > 0
     assert (s.historyFallbacks > 0) == (speed > 1.0)
     # (whether the cost-weighted partition moves depends on measured stage times; the rule itself is tested on the CPU: tests/test_abi.py)
+    m.destroy(); ref.destroy()
+
+
+@pytest.mark.parametrize("world,balance,speed,gather", [(3, True, 0.04, True), (4, False, 0.04, False), (8, True, 0.04, True), (3, True, 1.5, True), (1, True, 0.04, True)],
+                         ids=["3-balanced", "4-equal-no-gather", "8-balanced", "3-fast-camera-fallback", "1-rank"])
+def test_mgpu_frames_in_flight_equal_single_gpu(world, balance, speed, gather):
+    """Frames in flight: the frames are queued back to back with nothing in between (three streams per rank, cross-rank event waits, deferred second
+    halves, rank-local history fallback, rebalancing while frames are in flight); compared after 6 frames and again after 3 more."""
+    from restir_amd.renderer import Renderer, MultiGpuRenderer
+    W, H, frames = 480, 272, 9
+    sc, env = make_scene(abi.PROC_BISTRO_EXT, 0.02, 1, (256, 128))
+    st = host.default_state(W, H, sc, env)
+    desc = sc.desc(env)
+    cams = _cams(sc, W, H, frames, speed)
+    ref = Renderer().setup(0); ref.load_scene(desc); ref.update(W, H)
+    m = MultiGpuRenderer().setup(_devices(world)); m.load_scene(desc); m.update(W, H)
+    m.set_balance(balance); m.set_pipeline(True); m.set_gather(gather)
+    f = 0
+    for stop in (6, 9):
+        while f < stop:
+            st.time = 800 + f
+            ref.set_camera(cams[f]); ref.run(st, f)
+            m.set_camera(cams[f]); m.run(st, f)
+            f += 1
+        for b in frame_buffers(f - 1):
+            if b in (abi.BUF_DENOISE_DIR_A, abi.BUF_DENOISE_DIR_B, abi.BUF_DENOISE_IND_A, abi.BUF_DENOISE_IND_B):
+                continue
+            got, want = m.readback(b), ref.readback(b)
+            bad = int((got.view(np.uint32) != want.view(np.uint32)).sum())
+            assert bad == 0, (f - 1, abi.BUFFER_NAMES[b], bad)
+    s = m.stats()
+    assert s.numRanks == world and s.frames == frames
+    if world > 1:
+        assert s.haloBytes > 0 and (s.haloBytesKind[4] > 0) == gather
+        assert (s.historyFallbacks > 0) == (speed > 1.0)
     m.destroy(); ref.destroy()
 
 
