@@ -34,20 +34,58 @@ NODE_B, TRI_B, HIT_B, RIS_B = 80, 48, 12 + 96 + 80, 16 + 96
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E
 
 
+# SURVEY.md 8(d) configurations 2-5 (config 1 is the CPU-only plumbing case: tests/test_oracle.py).  The real assets are absent from the image: seeded procedural
+# stand-ins of the same class (host/scene_gen.cpp).
+CONFIGS = {
+    2: {"name": "Cornell box", "kind": "PROC_CORNELL", "size": (512, 512), "env": None, "di_only": True,
+        "state": {"environmentProb": 0.0, "fireflyClampThreshold": 100.0}, "pipeline": "ReSTIR DI only (temporal, M=4, clamp 80): direct stage alone"},
+    3: {"name": "Sponza-class", "kind": "PROC_SPONZA", "size": (1920, 1080), "env": (2048, 1024), "state": {"maxDepth": 2},
+        "pipeline": "ReSTIR DI (temporal, M=4) + GI (maxDepth 2 = one indirect bounce, MIS) + A-Trous 4+5 levels + compose"},
+    4: {"name": "bistro-exterior-class", "kind": "PROC_BISTRO_EXT", "size": (1920, 1080), "env": (2048, 1024),
+        "pipeline": "ReSTIR DI (temporal, M=4) + GI (maxDepth 4, MIS) + A-Trous 4+5 levels + compose"},
+    5: {"name": "bistro-interior-class", "kind": "PROC_BISTRO_INT", "size": (3840, 2160), "env": (512, 256), "orbit": True,
+        "pipeline": "ReSTIR DI (temporal, M=4) + GI (maxDepth 4, MIS) + A-Trous 4+5 levels + compose, temporal reuse under motion"},
+}
+
+
+def lib_sha256_16():
+    import hashlib
+    from restir_amd.renderer import HIP_LIB_PATH
+    with open(HIP_LIB_PATH, "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()[:16]
+
+
+def di_only_roofline(r, abi, st, W, H, first_timed, n_count, ms_per_step):
+    """config 2: the direct stage is the whole step.  Algorithmic bytes as for the headline line; the launch time is the step time (one launch per step)."""
+    r.set_counting(True)
+    for k in range(n_count):
+        st.time = 1000 + first_timed + k
+        r.run_stage(st, first_timed + k, abi.STAGE_DIRECT, 0)
+    r.sync()
+    c2 = r.counters(); r.set_counting(False)
+    b_screen = SCREEN_BYTES[0] * W * H
+    b_trav = (c2.nodesVisited * NODE_B + c2.trisTested * TRI_B + c2.hitsShaded * HIT_B + c2.risCandidates * RIS_B) / float(n_count)
+    ach = (b_screen + b_trav) / (ms_per_step * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "direct_stage", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+            "algorithmic_bytes_per_launch": round(b_screen + b_trav), "screen_bytes": round(b_screen), "traversal_bytes": round(b_trav), "launch_ms": round(ms_per_step, 4),
+            "note": "launch_ms = wall clock per step (launch-to-launch, one direct-stage launch per step): a 512x512 launch is bound by launch rate and latency, not by bandwidth"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--scale", type=float, default=1.0, help="scene tessellation scale (1.0 = the 2.8 M-triangle benchmark scene)")
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--config", type=int, default=4, choices=[2, 3, 4, 5], help="BASELINE.json / SURVEY.md 8(d) configuration (4 = the headline workload)")
+    ap.add_argument("--moving-camera", action="store_true", help="the camera orbits its centre of interest by 0.5 degrees per frame (always on for --config 5)")
+    ap.add_argument("--scale", type=float, default=1.0, help="scene tessellation scale (1.0 = the configuration's triangle count)")
+    ap.add_argument("--width", type=int, default=0, help="default: the configuration's width")
+    ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-run", action="store_true", help="only the warm-up + K timed frames + the counting pass (for rocprofv3 --pmc / --kernel-trace runs)")
     ap.add_argument("--emulate-world", type=int, default=0, help="(1 GPU) N ranks of the native row-tiled frame (rt_mgpu_*) on this device, taking turns: per-rank stage times of a chip to itself")
     ap.add_argument("--equal-bands", action="store_true", help="N > 1 (and --emulate-world): equal-height row bands instead of cost-weighted ones")
     ap.add_argument("--band-rounds", type=int, default=8, help="N > 1: planning rounds of the cost-weighted band heights before the warm-up")
-    ap.add_argument("--cpu-rows", type=int, default=256, help="height of the row band the CPU baseline renders")
     ap.add_argument("--no-period", action="store_true", help="--emulate-world: skip the frames-in-flight period pass")
     ap.add_argument("--period-rounds", type=int, default=4, help="--emulate-world: re-planning rounds of the band heights on the measured per-rank periods")
     args = ap.parse_args()
@@ -75,11 +113,18 @@ def main():
         # a stuck exchange should end the run with an error instead of hanging it
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"), timeout=datetime.timedelta(seconds=300))
 
-    W, H = args.width, args.height
-    scene = host.Scene().makeProcedural(abi.PROC_BISTRO_EXT, args.scale, 1)
-    env = host.HdrSampling()
-    env.makeSyntheticSky(2048, 1024, 5e4, 7)
+    cfg = CONFIGS[args.config]
+    W, H = args.width or cfg["size"][0], args.height or cfg["size"][1]
+    orbit = args.moving_camera or cfg.get("orbit", False)
+    scene = host.Scene().makeProcedural(getattr(abi, cfg["kind"]), args.scale, 1)
+    env = None
+    if cfg["env"]:
+        env = host.HdrSampling()
+        env.makeSyntheticSky(cfg["env"][0], cfg["env"][1], 5e4, 7)
     st = host.default_state(W, H, scene, env)
+    for k, v in cfg.get("state", {}).items():
+        setattr(st, k, v)
+    di_only = cfg.get("di_only", False)
     desc = scene.desc(env)
     r = Renderer().setup(local_rank)
     t0 = time.time()
@@ -97,13 +142,20 @@ def main():
     if world == 1 and args.emulate_world > 1:
         return emulate_world(args, abi, host, scene, env, st, desc, r, W, H, local_rank)
 
-    scene.updateCamera(W, H)  # prime the camera history (static camera: SURVEY.md §8d)
+    eye0, center0, up0, fov0 = scene.cameraPose()
+    scene.updateCamera(W, H)  # prime the camera history (static camera unless --moving-camera / config 5: SURVEY.md §8d)
 
     def step(f):
         st.time = 1000 + f
+        if orbit:   # the camera orbits its centre of interest, 0.5 degrees per frame (src/scene.cpp:777-826 keeps the history matrices)
+            a = np.deg2rad(0.5 * (f + 1))
+            rot = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], dtype=np.float32)
+            scene.setCamera(center0 + rot @ (eye0 - center0), center0, up0, fov0)
         scene.updateCamera(W, H)
         r.set_camera(scene.getCamera())
-        if frame is None:
+        if di_only:
+            r.run_stage(st, f, abi.STAGE_DIRECT, 0)        # config 2: ReSTIR DI only, the indirect stage and the filters are skipped
+        elif frame is None:
             r.run(st, f)
         else:
             frame.render_frame(st, f)
@@ -158,7 +210,7 @@ def main():
     # a sustained pass of >= 1 s of back-to-back frames (the K timed steps above are what `value` reports; at the driver's K = 20 they
     # last 70 ms, too short for any sampling monitor to see the GPU busy): same frames-in-flight schedule, reported beside it
     sustained = None
-    if world == 1 and frame is None and not args.profile_run:
+    if world == 1 and frame is None and not args.profile_run and not di_only:
         n_s = max(args.steps, int(1.0 / max(1e-4, elapsed / args.steps)) + 1)
         t1 = time.perf_counter()
         for _ in range(n_s):
@@ -188,13 +240,13 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         mrays = rays_per_frame * args.steps / elapsed / 1e6
         out = {
-            "metric": "Mrays/s (ClosestHit+AnyHit ray queries per second) of the 1080p ReSTIR DI+GI+denoise frame; ms_per_step = ms/frame",
+            "metric": "Mrays/s (ClosestHit+AnyHit ray queries per second) of the " + ("1080p ReSTIR DI+GI+denoise frame" if args.config == 4 else f"config-{args.config} frame") + "; ms_per_step = ms/frame",
             "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"bistro-exterior-class procedural scene, {scene.getStat()['instancedTriangles']} triangles, {W}x{H}, "
-                                   "ReSTIR DI (temporal, M=4) + GI (maxDepth 4, MIS) + A-Trous 4+5 levels + compose, static camera, "
-                                   "2048x1024 synthetic HDR sky", "width": W, "height": H, "scene_scale": args.scale,
+            "config": {"workload": f"config {args.config}: {cfg['name']} procedural scene, {scene.getStat()['instancedTriangles']} triangles, {W}x{H}, {cfg['pipeline']}, "
+                                   + ("camera orbiting 0.5 deg / frame" if orbit else "static camera") + (f", {cfg['env'][0]}x{cfg['env'][1]} synthetic HDR sky" if cfg["env"] else ", no environment"),
+                       "baseline_config": args.config, "width": W, "height": H, "scene_scale": args.scale,
                        "parallelism": ("single GPU" if frame is None else f"ONE rank of an emulated {args.emulate_world}-way row tiling, communication stubbed (not a benchmark result)") if world == 1 else f"row-tiled x{world}: frames in flight on 3 streams per rank, halo exchanges over RCCL (restir_amd/tiled.py PipelinedTiledFrame), " + ("equal-height bands" if band_plan is None else f"cost-weighted bands {band_plan}"),
                        "rays_per_frame": round(rays_per_frame), "fps": round(1e3 / ms_per_step, 2), "bvh8_build_s": round(build_s, 2),
                        "accel": r.accel_stats()},
@@ -204,14 +256,18 @@ def main():
                               "median over the frames of a separate pass; frame_latency_ms = first launch to last launch of one frame while frames are in flight")
         if sustained:
             out["sustained"] = sustained
-    if world == 1 and timing.framesTimed > 0 and not args.profile_run:
+    if world == 1 and di_only and not args.profile_run:
+        out["roofline"], out["cpu_baseline"] = di_only_roofline(r, abi, st, W, H, first_timed, n_count, elapsed / args.steps * 1e3), None
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(abi, host, scene, env, st, desc, W, H, first_timed, di_only=True)
+    if world == 1 and timing.framesTimed > 0 and not args.profile_run and not di_only:
         stage_ms = [timing.stageMs[i] / max(1, timing.framesTimed) for i in range(5)]
         frame_latency_ms = timing.frameMs / max(1, timing.framesTimed)
         # The timed region runs with frames in flight (rt_set_overlap mode 2): kernels of consecutive frames share the chip,
         # so each launch is stretched while the frame rate goes up.  A short extra pass with every launch alone on one
         # stream gives the un-overlapped duration of the same kernels on the same frames.
         serial_ms = None
-        if frame is None:
+        if frame is None and not di_only:
             r.set_overlap(0)
             for k in range(2):
                 step(first_timed + k)
@@ -246,7 +302,7 @@ def main():
         b_trav = (c2.nodesVisited * NODE_B + c2.trisTested * TRI_B + c2.hitsShaded * HIT_B + c2.risCandidates * RIS_B) / float(n_count) / launches
         dur_ms = stage_ms[dom] / launches
         achieved = (b_screen + b_trav) / (dur_ms * 1e-3) / 1e9
-        kname = {0: "k_direct_stage", 1: "k_indirect_stage", 2: "k_denoise", 3: "k_denoise", 4: "k_compose"}[dom]
+        kname = {0: "k_direct_stage", 1: "k_indirect_stage", 2: "k_denoise_lds<false, true>", 3: "k_denoise_lds<true, true>", 4: "k_compose"}[dom]
         out["roofline"] = {"bound": "hbm", "kernel": STAGE_NAMES[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                            "algorithmic_bytes_per_launch": round(b_screen + b_trav), "screen_bytes": round(b_screen), "traversal_bytes": round(b_trav),
@@ -261,7 +317,12 @@ def main():
             with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as fh:
                 pmc = json.load(fh)
             t = pmc.get(kname)
-            if t and dom in (0, 1, 4):
+            # the counters were collected on ONE build of the library: a different build makes them history, not measurement
+            out["roofline"]["traffic_lib"] = pmc.get("_lib_sha256_16")
+            out["roofline"]["traffic_stale"] = pmc.get("_lib_sha256_16") != lib_sha256_16()
+            if t and (args.config != 4 or orbit):
+                t = None          # collected on the static config-4 frame only
+            if t:
                 traffic = 2 * t["FETCH_SIZE_KB"] * 1024 + t["WRITE_SIZE_KB"] * 1024
                 out["roofline"]["traffic"] = round(traffic)
                 out["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch, separate run)"
@@ -308,7 +369,7 @@ def main():
         except Exception as e:  # the headline number must not depend on this extra pass
             out["roofline"]["valu"] = {"error": repr(e)}
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(abi, host, scene, env, st, desc, W, H, args.cpu_rows, first_timed)
+            out["cpu_baseline"] = cpu_baseline(abi, host, scene, env, st, desc, W, H, first_timed)
     if rank == 0 and frame is not None and out is not None and "roofline" not in out:
         # Row-tiled run (or its one-GPU emulation): the dominant kernel of THIS rank — the direct stage on the rank's band — launched
         # alone after the timed region, timed with HIP events on the stream it runs on; algorithmic bytes from the instrumented
@@ -477,10 +538,10 @@ def emulate_world(args, abi, host, scene, env, st, desc, single, W, H, device):
     return None
 
 
-def cpu_baseline(abi, host, scene, env, st, desc, W, H, rows, frame0):
-    """The CPU oracle (naive binary BVH + scalar C++, std::thread over all host cores) on a bounded sample: the full
-    12-dispatch frame restricted to a horizontal band of full-res rows around the image centre.  Two passes: a warm-up band
-    (threads, page cache, BVH in the host caches) that also sizes the second, >= 3 s pass; the second pass is reported."""
+def cpu_baseline(abi, host, scene, env, st, desc, W, H, frame0, di_only=False):
+    """The CPU oracle (naive binary BVH + scalar C++, std::thread over all host cores) on a bounded sample that is THE SAME in every round: the full
+    12-dispatch frame (config 2: its direct stage) restricted to the 256 full-res rows around the image centre, cold temporal history, timed once after a
+    64-row warm-up band (threads, page cache, BVH in the host caches)."""
     from oracle.binding import Oracle
     o = Oracle(0)
     o.upload_scene(desc)
@@ -493,27 +554,24 @@ def cpu_baseline(abi, host, scene, env, st, desc, W, H, rows, frame0):
         o.reset_counters()
         t0 = time.perf_counter()
         o.run_stage(st, frame0, abi.STAGE_DIRECT, 0, y0, y1)
-        o.run_stage(st, frame0, abi.STAGE_INDIRECT, 0, h0, h1)
-        for l in range(4):
-            o.run_stage(st, frame0, abi.STAGE_DENOISE_DIRECT, l, y0, y1)
-        for l in range(5):
-            o.run_stage(st, frame0, abi.STAGE_DENOISE_INDIRECT, l, h0, h1)
-        o.run_stage(st, frame0, abi.STAGE_COMPOSE, 0, y0, y1)
+        if not di_only:
+            o.run_stage(st, frame0, abi.STAGE_INDIRECT, 0, h0, h1)
+            for l in range(4):
+                o.run_stage(st, frame0, abi.STAGE_DENOISE_DIRECT, l, y0, y1)
+            for l in range(5):
+                o.run_stage(st, frame0, abi.STAGE_DENOISE_INDIRECT, l, h0, h1)
+            o.run_stage(st, frame0, abi.STAGE_COMPOSE, 0, y0, y1)
         dt = time.perf_counter() - t0
         c = o.counters()
         return c.closestHitRays + c.anyHitRays, dt
 
     mid = (H // 2 // 16) * 16
-    w0, w1 = max(0, mid - 64), min(H, mid + 64)
-    _, dt_w = band(w0, w1)                                       # warm-up, 128 rows
-    want = 10.0                                                  # seconds of CPU work in the reported pass
-    n = int(min(H, max(rows, (w1 - w0) * want / max(dt_w, 1e-3))) // 16 * 16)
-    y0 = max(0, min(H - n, mid - n // 2)) // 2 * 2
-    y1 = min(H, y0 + n)
+    band(max(0, mid - 32), min(H, mid + 32))                     # warm-up, 64 rows, not reported
+    y0, y1 = max(0, mid - 128), min(H, mid + 128)
     rays, dt = band(y0, y1)
     return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": o.threads, "kind": "port",
-            "sample": f"rows {y0}..{y1} of one {W}x{H} frame (all 12 dispatches, cold temporal history), second of two passes (the first, 128 rows, "
-                      f"warms the host and sizes this one): {rays} rays in {dt:.2f} s => {dt * H / max(1, y1 - y0) * 1e3:.0f} ms/frame extrapolated"}
+            "sample": f"rows {y0}..{y1} of one {W}x{H} frame ({'direct stage' if di_only else 'all 12 dispatches'}, cold temporal history), after a 64-row warm-up band: "
+                      f"{rays} rays in {dt:.2f} s => {dt * H / max(1, y1 - y0) * 1e3:.0f} ms/frame extrapolated (fixed sample since round 3; rounds 1-2 used other bands)"}
 
 
 if __name__ == "__main__":

@@ -28,7 +28,11 @@ with open(out + "/summary.txt", "w") as fo:
         for c, v in sorted(d.items()):
             fo.write("   %-28s %16.1f per launch (%d launches)\n" % (c, v / calls[(k, c)], calls[(k, c)]))
 import json
-traffic = {k.replace("void ", "").split("<")[0].split("::")[-1]: {"FETCH_SIZE_KB": d.get("FETCH_SIZE", 0) / max(1, calls[(k, "FETCH_SIZE")]),
+def key(k):   # kernel name with its template arguments, without namespaces: k_denoise_lds<false, true>
+    k = k.replace("void ", "")
+    head = k.split("<")[0]
+    return head.split("::")[-1] + k[len(head):]
+traffic = {key(k): {"FETCH_SIZE_KB": d.get("FETCH_SIZE", 0) / max(1, calls[(k, "FETCH_SIZE")]),
                                                               "WRITE_SIZE_KB": d.get("WRITE_SIZE", 0) / max(1, calls[(k, "WRITE_SIZE")]),
                                                               "INSTS_VALU": d.get("SQ_INSTS_VALU", 0) / max(1, calls[(k, "SQ_INSTS_VALU")]),
                                                               "THREAD_CYCLES_VALU": d.get("SQ_THREAD_CYCLES_VALU", 0) / max(1, calls[(k, "SQ_THREAD_CYCLES_VALU")])}
@@ -36,6 +40,9 @@ traffic = {k.replace("void ", "").split("<")[0].split("::")[-1]: {"FETCH_SIZE_KB
 frames = max(1, calls[("rt::base::k_direct_stage", "SQ_INSTS_VALU")])
 traffic["_frame"] = {"INSTS_VALU": sum(d.get("SQ_INSTS_VALU", 0) for k, d in agg.items() if k.startswith(("rt::base::", "void rt::base::"))) / frames,
                      "note": "sum over the kernels of one frame (count-free variants), SQ_INSTS_VALU per launch x launches per frame"}
+import hashlib
+lib = os.path.join(os.environ["GRAFT_REPO_ROOT"], "cis-565-final-vr-raytracer_amd", "csrc", "librestir_hip.so")
+traffic["_lib_sha256_16"] = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]   # bench.py marks these numbers stale for any other build
 json.dump(traffic, open(out + "/pmc_traffic.json", "w"), indent=1)
 print(open(out + "/summary.txt").read())
 PY
