@@ -462,6 +462,7 @@ void pipeDirect(rt_mgpu& M, Rank& R, const FrameCmd& c)
     const int gs = s >= 1 ? int((s - 1) % RING) : -1;   // (first frame after a restart: everything is drained, the boundary ids name last frame's buffers on every rank)
     const int HIST_HALO = c.histHalo;
     if(!(c.samePartition && HIST_HALO <= HALO_GBUFFER_FULL)) pullRowsOn(M, R, R.stream, RT_BUF_GBUFFER0 + last, y0 - HIST_HALO, y1 + HIST_HALO, c.prev, HK_HISTORY, gs);
+    else if(s >= 1) MG_HIP(hipStreamWaitEvent(R.stream, R.evp[Rank::E_X][(s - 1) % RING], 0), "hipStreamWaitEvent");   // those rows came with the filter halo of f-1, pulled on this rank's SIDE stream
     for(int buf : {RT_BUF_DIRECT_RESV0 + last, RT_BUF_LIGHT_ID0 + last}) pullRowsOn(M, R, R.stream, buf, y0 - HIST_HALO, y1 + HIST_HALO, c.prev, HK_HISTORY);
     for(int buf : {RT_BUF_DIRECT_RESV0 + cur, RT_BUF_LIGHT_ID0 + cur, int(RT_BUF_DIRECT_RESV_TEMP)}) pullRowsOn(M, R, R.stream, buf, y0, y1, c.prev, HK_MOVED);
   }

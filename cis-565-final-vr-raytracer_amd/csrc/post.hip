@@ -197,6 +197,27 @@ __global__ __launch_bounds__(64) void k_pick(DevScene S, rt_mat4 viewInv, rt_mat
   }
   *out = r;
 }
+// The ray query on its own (rt_trace_rays): one ray per lane, ClosestHit / AnyHit of traceray_rq.glsl:108-185 with the traversal the stage kernels use.
+__global__ __launch_bounds__(64) void k_trace_rays(DevScene S, int n, const float4* rays, float4* out, int anyHit)
+{
+  extern __shared__ uint2 s_stack[];
+  const int i = int(blockIdx.x) * 64 + int(threadIdx.x);
+  const float nanv = rt_u2f(0x7fc00000u);
+  const float4 a = i < n ? rays[2 * i] : make_float4(nanv, nanv, nanv, nanv), b = i < n ? rays[2 * i + 1] : make_float4(nanv, nanv, 0.f, 0.f);
+  RayHit hit; TravCounters tc{0, 0};
+  hit.t = RT_INFINITY; hit.gid = 0xffffffffu; hit.u = hit.v = 0.f;
+  const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
+  bool found;
+  if(anyHit) found = traceRay<true>(S, o, d, b.z, rt_f2u(b.w), s_stack + threadIdx.x, hit, tc);
+  else found = traceRay<false>(S, o, d, RT_INFINITY, rt_f2u(b.w), s_stack + threadIdx.x, hit, tc);
+  if(i < n) out[i] = anyHit ? make_float4(found ? 1.0f : 0.0f, 0.f, 0.f, 0.f) : make_float4(hit.t, rt_u2f(hit.gid), hit.u, hit.v);
+}
+hipError_t launchTraceRays(hipStream_t stream, const DevScene& S, int n, const float4* rays, float4* out, int anyHit)
+{
+  hipLaunchKernelGGL(k_trace_rays, dim3(unsigned((n + 63) / 64)), dim3(64), size_t(S.stackEntries) * 64 * sizeof(uint2), stream, S, n, rays, out, anyHit);
+  return hipGetLastError();
+}
+
 hipError_t launchPick(hipStream_t stream, const DevScene& S, const rt_mat4& viewInv, const rt_mat4& projInv, float pickX, float pickY, rt_pick_result* out)
 {
   hipLaunchKernelGGL(k_pick, dim3(1), dim3(64), size_t(S.stackEntries) * 64 * sizeof(uint2), stream, S, viewInv, projInv, pickX, pickY, out);

@@ -843,6 +843,25 @@ int rt_pick(rt_ctx* c, const rt_mat4* modelViewInv, const rt_mat4* perspectiveIn
   return RT_OK;
 }
 
+int rt_trace_rays(rt_ctx* c, int n, const float* rays, float* out, int anyHit)
+{
+  if(!c || n < 0 || (n > 0 && (!rays || !out))) return RT_ERR_INVALID_ARG;
+  if(!c->haveScene) return fail(c, RT_ERR_NO_SCENE, "no scene uploaded");
+  if(!c->haveAccel) return fail(c, RT_ERR_NO_ACCEL, "rt_build_accel has not been called");
+  if(n == 0) return RT_OK;
+  RT_HIP(c, hipSetDevice(c->device));
+  float4* dr = nullptr; float4* dout = nullptr;
+  RT_HIP(c, hipMalloc(reinterpret_cast<void**>(&dr), size_t(n) * 32));
+  if(hipMalloc(reinterpret_cast<void**>(&dout), size_t(n) * 16) != hipSuccess) { (void)hipFree(dr); return fail(c, RT_ERR_OOM, "rt_trace_rays: hipMalloc failed"); }
+  hipError_t e = hipMemcpyAsync(dr, rays, size_t(n) * 32, hipMemcpyHostToDevice, c->stream);
+  if(e == hipSuccess) e = launchTraceRays(c->stream, c->ds, n, dr, dout, anyHit);
+  if(e == hipSuccess) e = hipMemcpyAsync(out, dout, size_t(n) * 16, hipMemcpyDeviceToHost, c->stream);
+  if(e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(dr); (void)hipFree(dout);
+  RT_HIP(c, e);
+  return RT_OK;
+}
+
 int rt_set_sun_and_sky(rt_ctx* c, const rt_sun_and_sky* ss)
 {
   if(!c || !ss) return RT_ERR_INVALID_ARG;

@@ -23,6 +23,7 @@ RT_DECL_LAUNCH(sky_lat)
 // uniform-only terms of sun_and_sky() (sky.h), one thread
 struct SkyPre;
 hipError_t launchSkyPrepare(hipStream_t stream, const rt_sun_and_sky& ss, SkyPre* out);
+hipError_t launchTraceRays(hipStream_t stream, const DevScene& S, int n, const float4* rays, float4* out, int anyHit);
 hipError_t launchPick(hipStream_t stream, const DevScene& S, const rt_mat4& viewInv, const rt_mat4& projInv, float pickX, float pickY, rt_pick_result* out);
 // RenderOutput::run + post.frag as compute (post.hip)
 // csrc/microbench.hip

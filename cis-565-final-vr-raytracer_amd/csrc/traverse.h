@@ -207,9 +207,20 @@ RT_DEV bool intersectTri(const Tri48& T, f3 o, f3 d, float& t, float& u, float& 
   t = dot(e2, q) * inv;
   return !rt_isnan(t);
 }
-// second half of the test (see above); evaluated only for the few candidates that survive the range / closer-than-best tests
-RT_DEV bool hitInsidePaddedBox(const Tri48& T, f3 o, f3 d, float pad, float t)
+// second half of the test (see above).  The box is widened by the build's pad PLUS a term for the rounding error of the hit point itself,
+// 2^-21 x (largest |origin component| + t x largest |direction component|): with the build's pad alone a camera far outside the scene lost genuine
+// hits (the error of o + t*d grows with |o|; DESIGN.md deviation 6; tests/test_trace_pin.py).  Every candidate that survives the range / closer-than-best
+// tests is checked.  (Checking only the FINAL hit of a closest-hit ray and re-tracing strictly when it fails is equivalent — a candidate accepted wrongly on
+// the way can only be displaced by closer ones — and was built in round 3: the extra record fetch and the re-trace path cost more than the 35 instructions
+// per surviving candidate they save: frame +3.3 %, indirect stage +8 %, profiles/r03_final_hit_ab.txt.)
+RT_DEV float hitPointPad(f3 o, f3 d, float pad, float t)
 {
+  const float om = fmaxf(fmaxf(rt_abs(o.x), rt_abs(o.y)), rt_abs(o.z)), dm = fmaxf(fmaxf(rt_abs(d.x), rt_abs(d.y)), rt_abs(d.z));
+  return pad + (om + t * dm) * 4.76837158203125e-07f;
+}
+RT_DEV bool hitInsidePaddedBox(const Tri48& T, f3 o, f3 d, float buildPad, float t)
+{
+  const float pad = hitPointPad(o, d, buildPad, t);
   const f3 e1 = mk3(T.e1x, T.e1y, T.e1z), e2 = mk3(T.e2x, T.e2y, T.e2z), v0 = mk3(T.v0x, T.v0y, T.v0z);
   // min(v0, v0 + e1, v0 + e2) = v0 + min(0, e1, e2) exactly (rounded addition is monotonic): one v_min3 / v_max3 per bound
   const f3 h = o + d * t;

@@ -377,6 +377,11 @@ int rt_rotate_buffers(rt_ctx* ctx, int frames);
  * formula of RenderOutput::genMipmap (render_output.cpp:243-254; 2x2 box for even sizes) and sampled bilinearly at the fragment;
  * the variable the reference leaves uninitialised in the default view (`v2 ==` at post.frag:91) is 0. */
 int rt_tonemap(rt_ctx* ctx, const rt_tonemapper* tm, int debugging_mode, int frames);
+/* The ray query on its own, for tests and tools: n rays (8 floats each: origin xyz, direction xyz, tmax, the bits of the ray's seed — the seed only enters
+ * the stochastic alpha test) through ClosestHit (anyHit = 0: out = 4 floats per ray, t | bits of the flattened triangle index (0xffffffff: miss) | u | v;
+ * tmax is ignored, the range is (0, 1e28)) or AnyHit (anyHit = 1: out[4 i] = 1 if anything accepts inside (0, tmax), else 0) of traceray_rq.glsl:108-185,
+ * with the traversal the stage kernels use.  Host arrays in, host arrays out. */
+int rt_trace_rays(rt_ctx* ctx, int n, const float* rays, float* out, int anyHit);
 /* Which build of the ray-traced kernels (direct_stage / direct_gen / indirect_stage) a launch gets.  There are two, with identical
  * results: THROUGHPUT (majority-vote traversal rounds, 4-5 waves per SIMD — a full frame is bound by instruction issue) and LATENCY
  * (every ray advances every round, node fetches overlapped with the triangle work, register budget of 2 waves per SIMD — a row band

@@ -15,10 +15,12 @@ _lib = None
 
 def build(force=False):
     # make decides whether the library is stale (a no-op when it is up to date); without a compiler the prebuilt file is used
+    import shutil
     try:
         subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     except (OSError, subprocess.CalledProcessError):
-        if not os.path.exists(LIB_PATH):
+        # a machine without a compiler uses the prebuilt file; with one, a failed build must not fall back to a stale library silently
+        if not os.path.exists(LIB_PATH) or (shutil.which("g++") and shutil.which("make")):
             raise
     return LIB_PATH
 

@@ -215,6 +215,19 @@ void orc_trace_closest_brute(void* p, int n, const float* rays, float* out)
   }
 }
 
+// the sampler on its own (tests/test_trace_pin.py: against a float64 statement of the Vulkan rules): n uv pairs -> n RGBA values
+void orc_sample_texture(const uint8_t* bgra, int w, int h, int wrapS, int wrapT, int filter, int n, const float* uv, float* out)
+{
+  Scene S;
+  Texture t;
+  t.bgra.assign(bgra, bgra + size_t(w) * h * 4); t.w = w; t.h = h; t.wrapS = wrapS; t.wrapT = wrapT; t.filter = filter;
+  S.textures.push_back(t);
+  for(int i = 0; i < n; i++) {
+    const vec4 c = S.sampleTexture(0, V2(uv[2 * i], uv[2 * i + 1]));
+    out[4 * i] = c.x; out[4 * i + 1] = c.y; out[4 * i + 2] = c.z; out[4 * i + 3] = c.w;
+  }
+}
+
 // ---- known-answer entry points (random.glsl, compress.glsl, common.glsl) ------------------------------------
 uint32_t orc_tea(uint32_t a, uint32_t b) { return tea(a, b); }
 uint32_t orc_pcg(uint32_t* s) { return pcg(*s); }

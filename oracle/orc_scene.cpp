@@ -148,8 +148,11 @@ bool Scene::intersectTri(const Tri& T, vec3 o, vec3 d, float& t, float& u, float
   if(rt_isnan(t)) return false;
   // an accepted hit point lies inside the triangle's box widened by the build's padding (csrc/traverse.h intersectTri: a sliver's
   // quotients are rounding noise; without this the result would depend on which triangles share a leaf with it)
+  // The box is widened by the build's pad plus a term for the rounding error of the hit point itself (a far-away ray origin): the expression of
+  // csrc/traverse.h hitPointPad, operation for operation.
   const vec3 h = o + d * t, w1 = T.v0 + e1, w2 = T.v0 + e2;
-  const float pad = triPad;
+  const float om = rt_max(rt_max(rt_abs(o.x), rt_abs(o.y)), rt_abs(o.z)), dm = rt_max(rt_max(rt_abs(d.x), rt_abs(d.y)), rt_abs(d.z));
+  const float pad = triPad + (om + t * dm) * 4.76837158203125e-07f;
   const vec3 lo = V3(rt_min(rt_min(T.v0.x, w1.x), w2.x) - pad, rt_min(rt_min(T.v0.y, w1.y), w2.y) - pad, rt_min(rt_min(T.v0.z, w1.z), w2.z) - pad);
   const vec3 hi = V3(rt_max(rt_max(T.v0.x, w1.x), w2.x) + pad, rt_max(rt_max(T.v0.y, w1.y), w2.y) + pad, rt_max(rt_max(T.v0.z, w1.z), w2.z) + pad);
   return h.x >= lo.x && h.x <= hi.x && h.y >= lo.y && h.y <= hi.y && h.z >= lo.z && h.z <= hi.z;
