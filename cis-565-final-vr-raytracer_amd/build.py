@@ -82,6 +82,19 @@ def build_host(force=False, verbose=False):
     return HOST_LIB
 
 
+def build_host_sanitized(force=False):
+    """AddressSanitizer + UndefinedBehaviorSanitizer build of the host library (loaders, decoders, scene preparation) into host/_san/; tests/test_ingest_fuzz.py
+    runs the ingest tests and the mutation fuzz against it in a subprocess (LD_PRELOAD of the sanitizer run-time)."""
+    d = os.path.join(_HERE, "host")
+    out = os.path.join(d, "_san", "librestir_host_san.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    if force or _stale(out, _deps(d, (".cpp", ".h", ".hpp"))):
+        cmd = [os.environ.get("CXX", "g++"), "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+               "-fno-omit-frame-pointer"] + [os.path.join(d, s) for s in HOST_SRC] + ["-o", out, "-lz"]
+        subprocess.check_call(cmd)
+    return out
+
+
 DEMO_BIN = os.path.join(_HERE, "host", "restir_demo")
 
 

@@ -9,7 +9,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HOST_LIB_PATH = os.path.join(_HERE, "host", "librestir_host.so")
+HOST_LIB_PATH = os.environ.get("RESTIR_HOST_LIB") or os.path.join(_HERE, "host", "librestir_host.so")   # env override: the sanitizer build (tests/test_ingest_fuzz.py)
 _lib = None
 
 def host_lib():

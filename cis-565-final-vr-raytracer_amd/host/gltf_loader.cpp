@@ -6,7 +6,7 @@
 // one GltfPrimMesh per (mesh, primitive) and one GltfNode per drawable instance like nvh::GltfScene; triangle primitives
 // with POSITION / NORMAL / TANGENT / TEXCOORD_0 / COLOR_0 and any index type; pbrMetallicRoughness materials with
 // KHR_materials_transmission, KHR_materials_ior, KHR_materials_emissive_strength; KHR_lights_punctual; perspective cameras;
-// samplers; PNG images (8-bit, non-interlaced, via zlib) and JPEG images (baseline / progressive, jpeg_decoder.cpp).
+// samplers; PNG images (every colour type / bit depth, Adam7 included, via zlib) and JPEG images (baseline / progressive, jpeg_decoder.cpp).
 #include "scene.hpp"
 #include <zlib.h>
 #include <cmath>
@@ -136,57 +136,94 @@ bool loadUri(const std::string& uri, const std::string& dir, std::vector<uint8_t
   return readFile(dir + path, out);
 }
 
-// PNG: 8- or 16-bit gray / gray+alpha / RGB / RGBA, 8-bit palette, non-interlaced.  Output BGRA8 (scene.cpp:559: VK_FORMAT_B8G8R8A8_UNORM,
-// FreeImage's native channel order).
+// PNG: every colour type and bit depth of the specification (gray 1/2/4/8/16, RGB 8/16, palette 1/2/4/8, gray+alpha 8/16, RGBA 8/16), non-interlaced and
+// Adam7-interlaced, tRNS for palette images.  Output BGRA8 (scene.cpp:559: VK_FORMAT_B8G8R8A8_UNORM, FreeImage's native channel order); 16-bit samples keep
+// their high byte, sub-byte gray samples are scaled to 0..255.  Every length is checked before it is used: a malformed file is `false`, never a fault
+// (tests/test_ingest_fuzz.py).
+constexpr uint32_t PNG_MAX_DIM = 16384;
 bool decodePng(const uint8_t* d, size_t n, TextureImage& img)
 {
   static const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
   if(n < 8 || memcmp(d, sig, 8) != 0) return false;
   auto be32 = [](const uint8_t* p) { return (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | p[3]; };
-  uint32_t w = 0, h = 0; int depth = 0, ctype = 0, interlace = 0;
+  uint32_t w = 0, h = 0; int depth = 0, ctype = -1, interlace = 0; bool haveHdr = false;
   std::vector<uint8_t> idat, plte, trns;
   size_t pos = 8;
   while(pos + 12 <= n) {
-    uint32_t len = be32(d + pos);
+    const uint32_t len = be32(d + pos);
     const uint8_t* tag = d + pos + 4; const uint8_t* body = d + pos + 8;
-    if(pos + 12 + len > n) return false;
-    if(!memcmp(tag, "IHDR", 4)) { w = be32(body); h = be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12]; }
+    if(len > n || pos + 12 + size_t(len) > n) return false;
+    if(!memcmp(tag, "IHDR", 4)) {
+      if(len < 13) return false;
+      w = be32(body); h = be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12]; haveHdr = true;
+      if(body[10] != 0 || body[11] != 0) return false;   // compression / filter method
+    }
     else if(!memcmp(tag, "PLTE", 4)) plte.assign(body, body + len);
     else if(!memcmp(tag, "tRNS", 4)) trns.assign(body, body + len);
     else if(!memcmp(tag, "IDAT", 4)) idat.insert(idat.end(), body, body + len);
     else if(!memcmp(tag, "IEND", 4)) break;
-    pos += 12 + len;
+    pos += 12 + size_t(len);
   }
-  if(!w || !h || (depth != 8 && depth != 16) || interlace != 0 || (depth == 16 && ctype == 3)) return false;
+  if(!haveHdr || !w || !h || w > PNG_MAX_DIM || h > PNG_MAX_DIM || interlace > 1 || idat.empty()) return false;
   const int chn = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
   if(!chn) return false;
-  const int bps = depth / 8;               // bytes per sample; 16-bit samples keep their high byte
-  const int ch = chn * bps;                // bytes per pixel = the filter distance
-  const size_t stride = size_t(w) * ch;
-  std::vector<uint8_t> raw((stride + 1) * h);
+  const bool depthOk = (ctype == 0 && (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) || (ctype == 3 && (depth == 1 || depth == 2 || depth == 4 || depth == 8)) ||
+                       ((ctype == 2 || ctype == 4 || ctype == 6) && (depth == 8 || depth == 16));
+  if(!depthOk) return false;
+  const int bpp = chn * depth;                       // bits per pixel
+  const int fd = std::max(1, bpp / 8);               // filter distance in bytes
+  auto rowBytes = [&](uint32_t pw) { return (size_t(pw) * size_t(bpp) + 7) / 8; };
+  // the passes: {x0, y0, dx, dy}; a non-interlaced image is one pass
+  static const int adam7[7][4] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+  static const int single[1][4] = {{0, 0, 1, 1}};
+  const int (*passes)[4] = interlace ? adam7 : single; const int npass = interlace ? 7 : 1;
+  size_t total = 0;
+  for(int k = 0; k < npass; k++) {
+    const uint32_t pw = (w - uint32_t(passes[k][0]) + uint32_t(passes[k][2]) - 1) / uint32_t(passes[k][2]), ph = (h - uint32_t(passes[k][1]) + uint32_t(passes[k][3]) - 1) / uint32_t(passes[k][3]);
+    if(uint32_t(passes[k][0]) >= w || uint32_t(passes[k][1]) >= h || !pw || !ph) continue;
+    total += (rowBytes(pw) + 1) * ph;
+  }
+  std::vector<uint8_t> raw(total);
   uLongf rawLen = uLongf(raw.size());
   if(uncompress(raw.data(), &rawLen, idat.data(), uLong(idat.size())) != Z_OK || rawLen != raw.size()) return false;
-  std::vector<uint8_t> px(stride * h);
-  for(uint32_t y = 0; y < h; y++) {  // un-filter
-    const uint8_t ft = raw[y * (stride + 1)];
-    const uint8_t* in = &raw[y * (stride + 1) + 1];
-    uint8_t* cur = &px[y * stride]; const uint8_t* up = y ? &px[(y - 1) * stride] : nullptr;
-    for(size_t x = 0; x < stride; x++) {
-      int a = x >= size_t(ch) ? cur[x - ch] : 0, b = up ? up[x] : 0, c = (up && x >= size_t(ch)) ? up[x - ch] : 0, v = in[x];
-      switch(ft) {
-        case 1: v += a; break; case 2: v += b; break; case 3: v += (a + b) >> 1; break;
-        case 4: { int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c); v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
-        default: break;
+  std::vector<uint8_t> px(size_t(w) * h * chn);      // one byte per sample
+  const int maxv = (1 << std::min(depth, 8)) - 1;
+  size_t off = 0;
+  std::vector<uint8_t> prev, cur;
+  for(int k = 0; k < npass; k++) {
+    if(uint32_t(passes[k][0]) >= w || uint32_t(passes[k][1]) >= h) continue;
+    const uint32_t pw = (w - uint32_t(passes[k][0]) + uint32_t(passes[k][2]) - 1) / uint32_t(passes[k][2]), ph = (h - uint32_t(passes[k][1]) + uint32_t(passes[k][3]) - 1) / uint32_t(passes[k][3]);
+    if(!pw || !ph) continue;
+    const size_t stride = rowBytes(pw);
+    prev.assign(stride, 0); cur.assign(stride, 0);
+    for(uint32_t y = 0; y < ph; y++) {  // un-filter one scanline of the pass, then scatter its samples
+      const uint8_t ft = raw[off]; const uint8_t* in = &raw[off + 1];
+      off += stride + 1;
+      if(ft > 4) return false;
+      for(size_t x = 0; x < stride; x++) {
+        const int a = x >= size_t(fd) ? cur[x - size_t(fd)] : 0, b = prev[x], c = x >= size_t(fd) ? prev[x - size_t(fd)] : 0;
+        int v = in[x];
+        switch(ft) {
+          case 1: v += a; break; case 2: v += b; break; case 3: v += (a + b) >> 1; break;
+          case 4: { const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c); v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
+          default: break;
+        }
+        cur[x] = uint8_t(v);
       }
-      cur[x] = uint8_t(v);
+      const size_t Y = size_t(passes[k][1]) + size_t(y) * size_t(passes[k][3]);
+      for(uint32_t x = 0; x < pw; x++) {
+        const size_t X = size_t(passes[k][0]) + size_t(x) * size_t(passes[k][2]);
+        uint8_t* o = &px[(Y * w + X) * size_t(chn)];
+        for(int s2 = 0; s2 < chn; s2++) {
+          const size_t bit = (size_t(x) * size_t(chn) + size_t(s2)) * size_t(depth);
+          if(depth == 8) o[s2] = cur[bit / 8];
+          else if(depth == 16) o[s2] = cur[bit / 8];          // big-endian: the high byte
+          else { const int v = (cur[bit / 8] >> (8 - depth - int(bit % 8))) & maxv; o[s2] = (ctype == 3) ? uint8_t(v) : uint8_t(v * 255 / maxv); }
+        }
+      }
+      prev.swap(cur);
     }
   }
-  if(bps == 2) {  // big-endian 16-bit samples -> their high bytes
-    for(size_t i = 0; i < size_t(w) * h * chn; i++) px[i] = px[2 * i];
-  }
-  {
-    const int ch = chn;  // from here on: one byte per sample
-    (void)ch;
   img.width = int(w); img.height = int(h); img.bgra.resize(size_t(w) * h * 4);
   for(size_t i = 0; i < size_t(w) * h; i++) {
     uint8_t r, g, b, a = 255;
@@ -197,7 +234,6 @@ bool decodePng(const uint8_t* d, size_t n, TextureImage& img)
     else { r = s[0]; g = s[1]; b = s[2]; if(chn == 4) a = s[3]; }
     uint8_t* o = &img.bgra[i * 4];
     o[0] = b; o[1] = g; o[2] = r; o[3] = a;
-  }
   }
   return true;
 }

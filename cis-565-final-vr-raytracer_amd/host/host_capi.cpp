@@ -11,12 +11,14 @@ extern "C" {
 
 void* rth_scene_create() { return new(std::nothrow) Scene(); }
 void rth_scene_destroy(void* s) { delete static_cast<Scene*>(s); }
-int rth_scene_load(void* s, const char* path) { return static_cast<Scene*>(s)->load(path) ? 0 : -1; }
+// no exception crosses the C boundary (the loaders allocate from sizes they read in files): a malformed or oversized input is an error code
+#define RTH_GUARD(expr) do { try { return (expr); } catch(...) { return -1; } } while(0)
+int rth_scene_load(void* s, const char* path) { RTH_GUARD(static_cast<Scene*>(s)->load(path) ? 0 : -1); }
 // image decoders on a memory block (tests): returns 0 and fills w/h + BGRA8 pixels (caller passes a buffer of cap bytes)
 int rth_decode_jpeg(const uint8_t* data, size_t n, int* w, int* h, uint8_t* out, size_t cap)
 {
   TextureImage t;
-  if(!rth::decodeJpeg(data, n, t)) return -1;
+  try { if(!rth::decodeJpeg(data, n, t)) return -1; } catch(...) { return -1; }
   *w = t.width; *h = t.height;
   if(t.bgra.size() > cap) return -2;
   memcpy(out, t.bgra.data(), t.bgra.size());
@@ -26,7 +28,7 @@ int rth_write_png(const char* path, const uint8_t* rgba, int w, int h, int keepA
 int rth_decode_png(const uint8_t* data, size_t n, int* w, int* h, uint8_t* out, size_t cap)
 {
   TextureImage t;
-  if(!rth::decodePngImage(data, n, t)) return -1;
+  try { if(!rth::decodePngImage(data, n, t)) return -1; } catch(...) { return -1; }
   *w = t.width; *h = t.height;
   if(t.bgra.size() > cap) return -2;
   memcpy(out, t.bgra.data(), t.bgra.size());
@@ -70,7 +72,7 @@ void rth_scene_desc(void* s, void* env, rt_scene_desc* out) { *out = static_cast
 
 void* rth_env_create() { return new(std::nothrow) HdrSampling(); }
 void rth_env_destroy(void* e) { delete static_cast<HdrSampling*>(e); }
-int rth_env_load(void* e, const char* path) { return static_cast<HdrSampling*>(e)->loadEnvironment(path) ? 0 : -1; }
+int rth_env_load(void* e, const char* path) { RTH_GUARD(static_cast<HdrSampling*>(e)->loadEnvironment(path) ? 0 : -1); }
 void rth_env_set(void* e, const float* rgba, int w, int h) { static_cast<HdrSampling*>(e)->setEnvironment(rgba, w, h); }
 void rth_env_make_sky(void* e, int w, int h, float sunPeak, uint32_t seed) { static_cast<HdrSampling*>(e)->makeSyntheticSky(w, h, sunPeak, seed); }
 float rth_env_integral(void* e) { return static_cast<HdrSampling*>(e)->getIntegral(); }

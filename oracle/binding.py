@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+LIB_PATH = os.environ.get("RESTIR_ORACLE_LIB") or os.path.join(_HERE, "_build", "liboracle.so")   # env override: the sanitizer build
 _lib = None
 
 def build(force=False):
@@ -27,7 +27,8 @@ def build(force=False):
 def lib():
     global _lib
     if _lib is None:
-        build()
+        if not os.environ.get("RESTIR_ORACLE_LIB"):
+            build()
         L = C.CDLL(LIB_PATH)
         L.orc_create.restype = C.c_void_p
         L.orc_create.argtypes = [C.c_int]
