@@ -479,6 +479,8 @@ def emulate_world(args, abi, host, scene, env, st, desc, single, W, H, device):
     # ---- frames in flight per rank: the PERIOD of every rank alone on the GPU, on the partition found above -------------------------------------------
     if not args.no_period:
         m.set_balance(2); m.set_serialize(False); m.set_pipeline(True)
+        if os.environ.get("RESTIR_EMULATE_GATHER") == "0":
+            m.set_gather(False)
         only = [int(x) for x in os.environ["RESTIR_EMULATE_RANKS"].split(",")] if os.environ.get("RESTIR_EMULATE_RANKS") else range(n)
 
         def solo_period(r, k):

@@ -36,6 +36,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cstdio>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -99,10 +100,12 @@ struct Rank {
   std::atomic<int64_t> issued[E_KINDS];
   hipEvent_t tm[RING][8] = {};                                       // timing: direct begin/end, indirect begin/end, direct filters begin/end, second half begin/end
   void* gptr[RING] = {};                                              // this rank's physical G-buffer of frame seq (the boundary ids rotate)
+  void* indA[2] = {};                                                 // its two noisy-indirect-colour buffers, by frame parity (rt_select_frame)
   bool havePrev = false; FrameCmd prevCmd;                           // frame whose second half is still to be issued
   int64_t aIssued = -1;                                               // frame sequence number whose direct stage has been issued (look-ahead)
   int rotatedFor = -1;                                                // `frames` value the rotating buffer ids currently name
   int mode = -1;                                                      // rt_set_overlap value of the ctx (0: barrier schedule, 2: frames in flight)
+  double logT0 = 0;
   std::thread th;
   std::mutex qm; std::condition_variable qcv; std::deque<Cmd> q;
   int rc = RT_OK;
@@ -170,7 +173,7 @@ bool halfRows(int buf)
 // G-buffer and both sides address the physical buffer of that frame slot (the ids rotate with frames in flight).
 // evenOnly: only the even rows of [a, b) (the half-resolution filters read G(2q)); widthBytes > 0: only the first widthBytes of every row (the half-res filter
 // temporaries live in the left half of full-pitch images).
-void pullRowsOn(rt_mgpu& M, Rank& R, hipStream_t strm, int buf, int a, int b, const int* part, int kind, int gslot = -1, bool evenOnly = false, size_t widthBytes = 0)
+void pullRowsOn(rt_mgpu& M, Rank& R, hipStream_t strm, int buf, int a, int b, const int* part, int kind, int gslot = -1, bool evenOnly = false, size_t widthBytes = 0, int indParity = -1)
 {
   const bool half = halfRows(buf);
   const int limit = half ? M.H / 2 : M.H;
@@ -179,6 +182,7 @@ void pullRowsOn(rt_mgpu& M, Rank& R, hipStream_t strm, int buf, int a, int b, co
   void* dst = nullptr; size_t bytes = 0, pitch = 0;
   MG_CHECK(rt_device_ptr(R.ctx, buf, &dst, &bytes, &pitch), "rt_device_ptr");
   if(gslot >= 0) dst = R.gptr[gslot];
+  if(indParity >= 0) dst = R.indA[indParity];
   for(int q = 0; q < M.n; q++) {
     if(q == R.id) continue;
     int lo = half ? part[q] / 2 : part[q], hi = half ? part[q + 1] / 2 : part[q + 1];
@@ -189,6 +193,7 @@ void pullRowsOn(rt_mgpu& M, Rank& R, hipStream_t strm, int buf, int a, int b, co
     Rank& Q = M.ranks[q];
     if(rt_device_ptr(Q.ctx, buf, &src, &sb, &sp) != RT_OK || sp != pitch) { M.fail(R.id, RT_ERR_INVALID_ARG, "peer rt_device_ptr", ""); R.rc = RT_ERR_INVALID_ARG; return; }
     if(gslot >= 0) src = Q.gptr[gslot];
+    if(indParity >= 0) src = Q.indA[indParity];
     if(!dst || !src) continue;   // (frame slot never rendered on that rank: nothing to pull)
     if(evenOnly || (widthBytes > 0 && widthBytes < pitch)) {
       if(evenOnly) lo = (lo + 1) & ~1;
@@ -215,9 +220,9 @@ void pullFilterHaloDirect(rt_mgpu& M, Rank& R, hipStream_t strm, int cur, int y0
   pullRowsOn(M, R, strm, RT_BUF_GBUFFER0 + cur, y1 + HALO_GBUFFER_FULL, y1 + HALO_GBUFFER, part, HK_FILTER, gslot, true);
   pullRowsOn(M, R, strm, RT_BUF_DIRECT_RESULT0 + cur, y0 - HALO_DIRECT_COLOR, y1 + HALO_DIRECT_COLOR, part, HK_FILTER);
 }
-void pullFilterHaloIndirect(rt_mgpu& M, Rank& R, hipStream_t strm, int h0, int h1, const int* part)
+void pullFilterHaloIndirect(rt_mgpu& M, Rank& R, hipStream_t strm, int frames, int h0, int h1, const int* part)
 {
-  pullRowsOn(M, R, strm, RT_BUF_DENOISE_IND_A, h0 - HALO_INDIRECT_COLOR, h1 + HALO_INDIRECT_COLOR, part, HK_FILTER, -1, false, size_t(M.W / 2) * 16);
+  pullRowsOn(M, R, strm, RT_BUF_DENOISE_IND_A, h0 - HALO_INDIRECT_COLOR, h1 + HALO_INDIRECT_COLOR, part, HK_FILTER, -1, false, size_t(M.W / 2) * 16, frames & 1);
 }
 
 void runStage(rt_mgpu& M, Rank& R, const rt_state& st, int frames, int stage, int level, int r0, int r1, int limit)
@@ -307,7 +312,7 @@ void frameOnRank(rt_mgpu& M, Rank& R, const FrameCmd& c)
   // ---- 3. one exchange for the nine filter passes, filters, compose ----
   if(multi && c.st.denoise > 0) {
     pullFilterHaloDirect(M, R, R.stream, cur, y0, y1, bands.data(), -1);
-    pullFilterHaloIndirect(M, R, R.stream, h0, h1, bands.data());
+    pullFilterHaloIndirect(M, R, R.stream, f, h0, h1, bands.data());
     MG_HIP(hipStreamSynchronize(R.stream), "sync");
   }
   M.step.wait();   // nobody overwrites a source row (level 3 / compose write the result image) before every pull has landed
@@ -368,7 +373,7 @@ void waitAll(rt_mgpu& M, Rank& R, hipStream_t strm, int kind, int64_t seq, bool 
 void syncRank(rt_mgpu& M, Rank& R)
 {
   MG_HIP(hipStreamSynchronize(R.stream), "sync"); MG_HIP(hipStreamSynchronize(R.sInd), "sync");
-  MG_HIP(hipStreamSynchronize(R.sSide), "sync"); MG_HIP(hipStreamSynchronize(R.sCopy), "sync");
+  MG_HIP(hipStreamSynchronize(R.sSide), "sync"); if(R.sCopy) MG_HIP(hipStreamSynchronize(R.sCopy), "sync");
 }
 void harvestTiming(Rank& R, int64_t seq)
 {
@@ -414,7 +419,7 @@ void finishPrev(rt_mgpu& M, Rank& R, int rotatedFrames /* frames value the G-buf
   MG_CHECK(rt_set_stream(R.ctx, R.sSide), "rt_set_stream");
   waitAll(M, R, R.sSide, Rank::E_I, p, true);
   MG_HIP(hipEventRecord(R.tm[slot][6], R.sSide), "hipEventRecord");
-  if(multi && c.st.denoise > 0) pullFilterHaloIndirect(M, R, R.sSide, h0, h1, c.bands);
+  if(multi && c.st.denoise > 0) pullFilterHaloIndirect(M, R, R.sSide, f, h0, h1, c.bands);
   recordIssued(M, R, Rank::E_XI, p, R.sSide);
   if(c.st.denoise > 0) {
     runStage(M, R, c.st, f, RT_STAGE_DENOISE_INDIRECT, 0, h0 - (multi ? INDIRECT_GROW[0] : 0), h1 + (multi ? INDIRECT_GROW[0] : 0), Hh);   // IndA -> IndB
@@ -461,8 +466,11 @@ void pipeDirect(rt_mgpu& M, Rank& R, const FrameCmd& c)
   if(multi && c.haveHistory) {
     const int gs = s >= 1 ? int((s - 1) % RING) : -1;   // (first frame after a restart: everything is drained, the boundary ids name last frame's buffers on every rank)
     const int HIST_HALO = c.histHalo;
-    if(!(c.samePartition && HIST_HALO <= HALO_GBUFFER_FULL)) pullRowsOn(M, R, R.stream, RT_BUF_GBUFFER0 + last, y0 - HIST_HALO, y1 + HIST_HALO, c.prev, HK_HISTORY, gs);
-    else if(s >= 1) MG_HIP(hipStreamWaitEvent(R.stream, R.evp[Rank::E_X][(s - 1) % RING], 0), "hipStreamWaitEvent");   // those rows came with the filter halo of f-1, pulled on this rank's SIDE stream
+    // The G-buffer rows next to the band came with the filter halo of f-1 when the partition did not move — IF that pull (this rank's SIDE stream) has been
+    // issued: a direct stage issued ahead of the previous frame's filters (look-ahead) pulls the rows itself.
+    const bool haloHasThem = c.samePartition && HIST_HALO <= HALO_GBUFFER_FULL && s >= 1 && R.issued[Rank::E_X].load(std::memory_order_acquire) >= s - 1;
+    if(haloHasThem) MG_HIP(hipStreamWaitEvent(R.stream, R.evp[Rank::E_X][(s - 1) % RING], 0), "hipStreamWaitEvent");
+    else pullRowsOn(M, R, R.stream, RT_BUF_GBUFFER0 + last, y0 - HIST_HALO, y1 + HIST_HALO, c.prev, HK_HISTORY, gs);
     for(int buf : {RT_BUF_DIRECT_RESV0 + last, RT_BUF_LIGHT_ID0 + last}) pullRowsOn(M, R, R.stream, buf, y0 - HIST_HALO, y1 + HIST_HALO, c.prev, HK_HISTORY);
     for(int buf : {RT_BUF_DIRECT_RESV0 + cur, RT_BUF_LIGHT_ID0 + cur, int(RT_BUF_DIRECT_RESV_TEMP)}) pullRowsOn(M, R, R.stream, buf, y0, y1, c.prev, HK_MOVED);
   }
@@ -510,8 +518,8 @@ void pipeIndirectAndDirectFilters(rt_mgpu& M, Rank& R, const FrameCmd& c)
   if(ahead) MG_CHECK(rt_rotate_buffers(R.ctx, R.rotatedFor), "rt_rotate_buffers");
   MG_HIP(hipStreamWaitEvent(R.sInd, R.evp[Rank::E_D][slot], 0), "hipStreamWaitEvent");
   waitAll(M, R, R.sInd, Rank::E_I, s - 1, false);       // the neighbours' indirect reservoirs of f-1
-  waitAll(M, R, R.sInd, Rank::E_XI, s - 1, false);      // the noisy-indirect scratch of f-1: pulled next door ...
-  if(s >= 1) MG_HIP(hipStreamWaitEvent(R.sInd, R.evp[Rank::E_DONE][(s - 1) % RING], 0), "hipStreamWaitEvent");   // ... and filtered here
+  waitAll(M, R, R.sInd, Rank::E_XI, s - 2, false);      // the noisy-indirect buffer of this parity (frame f-2): pulled next door ...
+  if(s >= 2) MG_HIP(hipStreamWaitEvent(R.sInd, R.evp[Rank::E_DONE][(s - 2) % RING], 0), "hipStreamWaitEvent");   // ... and filtered here
   MG_CHECK(rt_set_stream(R.ctx, R.sInd), "rt_set_stream");
   if(multi && c.haveHistory) {
     pullRowsOn(M, R, R.sInd, RT_BUF_INDIRECT_RESV0 + last, h0 - c.histHalo / 2, h1 + c.histHalo / 2, c.prev, HK_HISTORY);
@@ -551,9 +559,14 @@ bool peersReadyForDirect(rt_mgpu& M, Rank& R, const FrameCmd& next)
   return true;
 }
 
+// host-side step log of one rank (RESTIR_MGPU_LOG=<rank>): where the rank's thread spends its time within a frame
+static double nowUs() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static int logRank() { static const int r = getenv("RESTIR_MGPU_LOG") ? atoi(getenv("RESTIR_MGPU_LOG")) : -1; return r; }
+#define MG_LOG(what) do { if(R.id == logRank()) fprintf(stderr, "[mgpu %d] seq %lld %-28s %.1f us\n", R.id, (long long)c.seq, what, nowUs() - R.logT0); } while(0)
+
 // One frame of the frames-in-flight schedule.  `next`: the frame after this one if the application has already queued it — its direct stage is then issued
 // as soon as this frame's direct stage is validated, BEFORE this frame's indirect stage and filters, so the main stream never waits for the host.
-void framePipelined(rt_mgpu& M, Rank& R, const FrameCmd& c, const FrameCmd* next)
+void framePipelined(rt_mgpu& M, Rank& R, const FrameCmd& c)
 {
   const int64_t s = c.seq;
   if(c.solo >= 0 && c.solo != R.id) {   // measurement: this rank sits the frame out; its flags must not hold the others back
@@ -561,13 +574,25 @@ void framePipelined(rt_mgpu& M, Rank& R, const FrameCmd& c, const FrameCmd* next
     for(auto& a : R.issued) a.store(s, std::memory_order_release);
     return;
   }
-  if(R.aIssued != s) pipeDirect(M, R, c);
+  if(R.id == logRank()) { if(R.logT0 == 0) R.logT0 = nowUs(); }
+  MG_LOG("begin");
+  if(R.aIssued != s) { pipeDirect(M, R, c); MG_LOG("direct issued"); }
   // second half of frame f-1, issued while direct(f) runs (the ids of the rotating buffers name frame f's: finishPrev undoes that for a re-run only)
   finishPrev(M, R, R.rotatedFor);
+  MG_LOG("second half of f-1 issued");
   pipeValidateDirect(M, R, c);
+  MG_LOG("direct validated");
   static const int ahead = getenv("RESTIR_MGPU_AHEAD") ? atoi(getenv("RESTIR_MGPU_AHEAD")) : 1;
-  if(ahead && next && next->seq == s + 1 && !(next->solo >= 0 && next->solo != R.id) && peersReadyForDirect(M, R, *next)) pipeDirect(M, R, *next);
+  // look-ahead: has the application queued the next frame by now?  (looked up here, a direct stage after this frame was taken from the queue)
+  Cmd nextCmd; bool haveNext = false;
+  if(ahead) {
+    std::lock_guard<std::mutex> l(R.qm);
+    if(R.q.size() >= 2 && R.q[1].kind == Cmd::FRAMEP) { nextCmd = R.q[1]; haveNext = true; }
+  }
+  const FrameCmd* next = haveNext ? &nextCmd.f : nullptr;
+  if(next && next->seq == s + 1 && !(next->solo >= 0 && next->solo != R.id) && peersReadyForDirect(M, R, *next)) { pipeDirect(M, R, *next); MG_LOG("next direct issued (ahead)"); }
   pipeIndirectAndDirectFilters(M, R, c);
+  MG_LOG("indirect + filters issued");
 }
 
 void drainRank(rt_mgpu& M, Rank& R)
@@ -595,17 +620,17 @@ void worker(rt_mgpu* Mp, int id)
         MG_CHECK(rt_upload_scene(R.ctx, M.desc), "rt_upload_scene");
         if(R.rc == RT_OK) { std::lock_guard<std::mutex> one(M.buildTurn); MG_CHECK(rt_build_accel(R.ctx), "rt_build_accel"); }   // the host build is multi-threaded itself
         break;
-      case Cmd::RESIZE: MG_CHECK(rt_resize(R.ctx, M.W, M.H), "rt_resize"); break;
-      case Cmd::FRAME: frameOnRank(M, R, cmd.f); break;
-      case Cmd::FRAMEP: {
-        Cmd nextCmd; bool haveNext = false;
-        {
-          std::lock_guard<std::mutex> l(R.qm);
-          if(R.q.size() >= 2 && R.q[1].kind == Cmd::FRAMEP) { nextCmd = R.q[1]; haveNext = true; }
+      case Cmd::RESIZE:
+        MG_CHECK(rt_resize(R.ctx, M.W, M.H), "rt_resize");
+        for(int par = 0; par < 2 && R.rc == RT_OK; par++) {
+          void* p = nullptr; size_t b = 0, pitch = 0;
+          MG_CHECK(rt_select_frame(R.ctx, par), "rt_select_frame");
+          MG_CHECK(rt_device_ptr(R.ctx, RT_BUF_DENOISE_IND_A, &p, &b, &pitch), "rt_device_ptr");
+          R.indA[par] = p;
         }
-        framePipelined(M, R, cmd.f, haveNext ? &nextCmd.f : nullptr);
         break;
-      }
+      case Cmd::FRAME: frameOnRank(M, R, cmd.f); break;
+      case Cmd::FRAMEP: framePipelined(M, R, cmd.f); break;
       case Cmd::DRAIN: drainRank(M, R); break;
       default: break;
     }
@@ -759,7 +784,8 @@ int rt_mgpu_create(rt_mgpu** out, int numRanks, const int* devices)
     const bool can = hi < lo;
     bool ok = (can && prio == 2 ? hipStreamCreateWithPriority(&R.stream, hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking)) == hipSuccess;
     ok = ok && (can && prio == 1 ? hipStreamCreateWithPriority(&R.sInd, hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(&R.sInd, hipStreamNonBlocking)) == hipSuccess;
-    ok = ok && hipStreamCreateWithFlags(&R.sSide, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&R.sCopy, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&R.sSide, hipStreamNonBlocking) == hipSuccess;
+    if(r == 0) ok = ok && hipStreamCreateWithFlags(&R.sCopy, hipStreamNonBlocking) == hipSuccess;   // the display rank's gather; the others have no use for a fourth hardware queue
     for(auto& e : R.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     for(auto& k : R.evp) for(auto& e : k) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     for(auto& k : R.tm) for(auto& e : k) ok = ok && hipEventCreate(&e) == hipSuccess;
@@ -961,6 +987,7 @@ int rt_mgpu_readback(rt_mgpu* M, int buffer, void* dst, size_t bytes)
     b = std::min(b, rowsTotal);
     if(b <= a) continue;
     void* src = nullptr; size_t sb = 0, sp = 0;
+    if(buffer == RT_BUF_DENOISE_IND_A) (void)rt_select_frame(R.ctx, M->lastFrames);   // one buffer per frame parity: the last frame's
     if(rt_device_ptr(R.ctx, buffer, &src, &sb, &sp) != RT_OK) return RT_ERR_INVALID_ARG;
     (void)hipSetDevice(R.dev);
     if(hipMemcpy(static_cast<char*>(dst) + size_t(a) * pitch, static_cast<char*>(src) + size_t(a) * pitch, size_t(b - a) * pitch, hipMemcpyDeviceToHost) != hipSuccess)

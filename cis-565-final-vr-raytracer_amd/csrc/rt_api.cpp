@@ -31,6 +31,10 @@ struct rt_ctx {
   void* dPick = nullptr;     // rt_pick_result written by k_pick
   rt_sun_and_sky sunAndSky{};
   void* spareG = nullptr; void* spareMotion = nullptr;   // third G-buffer / second motion buffer (rotated per pipelined frame)
+  // The noisy indirect colour (RT_BUF_DENOISE_IND_A: written by the indirect stage, read and rewritten by its five filter levels) exists twice, by frame parity:
+  // indirect(f+1) must not wait for the filters of frame f (round 3: that wait made a rank's period indirect + filters instead of max(direct, indirect)).
+  // The boundary id names the buffer of the frame most recently passed to rt_render_frame / rt_run_stage / rt_select_frame.
+  void* indA[2] = {nullptr, nullptr};
   int overlap = 2;           // 0 = one stream; 1 = direct A-Trous beside the indirect stage; 2 = 1 + consecutive frames overlap
   std::string err;
   // host copy of the scene (rt_build_accel runs after rt_upload_scene returns; the caller keeps ownership of its arrays)
@@ -103,9 +107,10 @@ typedef hipError_t (*StageLauncher)(hipStream_t, const DevScene&, const DevFrame
 // frames are bound by instruction issue) and the latency build (csrc/stages_lat.hip: every ray advances every round, node fetch overlapped with the
 // triangle work, 2 waves per SIMD worth of registers: a row band of a multi-GPU frame or a small image is bound by the dependent accesses of its
 // slowest wave).  RT_TRAVERSAL_AUTO decides by the number of 8x8 tiles of the launch; the thresholds are where the two builds measured equal on
-// the benchmark scene (profiles/r03_lat_ab.txt).  The counting build is a throughput build.  Results are bit-identical either way.
-static int latTilesDirect() { static const int v = getenv("RESTIR_LAT_TILES") ? atoi(getenv("RESTIR_LAT_TILES")) : 0; return v; }
-static int latTilesIndirect() { static const int v = getenv("RESTIR_LAT_TILES_IND") ? atoi(getenv("RESTIR_LAT_TILES_IND")) : 0; return v; }
+// the benchmark scene (profiles/r03_band_chunk_ab.txt): the latency build of the direct stage wins while all its 8-wave workgroups are resident at once
+// (512), the indirect stage's up to ~640 half-res tiles (a 64-row band at 1080p).  The counting build is a throughput build.  Bit-identical either way.
+static int latTilesDirect() { static const int v = getenv("RESTIR_LAT_TILES") ? atoi(getenv("RESTIR_LAT_TILES")) : 512; return v; }
+static int latTilesIndirect() { static const int v = getenv("RESTIR_LAT_TILES_IND") ? atoi(getenv("RESTIR_LAT_TILES_IND")) : 640; return v; }
 static StageLauncher stageLauncher(const rt_ctx* c, const rt_state& st, int stage, int rowBegin, int rowEnd)
 {
   bool lat = false;
@@ -243,23 +248,9 @@ int rt_create(rt_ctx** out, int device)
   if(!c) { g_createErr = "rt_create: out of host memory"; return RT_ERR_OOM; }
   c->device = device;
   {
-    // stream priorities of the frames-in-flight schedule (RESTIR_PRIO): 0 none, 1 ind + side high, 2 ind high (default: measured 2 % faster than 1, round 2),
-    // 3 side high, 4 main (direct stage) high, 5 main + ind high, 6 main + side high, 7 main high / ind normal / side low
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    const char* pe = getenv("RESTIR_PRIO");
-    const int mode = pe ? atoi(pe) : 2;
-    const bool can = hi < lo;
-    bool ok = true;
-    auto mk = [&](hipStream_t* s, int level) {   // level: 1 high, 0 default, -1 low
-      if(can && level != 0) ok = ok && hipStreamCreateWithPriority(s, hipStreamNonBlocking, level > 0 ? hi : lo) == hipSuccess;
-      else ok = ok && hipStreamCreateWithFlags(s, hipStreamNonBlocking) == hipSuccess;
-    };
-    mk(&c->ownStream, (mode >= 4 && mode <= 7) ? 1 : 0);
+    bool ok = hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) == hipSuccess;
     if(!ok) { g_createErr = "rt_create: hipStreamCreate failed"; delete c; return RT_ERR_HIP; }
     c->stream = c->ownStream;
-    mk(&c->sideStream, (mode == 1 || mode == 3 || mode == 6) ? 1 : (mode == 7 ? -1 : 0));
-    mk(&c->indStream, (mode == 1 || mode == 2 || mode == 5) ? 1 : 0);
     for(int i = 0; i < 4; i++) {
       ok = ok && hipEventCreateWithFlags(&c->evD[i], hipEventDisableTiming) == hipSuccess;
       ok = ok && hipEventCreateWithFlags(&c->evI[i], hipEventDisableTiming) == hipSuccess;
@@ -267,7 +258,7 @@ int rt_create(rt_ctx** out, int device)
     }
     ok = ok && hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming) == hipSuccess;
-    if(!ok) { g_createErr = "rt_create: creating the internal streams / events failed"; rt_destroy(c); return RT_ERR_HIP; }
+    if(!ok) { g_createErr = "rt_create: creating the internal events failed"; rt_destroy(c); return RT_ERR_HIP; }
   }
   if(const char* e = getenv("RESTIR_OVERLAP")) c->overlap = atoi(e);
   if(const char* e = getenv("RESTIR_LAT")) c->traversal = atoi(e) ? RT_TRAVERSAL_LATENCY : RT_TRAVERSAL_THROUGHPUT;   // A/B runs and the forced-variant parity tests
@@ -286,6 +277,7 @@ int rt_destroy(rt_ctx* c)
   for(int i = 0; i < RT_BUF_COUNT; i++) if(c->bufs[i]) (void)hipFree(c->bufs[i]);
   if(c->spareG) (void)hipFree(c->spareG);
   if(c->spareMotion) (void)hipFree(c->spareMotion);
+  for(void* p : c->indA) if(p && p != c->bufs[RT_BUF_DENOISE_IND_A]) (void)hipFree(p);
   if(c->indStream) (void)hipStreamDestroy(c->indStream);
   for(int i = 0; i < 4; i++) { if(c->evD[i]) (void)hipEventDestroy(c->evD[i]); if(c->evI[i]) (void)hipEventDestroy(c->evI[i]); if(c->evDone[i]) (void)hipEventDestroy(c->evDone[i]); }
   if(c->dCounters) (void)hipFree(c->dCounters);
@@ -490,6 +482,7 @@ int rt_resize(rt_ctx* c, int w, int h)
   if(w <= 0 || h <= 0 || w > 32767 || h > 32767) return fail(c, RT_ERR_INVALID_ARG, "rt_resize: size must be in 1..32767 (RG16_SINT motion vectors)");
   RT_HIP(c, hipSetDevice(c->device));
   RT_HIP(c, syncAll(c));
+  for(void*& p : c->indA) { if(p && p != c->bufs[RT_BUF_DENOISE_IND_A]) (void)hipFree(p); p = nullptr; }
   for(int i = 0; i < RT_BUF_COUNT; i++) { if(c->bufs[i]) (void)hipFree(c->bufs[i]); c->bufs[i] = nullptr; c->bufBytes[i] = 0; }
   if(c->spareG) { (void)hipFree(c->spareG); c->spareG = nullptr; }
   if(c->spareMotion) { (void)hipFree(c->spareMotion); c->spareMotion = nullptr; }
@@ -501,6 +494,11 @@ int rt_resize(rt_ctx* c, int w, int h)
     RT_HIP(c, hipMalloc(&c->bufs[i], alloc));
     RT_HIP(c, hipMemset(c->bufs[i], (i == RT_BUF_LIGHT_ID0 || i == RT_BUF_LIGHT_ID1) ? 0xff : 0, alloc));
     c->bufBytes[i] = bytes; c->bufAlloc[i] = alloc;
+    if(i == RT_BUF_DENOISE_IND_A) {  // the second parity of the noisy indirect colour
+      c->indA[0] = c->bufs[i];
+      RT_HIP(c, hipMalloc(&c->indA[1], alloc));
+      RT_HIP(c, hipMemset(c->indA[1], 0, alloc));
+    }
     if(i == RT_BUF_GBUFFER0 || i == RT_BUF_MOTION) {  // rotation partners for frames in flight (rt_render_frame, overlap 2)
       void** spare = (i == RT_BUF_MOTION) ? &c->spareMotion : &c->spareG;
       RT_HIP(c, hipMalloc(spare, alloc));
@@ -557,8 +555,29 @@ int rt_set_camera(rt_ctx* c, const rt_scene_camera* cam)
   return RT_OK;
 }
 
+static void selectFrame(rt_ctx* c, int frames) { if(c->indA[0]) c->bufs[RT_BUF_DENOISE_IND_A] = c->indA[frames & 1]; }
+
+// The two extra streams of rt_render_frame's overlapped schedules, created on first use: a host that drives the stages itself (rt_run_stage on its own streams:
+// rt_mgpu, tiled.py) never needs them, and every stream of a process takes one of the device's few hardware queues (4 by default) out of the rotation.
+// Stream priorities of the frames-in-flight schedule (RESTIR_PRIO): 0 none, 1 ind + side high, 2 ind high (default: measured 2 % faster than 1, round 2),
+// 3 side high.  (Modes 4-7 of round 2 — main stream high — measured slower and needed the main stream created with a priority: removed.)
+static hipError_t ensureOverlapStreams(rt_ctx* c)
+{
+  if(c->sideStream && c->indStream) return hipSuccess;
+  int lo = 0, hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+  static const int mode = getenv("RESTIR_PRIO") ? atoi(getenv("RESTIR_PRIO")) : 2;
+  const bool can = hi < lo;
+  auto mk = [&](hipStream_t* s, bool high) { return (can && high) ? hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(s, hipStreamNonBlocking); };
+  hipError_t e = hipSuccess;
+  if(!c->sideStream) e = mk(&c->sideStream, mode == 1 || mode == 3);
+  if(e == hipSuccess && !c->indStream) e = mk(&c->indStream, mode == 1 || mode == 2);
+  return e;
+}
+
 static DevFrame makeFrame(rt_ctx* c, int frames)
 {
+  selectFrame(c, frames);
   const int cur = frames & 1, last = (frames + 1) & 1;  // m_descSet[(frames+1)%2]: this = [!i] (renderer.cpp:157, 346-356)
   DevFrame F{};
   F.stackLds = stackLdsEnv() ? stackLdsEnv() : (c->overlap == 2 ? 6 : 0);
@@ -621,6 +640,7 @@ int rt_render_frame(rt_ctx* c, const rt_state* st, int frames)
     c->evSets.push_back(E);
   }
   rt_ctx::EvSet& E = c->evSets[c->evUsed];
+  if(c->overlap >= 1) RT_HIP(c, ensureOverlapStreams(c));
   const bool pipelined = c->overlap >= 2 && c->sideStream && c->indStream && c->spareG && c->spareMotion;
   if(pipelined) {
     // Rotate the G-buffer (3 physical buffers) and the motion buffer (2): direct(f+1) must not overwrite what indirect(f)
@@ -657,7 +677,7 @@ int rt_render_frame(rt_ctx* c, const rt_state* st, int frames)
     // tail of multi-bounce tiles no longer leaves the chip idle, and the bandwidth-bound filters hide behind traversal.
     // Buffer reuse across frames is ordered explicitly:
     //   direct(f) overwrites G(f-3) [read by indirect(f-2)], motion(f-2) [indirect(f-2)] and the result image of f-2 [compose(f-2)];
-    //   indirect(f) overwrites the noisy-indirect scratch that the indirect A-Trous of f-1 reads.
+    //   indirect(f) overwrites the noisy-indirect buffer of its parity, which the indirect A-Trous of f-2 read (two buffers: no wait for f-1's filters).
     const uint64_t s = c->seq;
     const int r = int(s & 3);
     if(s >= 2) {
@@ -669,7 +689,7 @@ int rt_render_frame(rt_ctx* c, const rt_state* st, int frames)
     RT_HIP(c, hipEventRecord(c->evD[r], c->stream));
 
     RT_HIP(c, hipStreamWaitEvent(c->indStream, c->evD[r], 0));
-    if(s >= 1) RT_HIP(c, hipStreamWaitEvent(c->indStream, c->evDone[(s - 1) & 3], 0));
+    if(s >= 2) RT_HIP(c, hipStreamWaitEvent(c->indStream, c->evDone[(s - 2) & 3], 0));   // the noisy-indirect buffer of this parity: filtered for f-2
     RT_HIP(c, mark(c->indStream, lastInd));
     if((rc = run(c->indStream, RT_STAGE_INDIRECT, 0))) return rc;
     RT_HIP(c, hipEventRecord(c->evI[r], c->indStream));
@@ -734,6 +754,8 @@ int rt_upload_history(rt_ctx* c, int buffer, const void* src, size_t bytes)
   RT_HIP(c, hipSetDevice(c->device));
   RT_HIP(c, syncAll(c));
   RT_HIP(c, hipMemcpy(c->bufs[buffer], src, bytes, hipMemcpyHostToDevice));
+  if(buffer == RT_BUF_DENOISE_IND_A)   // both parities: the caller's next stage may name either frame
+    for(void* p : c->indA) if(p && p != c->bufs[buffer]) RT_HIP(c, hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
   RT_HIP(c, hipDeviceSynchronize());
   return RT_OK;
 }
@@ -810,6 +832,13 @@ int rt_history_miss_stage(rt_ctx* c, int stage, int* missed)
   RT_HIP(c, hipMemsetAsync(flag, 0, sizeof(v), c->stream));
   RT_HIP(c, hipStreamSynchronize(c->stream));  // the ctx stream only: other streams of the host keep running
   *missed = v ? 1 : 0;
+  return RT_OK;
+}
+
+int rt_select_frame(rt_ctx* c, int frames)
+{
+  if(!c) return RT_ERR_INVALID_ARG;
+  selectFrame(c, frames);
   return RT_OK;
 }
 

@@ -20,11 +20,23 @@ constexpr int TILE_STRIPE = RT_TILE_STRIPE;
 // tiles per chunk; chunk c (row-major tile order) belongs to XCD c % 8.  Measured on the 1080p bench scene (frames in flight, ms/frame):
 // stripes of 8 / 4 / 2 / 1 tile rows: 3.70 / 3.39 / 3.23 / 3.15 — the finer the interleave, the better the XCDs are balanced
 // (sky rows vs street rows); profiles/r02_tile_order_ab.txt has the chunked variants.
-__host__ __device__ inline int tileChunk(int tilesX) { return RT_TILE_CHUNK > 0 ? RT_TILE_CHUNK : TILE_STRIPE * tilesX; }
+// SMALL launches (row bands of a multi-GPU frame: fewer than RT_TILE_SMALL_ROWS tile rows): whole tile rows per XCD would leave XCDs without work — a
+// 32-row band has 4 tile rows for 8 XCDs — so they are dealt in chunks of RT_TILE_SMALL_CHUNK tiles (round 3, profiles/r03_band_chunk_ab.txt).
+#ifndef RT_TILE_SMALL_ROWS
+#define RT_TILE_SMALL_ROWS 24
+#endif
+#ifndef RT_TILE_SMALL_CHUNK
+#define RT_TILE_SMALL_CHUNK 8
+#endif
+__host__ __device__ inline int tileChunk(int tilesX, int tilesY)
+{
+  if(RT_TILE_CHUNK > 0) return RT_TILE_CHUNK;
+  return tilesY < RT_TILE_SMALL_ROWS ? RT_TILE_SMALL_CHUNK : TILE_STRIPE * tilesX;
+}
 RT_DEV TileCoord tileOfBlock(int L, int tilesX, int tilesY)
 {
   const int xcd = L & 7, k = L >> 3;                 // k-th workgroup of this XCD
-  const int G = tileChunk(tilesX);
+  const int G = tileChunk(tilesX, tilesY);
   const int j = k / G, off = k - j * G;
   const int t = (j * 8 + xcd) * G + off;             // row-major tile index
   TileCoord tc;
@@ -37,7 +49,7 @@ RT_DEV TileCoord tileOf(int tilesX, int tilesY) { return tileOfBlock(int(blockId
 // grid size (in workgroups) that covers tilesX x tilesY tiles with the mapping above
 inline unsigned tileGrid(int tilesX, int tilesY)
 {
-  const int G = tileChunk(tilesX);
+  const int G = tileChunk(tilesX, tilesY);
   const int chunks = (tilesX * tilesY + G - 1) / G;
   const int perXcd = (chunks + 7) / 8;
   return unsigned(8 * perXcd * G);

@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256) void k_ind_tile_order(rt_state st, int rowBegi
   __syncthreads();
   uint32_t* list = lists + size_t(xcd) * cap;
   const int indW = st.size.x / 2;
-  const int G = tileChunk(tilesX), nTiles = tilesX * tilesY;
+  const int G = tileChunk(tilesX, tilesY), nTiles = tilesX * tilesY;
   const int chunks = (nTiles + G - 1) / G;
   for(int s = xcd; s < chunks; s += 8) {
     for(int i = int(threadIdx.x); i < G; i += int(blockDim.x)) {
@@ -661,7 +661,9 @@ RT_DEV void indirectSingleBounceTiles(const DevScene& S, const DevFrame& F, cons
 #if RT_LAT
 // latency build: a workgroup of NW waves per half-res tile; wave 0 runs the paths of the 64 pixels (the body below), the other waves only serve the
 // workgroup's ray pool: after every path vertex wave 0 lists the vertex's rays, all waves trace them eight lanes per ray, wave 0 goes on shading
-__global__ __launch_bounds__(512, 2) void k_indirect_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY, int cap,
+// (4 waves per SIMD = 128 VGPRs: two of these workgroups per CU, and beside one of them two direct-stage waves per SIMD — with 165 registers the next
+//  frame's direct stage, which runs beside this kernel when frames are in flight, had one wave slot per SIMD left: profiles/r03_mgpu_period_ab.txt)
+__global__ __launch_bounds__(512, 4) void k_indirect_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY, int cap,
                                                        const uint32_t* lists, const uint32_t* counts, int subShift, int sbK, int genericBlocks)
 #else
 __global__ __launch_bounds__(64, RT_INDIRECT_LB) void k_indirect_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY, int cap,

@@ -45,7 +45,7 @@ class HdrSampling:
     def __init__(self):
         self._h = host_lib().rth_env_create()
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and host_lib is not None:      # (module globals are gone at interpreter shutdown)
             host_lib().rth_env_destroy(self._h); self._h = None
     def loadEnvironment(self, path):
         return host_lib().rth_env_load(self._h, path.encode()) == 0
@@ -71,7 +71,7 @@ class Scene:
     def __init__(self):
         self._h = host_lib().rth_scene_create()
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and host_lib is not None:
             host_lib().rth_scene_destroy(self._h); self._h = None
     def load(self, filename):
         return host_lib().rth_scene_load(self._h, filename.encode()) == 0

@@ -15,7 +15,7 @@ _lib = None
 # every symbol include/rt_abi.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_build_accel", "rt_resize", "rt_set_camera",
                "rt_render_frame", "rt_run_stage", "rt_readback", "rt_upload_history", "rt_buffer_bytes", "rt_device_ptr",
-               "rt_set_counting", "rt_get_counters", "rt_sync", "rt_last_error", "rt_abi_version", "rt_set_traversal", "rt_set_history_rows", "rt_history_miss", "rt_set_overlap", "rt_tonemap", "rt_set_sun_and_sky", "rt_pick", "rt_trace_rays", "rt_history_miss_stage", "rt_rotate_buffers", "rt_measure_valu_peak",
+               "rt_set_counting", "rt_get_counters", "rt_sync", "rt_last_error", "rt_abi_version", "rt_set_traversal", "rt_set_history_rows", "rt_history_miss", "rt_set_overlap", "rt_tonemap", "rt_set_sun_and_sky", "rt_pick", "rt_trace_rays", "rt_history_miss_stage", "rt_rotate_buffers", "rt_select_frame", "rt_measure_valu_peak",
                "rt_mgpu_create", "rt_mgpu_destroy", "rt_mgpu_upload_scene", "rt_mgpu_resize", "rt_mgpu_set_camera", "rt_mgpu_render_frame", "rt_mgpu_readback",
                "rt_mgpu_sync", "rt_mgpu_set_balance", "rt_mgpu_set_serialize", "rt_mgpu_set_pipeline", "rt_mgpu_set_gather", "rt_mgpu_set_solo", "rt_mgpu_set_bands", "rt_mgpu_get_stats", "rt_mgpu_last_error", "rt_mgpu_plan_bands"]
 
@@ -58,6 +58,7 @@ def hip_lib():
         L.rt_set_sun_and_sky.argtypes = [C.c_void_p, C.c_void_p]
         L.rt_history_miss_stage.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.rt_rotate_buffers.argtypes = [C.c_void_p, C.c_int]
+        L.rt_select_frame.argtypes = [C.c_void_p, C.c_int]
         L.rt_trace_rays.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.rt_pick.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
         L.rt_set_history_rows.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -208,6 +209,10 @@ class Renderer:
     def set_sun_and_sky(self, ss):
         """updateUniformBuffer's SunAndSky upload (sample_example.cpp:172); ss.in_use = 1 switches the environment to the procedural sky."""
         self._chk(hip_lib().rt_set_sun_and_sky(self._h, C.byref(ss)), "rt_set_sun_and_sky")
+
+    def select_frame(self, frames):
+        """RT_BUF_DENOISE_IND_A exists once per frame parity: name the one of `frames` for the next device_array / readback."""
+        self._chk(hip_lib().rt_select_frame(self._h, int(frames)), "rt_select_frame")
 
     def set_overlap(self, mode):
         """0 = serial launches, 1 = direct A-Trous beside the indirect stage, 2 = 1 + frames in flight (default)."""

@@ -268,6 +268,13 @@ class TiledFrame:
     def _t(self, buf):
         return self.b.tensor(buf)
 
+    def _icol(self, frames):
+        """The noisy indirect colour of frame `frames` (the HIP library keeps one buffer per frame parity: rt_select_frame)."""
+        sel = getattr(self.b, "select_frame", None)
+        if sel:
+            sel(frames)
+        return self._t(abi.BUF_DENOISE_IND_A)[0]
+
     def _run(self, state, frames, stage, level, r0, r1, limit):
         r0, r1 = max(0, r0), min(limit, r1)
         if r1 > r0:
@@ -315,7 +322,7 @@ class TiledFrame:
         if state.denoise > 0 and not single:
             g, gp = self._t(abi.BUF_GBUFFER0 + cur)
             dcol, _ = self._t(abi.BUF_DIRECT_RESULT0 + cur)
-            icol, _ = self._t(abi.BUF_DENOISE_IND_A)
+            icol = self._icol(frames)
             c.halo_exchange([(g, gp, self.part, HALO_GBUFFER, self.H),
                              (dcol, pitch, self.part, HALO_DIRECT_COLOR, self.H),
                              (icol, pitch, self.parth, HALO_INDIRECT_COLOR, self.Hh)])
@@ -499,7 +506,7 @@ class PipelinedTiledFrame(TiledFrame):
             t, p = self._t(abi.BUF_INDIRECT_RESV0 + cur)
             items.append((t, p, self.parth, HIST_HALO // 2, self.Hh))
             if state.denoise > 0:
-                icol, _ = self._t(abi.BUF_DENOISE_IND_A)
+                icol = self._icol(f)
                 items.append((icol, self.W * _COLOR_BYTES, self.parth, HALO_INDIRECT_COLOR, self.Hh))
             self._wI = c.halo_exchange(items, async_op=True)
             self._record(("Ix", f))
@@ -605,8 +612,12 @@ class RendererTensors:
         self.torch.cuda.current_stream().wait_event(ev)
     def sync_all(self):
         self.torch.cuda.synchronize()
+    def select_frame(self, frames):
+        self.r.select_frame(frames)
+        self._ind_parity = frames & 1
     def tensor(self, buf):
-        if buf not in self._cache:
+        key = (buf, getattr(self, "_ind_parity", 0)) if buf == abi.BUF_DENOISE_IND_A else buf   # that buffer exists once per frame parity
+        if key not in self._cache:
             arr, pitch = self.r.device_array(buf)
-            self._cache[buf] = (self.torch.as_tensor(arr, device=f"cuda:{self.torch.cuda.current_device()}"), pitch)
-        return self._cache[buf]
+            self._cache[key] = (self.torch.as_tensor(arr, device=f"cuda:{self.torch.cuda.current_device()}"), pitch)
+        return self._cache[key]

@@ -367,6 +367,10 @@ int rt_history_miss_stage(rt_ctx* ctx, int stage, int* missed);
  * still running on another stream, reads.  Calling it a second time with the same `frames` undoes the swap.
  * Invalidates rt_device_ptr results for those three buffers. */
 int rt_rotate_buffers(rt_ctx* ctx, int frames);
+/* RT_BUF_DENOISE_IND_A (the noisy indirect colour: indirect stage -> its five filter levels) exists once per frame parity, so that the indirect stage of frame
+ * f+1 does not wait for the filters of frame f.  The id names the buffer of the frame most recently passed to rt_render_frame / rt_run_stage / this call:
+ * a host that touches the buffer itself (rt_device_ptr for a halo exchange) of a frame other than the last one it launched selects that frame first. */
+int rt_select_frame(rt_ctx* ctx, int frames);
 /* RenderOutput::run (render_output.cpp:224-237) + post.frag:103-175 as a compute pass: reads the two result images of
  * frame `frames` (RT_BUF_DIRECT_RESULT0/INDIRECT_RESULT0 + (frames & 1)), applies auto-exposure (tonemapping by the image
  * mean, post.frag:133-153), the Uncharted-2 tone curve (tonemapping.glsl:48-66), dithering (post.frag:50-55), contrast /
