@@ -485,7 +485,7 @@ def emulate_world(args, abi, host, scene, env, st, desc, single, W, H, device):
 
         def solo_period(r, k):
             m.set_solo(r)
-            for _ in range(6):
+            for _ in range(10):
                 frame()
             m.sync(); t0 = time.perf_counter()
             for _ in range(k):
@@ -499,7 +499,7 @@ def emulate_world(args, abi, host, scene, env, st, desc, single, W, H, device):
         cost = np.ones(stripes)
         history = []
         for rnd in range(0 if os.environ.get("RESTIR_EMULATE_RANKS") else args.period_rounds):
-            per = [solo_period(r, max(8, args.steps // 3)) for r in range(n)]
+            per = [solo_period(r, max(40, args.steps)) for r in range(n)]
             history.append({"bands": cur, "period_ms": [round(float(x), 3) for x in per]})
             for r in range(n):
                 a, b = cur[r] // 16, (cur[r + 1] + 15) // 16
@@ -509,11 +509,20 @@ def emulate_world(args, abi, host, scene, env, st, desc, single, W, H, device):
             for _ in range(3):
                 frame()      # the rows that moved travel with the history pulls
         if history:
+            # the re-planning is a noisy fixed-point iteration: measure the last plan as well and keep the best partition seen
+            per = [solo_period(r, max(40, args.steps)) for r in range(n)]
+            history.append({"bands": cur, "period_ms": [round(float(x), 3) for x in per]})
+            best = min(history, key=lambda h: max(h["period_ms"]))
+            if best["bands"] != cur:
+                cur = best["bands"]
+                m.set_solo(-1); m.set_bands(cur)
+                for _ in range(3):
+                    frame()
             out["period_balancing_rounds"] = history
             out["bands_period_balanced"] = [(cur[r], cur[r + 1]) for r in range(n)]
         periods, pk = [], np.zeros(6)
         for r in only:
-            periods.append(solo_period(r, args.steps))
+            periods.append(solo_period(r, max(60, args.steps)))
             s = m.stats()
             mine = np.array([s.haloBytesRankKind[r][i] for i in range(6)], dtype=np.float64)
             if mine[:4].sum() >= pk[:4].sum():

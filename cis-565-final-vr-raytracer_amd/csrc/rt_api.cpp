@@ -103,14 +103,18 @@ static hipError_t joinInFlight(rt_ctx* c)
 }
 
 typedef hipError_t (*StageLauncher)(hipStream_t, const DevScene&, const DevFrame&, const rt_state&, const rt_scene_camera&, int, int, int, int);
-// Which build of stages.hip runs a launch.  The traced kernels exist twice: the throughput build (majority-vote rounds, 4-5 waves per SIMD: full
-// frames are bound by instruction issue) and the latency build (csrc/stages_lat.hip: every ray advances every round, node fetch overlapped with the
-// triangle work, 2 waves per SIMD worth of registers: a row band of a multi-GPU frame or a small image is bound by the dependent accesses of its
-// slowest wave).  RT_TRAVERSAL_AUTO decides by the number of 8x8 tiles of the launch; the thresholds are where the two builds measured equal on
-// the benchmark scene (profiles/r03_band_chunk_ab.txt): the latency build of the direct stage wins while all its 8-wave workgroups are resident at once
-// (512), the indirect stage's up to ~640 half-res tiles (a 64-row band at 1080p).  The counting build is a throughput build.  Bit-identical either way.
-static int latTilesDirect() { static const int v = getenv("RESTIR_LAT_TILES") ? atoi(getenv("RESTIR_LAT_TILES")) : 512; return v; }
-static int latTilesIndirect() { static const int v = getenv("RESTIR_LAT_TILES_IND") ? atoi(getenv("RESTIR_LAT_TILES_IND")) : 640; return v; }
+// Which build of stages.hip runs a launch.  The traced kernels exist twice: the throughput build (one ray per lane, majority-vote rounds, 4-5 waves per
+// SIMD: full frames are bound by instruction issue) and the latency build (csrc/stages_lat.hip: eight lanes per ray, a workgroup of eight waves per tile:
+// a row band of a multi-GPU frame or a small image is bound by the dependent steps of its slowest rays, and the latency build shortens the step).
+// RT_TRAVERSAL_AUTO decides by the number of 8x8 tiles of the launch; the thresholds are where the two builds measured equal on the benchmark scene
+// (profiles/r03_band_chunk_ab.txt, profiles/r03_lat_wide_ab.txt):
+//   launches that run alone (rt_set_overlap 0/1; the barrier schedule of rt_mgpu): direct stage up to 1440 tiles (48 rows of 1080p), indirect stage up to
+//     1536 half-res tiles (~200 rows of 1080p);
+//   launches that share the CUs with the kernels of another frame (rt_set_overlap 2; frames in flight in rt_mgpu): 512 / 640 — eight lanes per ray buy a
+//     short chain with 2-4x the lane-cycles, which a co-running kernel would have used.
+// The counting build is a throughput build.  Bit-identical either way.  RESTIR_LAT_TILES / RESTIR_LAT_TILES_IND override both cases (experiments).
+static int latTilesDirect(bool shared) { static const int v = getenv("RESTIR_LAT_TILES") ? atoi(getenv("RESTIR_LAT_TILES")) : -1; return v >= 0 ? v : (shared ? 512 : 1440); }
+static int latTilesIndirect(bool shared) { static const int v = getenv("RESTIR_LAT_TILES_IND") ? atoi(getenv("RESTIR_LAT_TILES_IND")) : -1; return v >= 0 ? v : (shared ? 640 : 1536); }
 static StageLauncher stageLauncher(const rt_ctx* c, const rt_state& st, int stage, int rowBegin, int rowEnd)
 {
   bool lat = false;
@@ -121,7 +125,7 @@ static StageLauncher stageLauncher(const rt_ctx* c, const rt_state& st, int stag
       const int gw = half ? st.size.x / 2 : st.size.x, gh = half ? st.size.y / 2 : st.size.y;
       const int r1 = (rowEnd <= 0 || rowEnd > gh) ? gh : rowEnd, r0 = rowBegin < 0 ? 0 : rowBegin;
       const long tiles = long((gw + 7) / 8) * long((std::max(0, r1 - r0) + 7) / 8);
-      lat = tiles <= (half ? latTilesIndirect() : latTilesDirect());
+      lat = tiles <= (half ? latTilesIndirect(c->overlap == 2) : latTilesDirect(c->overlap == 2));
     }
   }
   if(c->ds.sky) return lat ? rt::sky_lat::launchStage : (c->counting ? rt::sky_cnt::launchStage : rt::sky::launchStage);

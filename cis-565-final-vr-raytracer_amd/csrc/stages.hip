@@ -202,7 +202,10 @@ RT_DEV void groupTrace(const DevScene& S, const WideLds& L, TravCounters& tc)
   __syncthreads();
 }
 
-__global__ __launch_bounds__(512, 2) void k_direct_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY)
+#ifndef RT_LAT_DIRECT_WAVES
+#define RT_LAT_DIRECT_WAVES 4   // 128 VGPRs: two workgroups per CU (151 VGPRs and one workgroup at 2: 15-30 % slower on every band, scripts/r03_dw4.sh)
+#endif
+__global__ __launch_bounds__(512, RT_LAT_DIRECT_WAVES) void k_direct_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY)
 {
   extern __shared__ uint2 s_stack[];
   const TileCoord tile = tileOf(tilesX, tilesY);
@@ -258,7 +261,11 @@ __global__ __launch_bounds__(512, 2) void k_direct_stage(DevScene S, DevFrame F,
       rec[0] = uint32_t(tile.x); rec[1] = uint32_t(tile.y); rec[2] = uint32_t(p5 - p0); rec[3] = uint32_t(p2 - p1); rec[4] = uint32_t(p4 - p3);
       rec[7] = uint32_t(p1 - p0); rec[10] = uint32_t(p3 - p2); rec[11] = uint32_t(p5 - p4); rec[15] = uint32_t(wall_clock64() - w0);
     }
-    if(lane == 0) { atomicMax(&rec[5], c.tc.rN); atomicMax(&rec[6], c.tc.rT); atomicMax(&rec[8], c.tc.cN); atomicMax(&rec[9], c.tc.cT); }
+    if(lane == 0) { atomicMax(&rec[5], c.tc.rN); atomicMax(&rec[6], c.tc.rT); atomicMax(&rec[8], c.tc.cN); atomicMax(&rec[9], c.tc.cT); atomicAdd(&rec[12], c.tc.rC); atomicAdd(&rec[13], c.tc.rN + c.tc.rT);   // 12 / (8 x 13) = share of the ray slots in use
+      uint32_t* acc = F.waveProf + size_t(65535) * 16;   // launch totals: cycles by phase of the triangle step, [7] = steps, [8] = cycles of rounds with a triangle step
+      for(int k = 0; k < 7; k++) atomicAdd(&acc[k], c.tc.ph[k] >> 4);
+      atomicAdd(&acc[7], c.tc.ph[7]);
+      atomicAdd(&acc[8], c.tc.cT >> 4); }
   }
 #endif
 }

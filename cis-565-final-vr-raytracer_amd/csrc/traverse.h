@@ -29,6 +29,7 @@ struct TravCounters {
   uint32_t nodes, tris, rounds, live;
 #if RT_WAVEPROF
   uint32_t rN, rT, rC, cN, cT, cC, aTex, aOmm;   // rounds / cycles by kind (node, triangle, cooperative tail), alpha candidates by resolution
+  uint32_t ph[8];                                // wide traversal: cycles by phase of the triangle step (see travTriW), [7] = steps
 #endif
 };
 
@@ -53,6 +54,11 @@ RT_DEV int wrapCoord(int i, int n, int mode)
   }
   return floorMod(i, n);
 }
+// REPEAT on power-of-two sizes (every texture of the benchmark scenes, most glTF assets) is a mask; anything else takes the general path, whose integer
+// modulo costs ~80 instructions per coordinate.  Callers choose per WAVE (a scalar branch: the general path is skipped, not predicated, when no active lane
+// needs it); both paths return the same values.
+RT_DEV bool wrapIsMask(int w, int h, int wrapS, int wrapT) { return (((w & (w - 1)) | (h & (h - 1))) == 0) && wrapS == RT_WRAP_REPEAT && wrapT == RT_WRAP_REPEAT; }
+RT_DEV bool waveNone(bool c) { return __builtin_amdgcn_ballot_w64(c) == 0ull; }
 RT_DEV f4 texelBGRA(const DevTexture& t, int x, int y)
 {
   uint32_t p = *reinterpret_cast<const uint32_t*>(t.bgra + (size_t(y) * t.w + x) * 4);
@@ -62,16 +68,22 @@ RT_DEV f4 sampleTexture(const DevScene& S, int id, f2 uv)
 {
   const DevTexture t = S.textures[id];
   float fx = uv.x * float(t.w), fy = uv.y * float(t.h);
+  const bool masks = waveNone(!wrapIsMask(t.w, t.h, t.wrapS, t.wrapT));
   if(t.filter == RT_FILTER_NEAREST) {
-    int x = wrapCoord(rt_ftoi(rt_floor(fx)), t.w, t.wrapS), y = wrapCoord(rt_ftoi(rt_floor(fy)), t.h, t.wrapT);
-    return texelBGRA(t, x, y);
+    const int xi = rt_ftoi(rt_floor(fx)), yi = rt_ftoi(rt_floor(fy));
+    if(masks) return texelBGRA(t, xi & (t.w - 1), yi & (t.h - 1));
+    return texelBGRA(t, wrapCoord(xi, t.w, t.wrapS), wrapCoord(yi, t.h, t.wrapT));
   }
   fx = fx - 0.5f; fy = fy - 0.5f;
   float x0f = rt_floor(fx), y0f = rt_floor(fy);
   float ax = fx - x0f, ay = fy - y0f;
   int x0 = rt_ftoi(x0f), y0 = rt_ftoi(y0f);
-  int xa = wrapCoord(x0, t.w, t.wrapS), xb = wrapCoord(x0 + 1, t.w, t.wrapS);
-  int ya = wrapCoord(y0, t.h, t.wrapT), yb = wrapCoord(y0 + 1, t.h, t.wrapT);
+  int xa, xb, ya, yb;
+  if(masks) { xa = x0 & (t.w - 1); xb = (x0 + 1) & (t.w - 1); ya = y0 & (t.h - 1); yb = (y0 + 1) & (t.h - 1); }
+  else {
+    xa = wrapCoord(x0, t.w, t.wrapS); xb = wrapCoord(x0 + 1, t.w, t.wrapS);
+    ya = wrapCoord(y0, t.h, t.wrapT); yb = wrapCoord(y0 + 1, t.h, t.wrapT);
+  }
   f4 top = mix(texelBGRA(t, xa, ya), texelBGRA(t, xb, ya), ax);
   f4 bot = mix(texelBGRA(t, xa, yb), texelBGRA(t, xb, yb), ax);
   return mix(top, bot, ay);
@@ -134,8 +146,12 @@ RT_DEV AlphaFetch alphaAddr(const AlphaRegs& A, float u, float v, const uint8_t*
     const f2 uv = (mk2(rt_u2f(A.r0.x), rt_u2f(A.r0.y)) * bary.x + mk2(rt_u2f(A.r0.z), rt_u2f(A.r0.w)) * bary.y) + mk2(rt_u2f(A.r1.x), rt_u2f(A.r1.y)) * bary.z;
     const int w = int(A.r2.z), h = int(A.r2.w), wrapS = int(A.r3.x), wrapT = int(A.r3.y), filter = int(A.r3.z);
     float fx = uv.x * float(w), fy = uv.y * float(h);
+    const bool masks = waveNone(!wrapIsMask(w, h, wrapS, wrapT));
     if(filter == RT_FILTER_NEAREST) {
-      const int x = wrapCoord(rt_ftoi(rt_floor(fx)), w, wrapS), y = wrapCoord(rt_ftoi(rt_floor(fy)), h, wrapT);
+      const int xi = rt_ftoi(rt_floor(fx)), yi = rt_ftoi(rt_floor(fy));
+      int x, y;
+      if(masks) { x = xi & (w - 1); y = yi & (h - 1); }
+      else { x = wrapCoord(xi, w, wrapS); y = wrapCoord(yi, h, wrapT); }
       F.p00 = F.p10 = F.p01 = F.p11 = bgra + (size_t(y) * w + x) * 4 + 3;
       F.kind = 1;
     } else {
@@ -143,8 +159,12 @@ RT_DEV AlphaFetch alphaAddr(const AlphaRegs& A, float u, float v, const uint8_t*
       const float x0f = rt_floor(fx), y0f = rt_floor(fy);
       F.ax = fx - x0f; F.ay = fy - y0f;
       const int x0 = rt_ftoi(x0f), y0 = rt_ftoi(y0f);
-      const int xa = wrapCoord(x0, w, wrapS), xb = wrapCoord(x0 + 1, w, wrapS);
-      const int ya = wrapCoord(y0, h, wrapT), yb = wrapCoord(y0 + 1, h, wrapT);
+      int xa, xb, ya, yb;
+      if(masks) { xa = x0 & (w - 1); xb = (x0 + 1) & (w - 1); ya = y0 & (h - 1); yb = (y0 + 1) & (h - 1); }
+      else {
+        xa = wrapCoord(x0, w, wrapS); xb = wrapCoord(x0 + 1, w, wrapS);
+        ya = wrapCoord(y0, h, wrapT); yb = wrapCoord(y0 + 1, h, wrapT);
+      }
       F.p00 = bgra + (size_t(ya) * w + xa) * 4 + 3; F.p10 = bgra + (size_t(ya) * w + xb) * 4 + 3;
       F.p01 = bgra + (size_t(yb) * w + xa) * 4 + 3; F.p11 = bgra + (size_t(yb) * w + xb) * 4 + 3;
       F.kind = 2;
@@ -759,24 +779,36 @@ RT_DEV void travTriW(const DevScene& S, Trav& T, int j, TravCounters& tc)
   T.tgroup.y = rem;
   WideCand c; c.t = __builtin_huge_valf(); c.gid = 0xffffffffu; c.u = 0.0f; c.v = 0.0f;
   bool ok = false;
+#if RT_WAVEPROF
+#define RT_PH(k) { __builtin_amdgcn_s_waitcnt(0); const uint64_t pn = clock64(); tc.ph[k] += uint32_t(pn - pc); pc = pn; }
+  uint64_t pc = clock64(); tc.ph[7]++;
+#else
+#define RT_PH(k)
+#endif
   if(mine >= 0) {
     float t, u, v; uint32_t gid, alphaIdx;
     const uint32_t ti = T.tgroup.x + uint32_t(mine);
     const TriRegs Q = triLoad(S, ti);
     const uint4* ap = reinterpret_cast<const uint4*>(S.alphaByTri + ti);   // fetched with the record, whether needed or not: no second dependent access
     AlphaRegs A; A.r0 = ap[0]; A.r1 = ap[1]; A.r2 = ap[2]; A.r3 = ap[3];
+    RT_PH(0)   // record + AlphaRec arrive
     const int s = triCandidateGeom(S, Q, T.o, T.d, ANY, T.tmax, T.hit.t, T.hit.gid, T.seed, t, u, v, gid, alphaIdx, tc);
     ok = s == 1;
+    RT_PH(1)   // intersection, padded-box check, opacity micro-map
     if(s == 2) {
       const AlphaFetch Fh = alphaAddr(A, u, v, reinterpret_cast<const uint8_t*>(S.alphaRec));
+      RT_PH(2) // texel addresses
       uint8_t a00 = 0, a10 = 0, a01 = 0, a11 = 0;
       if(Fh.kind == 1) a00 = *Fh.p00;
       else if(Fh.kind == 2) { a00 = *Fh.p00; a10 = *Fh.p10; a01 = *Fh.p01; a11 = *Fh.p11; }
+      RT_PH(3) // texels arrive
       ok = alphaFinish(A, Fh, a00, a10, a01, a11, gid, T.seed);
+      RT_PH(4) // filter + draw
     }
     if(ok) { c.t = t; c.gid = gid; c.u = u; c.v = v; }
   }
   // (all eight lanes of the group are back together here)
+  RT_PH(5)
   groupMinCand(c);
   const bool any = c.t < __builtin_huge_valf();   // an accepted candidate has a finite t
   if(any && (ANY || c.t < T.hit.t || (c.t == T.hit.t && c.gid < T.hit.gid))) {
@@ -784,19 +816,24 @@ RT_DEV void travTriW(const DevScene& S, Trav& T, int j, TravCounters& tc)
     T.found = true;
     if(ANY) { T.tgroup.y = 0u; T.ngroup.y = 0u; T.sp = 0; }
   }
+  RT_PH(6)     // minimum over the group, hit update
+#undef RT_PH
   (void)ok;
 }
-// one round of a wave: every group advances its ray — a triangle step if the ray has pending triangles, a node step otherwise; node fetches are issued
-// before the triangle work of the other groups
+// one round of a wave: a ray wants a triangle step if it has pending triangles, a node step otherwise; the wave takes the kind most of its rays want
 template <int MODE>
 RT_DEV bool travRoundW(const DevScene& S, Trav& T, bool live, int j, uint2* stack, TravCounters& tc)
 {
-  const bool wantTri = live && travHasTris(T);
-  const bool wantNode = live && !wantTri;
-  NodeRegs N{};
-  if(wantNode) N = nodeLoad(S, travNodeSelectW(T, stack, j));
+  bool wantTri = live && travHasTris(T);
+  bool wantNode = live && !wantTri;
+  {  // One kind of step per round, by vote of the wave's rays; the rays that wanted the other kind wait a round.  A round that serves both kinds costs the
+     // sum of the two (the groups diverge), i.e. a ray's cheap node steps are billed at the price of another ray's triangle step: with the vote the direct
+     // stage of a band takes 10-15 % less, the indirect stage 3-8 % (profiles/r03_lat_wide_ab.txt).  The result does not depend on the order of the steps.
+    const int nT = __popcll(__ballot(wantTri ? 1 : 0)), nN = __popcll(__ballot(wantNode ? 1 : 0));
+    if(nT >= nN) wantNode = false; else wantTri = false;
+  }
   if(wantTri) travTriW<MODE>(S, T, j, tc);
-  if(wantNode) travNodeTestW(T, N, j);
+  if(wantNode) { const NodeRegs N = nodeLoad(S, travNodeSelectW(T, stack, j)); travNodeTestW(T, N, j); }
   return live && (travHasTris(T) || travHasNodes(T));
 }
 
@@ -840,6 +877,7 @@ RT_DEV void tracePoolWide(const DevScene& S, float4* pool, const unsigned char* 
 #if RT_WAVEPROF
     const uint64_t pc0 = clock64();
     const bool anyTri = __ballot((live && travHasTris(T)) ? 1 : 0) != 0ull;
+    tc.rC += uint32_t(__popcll(liveMask & leaders));   // rays served this round (of WIDE_RAYS)
 #endif
     const bool still = travRoundW<2>(S, T, live, j, stack, tc);
 #if RT_WAVEPROF

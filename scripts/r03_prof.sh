@@ -4,6 +4,6 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r03p}; mkdir -p $O; shift
 cd $R
 export RESTIR_HIP_LIB=$R/cis-565-final-vr-raytracer_amd/csrc/_ab/librestir_hip_prof.so
 for e in "$@"; do export $e; done
-timeout 600 python scripts/wave_profile.py 496 528 528 576 > $O/wave_profile.txt 2>&1
+timeout 600 python scripts/wave_profile.py ${BANDS:-496 528 528 576} > $O/wave_profile.txt 2>&1
 grep -v "^   (" $O/wave_profile.txt | tail -40
-grep -A4 "slowest waves" $O/wave_profile.txt | head -40
+grep -A6 "slowest w" $O/wave_profile.txt | head -40

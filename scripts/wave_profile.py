@@ -46,6 +46,10 @@ def timed(fn, n=5):
 
 
 def report_wide(name, rec, ms):
+    acc = rec[65535].astype(np.float64); rec = rec[:65535]
+    if acc[7] > 0:
+        names = ["record+AlphaRec arrive", "intersection/box/micro-map", "texel addresses", "texels arrive", "filter+draw", "rejoin", "group minimum + update"]
+        print("   triangle step, cycles per step by phase (all waves): " + ", ".join(f"{n} {16 * acc[k] / acc[7]:.0f}" for k, n in enumerate(names)) + f"; sum {16 * acc[:7].sum() / acc[7]:.0f}; whole round {16 * acc[8] / acc[7]:.0f}")
     rec = rec[rec[:, 2] > 0]
     if len(rec) == 0:
         print(name, "no records"); return
@@ -57,8 +61,9 @@ def report_wide(name, rec, ms):
     print("   slowest workgroups: tile | total us | raygen | primary trace | pre-shadow shading | shadow trace | post | rounds node-only/with-tris (slowest wave) | cycles per round")
     for i in order[:12]:
         q = rec[i].astype(np.float64)
-        print(f"   ({int(q[0]):4d},{int(q[1]):3d}) | {us(q[2]):7.1f} | {us(q[7]):5.1f} | {us(q[3]):7.1f} | {us(q[10]):6.1f} | {us(q[4]):7.1f} | {us(q[11]):5.1f} | {int(q[5]):4d}/{int(q[6]):4d} | {q[8] / max(1, q[5]):6.0f}/{q[9] / max(1, q[6]):6.0f}")
+        print(f"   ({int(q[0]):4d},{int(q[1]):3d}) | {us(q[2]):7.1f} | {us(q[7]):5.1f} | {us(q[3]):7.1f} | {us(q[10]):6.1f} | {us(q[4]):7.1f} | {us(q[11]):5.1f} | {int(q[5]):4d}/{int(q[6]):4d} | {q[8] / max(1, q[5]):6.0f}/{q[9] / max(1, q[6]):6.0f} | ray slots in use {100 * q[12] / max(1, 8 * q[13]):.0f} % of {int(q[13])} wave-rounds")
     m = rec.astype(np.float64).mean(axis=0)
+    print(f"   ray slots in use over all workgroups: {100 * rec[:, 12].sum() / max(1, 8 * rec[:, 13].sum()):.0f} %")
     print(f"   mean workgroup: total {us(m[2]):.1f} us = raygen {us(m[7]):.1f} + primary {us(m[3]):.1f} + pre {us(m[10]):.1f} + shadow {us(m[4]):.1f} + post {us(m[11]):.1f}")
     pct = np.percentile(cyc, [50, 90, 99, 100])
     print(f"   workgroup time percentiles (us): p50 {us(pct[0]):.1f} p90 {us(pct[1]):.1f} p99 {us(pct[2]):.1f} max {us(pct[3]):.1f}; sum over workgroups / 512 concurrent = {us(cyc.sum()) / 512 / 1e3:.3f} ms")
