@@ -46,7 +46,7 @@ struct Builder2 {
       constexpr int NBMAX = 64;
       static const int envNB = getenv("RESTIR_BVH_BINS") ? std::min(NBMAX, std::max(4, atoi(getenv("RESTIR_BVH_BINS")))) : 16;
       static const float leafSlotCost = getenv("RESTIR_BVH_SLOTCOST") ? float(atof(getenv("RESTIR_BVH_SLOTCOST"))) : 0.25f;  // measured: 0.25 beats 0.5 by 2 % on the Bistro-class scene, bins 16 vs 32 vs 64 make no difference
-      const int NB = (cnt <= 64 && getenv("RESTIR_BVH_FINE")) ? NBMAX : envNB;
+      const int NB = envNB;
       float best = 3e38f; int bestAxis = -1, bestBin = 0;
       for(int ax = 0; ax < 3; ax++) {
         float ext = cb.hi[ax] - cb.lo[ax];
@@ -201,7 +201,7 @@ bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads)
   // node visits per ray only 16.49 -> 16.18 (the visits are in the upper and middle levels, not in the under-filled bottom nodes), depth
   // 11 -> 13, direct stage -2 %, indirect stage +4.6 %: no net gain, so the greedy rule stays the default (RESTIR_BVH_COLLAPSE=dp selects this).
   static const bool useDp = getenv("RESTIR_BVH_COLLAPSE") && strcmp(getenv("RESTIR_BVH_COLLAPSE"), "dp") == 0;
-  static const float cNode = getenv("RESTIR_BVH_CNODE") ? float(atof(getenv("RESTIR_BVH_CNODE"))) : 2.3f;   // a node step is ~230 instructions,
+  static const float cNode = 2.3f;   // a node step is ~230 instructions,
   static const float cTri = 1.0f;                                                                            // a triangle step ~100
   const uint32_t n2count = B2.nodeCount.load();
   std::vector<float> cost;        // [n][i], i = 1..7 at [n * 8 + i]

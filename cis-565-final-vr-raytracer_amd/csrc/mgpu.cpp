@@ -1,5 +1,6 @@
 // mgpu.cpp — rt_mgpu_*: the row-tiled multi-GPU frame as ONE native context that drives N devices from one
-// process: one host thread, one rt_ctx and one HIP stream per device, halos moved with hipMemcpyPeerAsync over xGMI.
+// process: one host thread, one rt_ctx and one (barrier schedule) or three (frames in flight) HIP streams per device, halos moved with
+// hipMemcpyPeerAsync over xGMI.
 // It is the C-ABI form of what restir_amd/tiled.py does over torch.distributed: a C++ host (the reference's language,
 // src/main.cpp:200-264) gets the multi-GPU frame behind the same five calls as the single-GPU one, and no Python runs per frame.
 //
@@ -10,7 +11,7 @@
 // what the history halo covers.  Scene, BVH8 and full-size screen buffers are replicated on every device; RNG seeds use global
 // pixel indices, so every output is bit-identical to the single-GPU frame (tests/test_gpu_mgpu.py).
 //
-// Frame schedule per rank (host barriers between the numbered steps; every copy is a PULL by the rank that needs the rows):
+// BARRIER SCHEDULE per rank (rt_mgpu_set_pipeline(0); host barriers between the numbered steps; every copy is a PULL by the rank that needs the rows):
 //   1. history: last frame's G-buffer / direct reservoirs / light ids / indirect reservoirs for the band +- 32 rows, from the ranks
 //      that owned those rows LAST frame (this also moves state when a boundary moved)
 //   2. direct stage on the band, indirect stage on the band's half-res rows; a temporal lookup outside band + halo raises a flag;
@@ -105,7 +106,6 @@ struct Rank {
   int64_t aIssued = -1;                                               // frame sequence number whose direct stage has been issued (look-ahead)
   int rotatedFor = -1;                                                // `frames` value the rotating buffer ids currently name
   int mode = -1;                                                      // rt_set_overlap value of the ctx (0: barrier schedule, 2: frames in flight)
-  double logT0 = 0;
   std::thread th;
   std::mutex qm; std::condition_variable qcv; std::deque<Cmd> q;
   int rc = RT_OK;
@@ -559,11 +559,6 @@ bool peersReadyForDirect(rt_mgpu& M, Rank& R, const FrameCmd& next)
   return true;
 }
 
-// host-side step log of one rank (RESTIR_MGPU_LOG=<rank>): where the rank's thread spends its time within a frame
-static double nowUs() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-static int logRank() { static const int r = getenv("RESTIR_MGPU_LOG") ? atoi(getenv("RESTIR_MGPU_LOG")) : -1; return r; }
-#define MG_LOG(what) do { if(R.id == logRank()) fprintf(stderr, "[mgpu %d] seq %lld %-28s %.1f us\n", R.id, (long long)c.seq, what, nowUs() - R.logT0); } while(0)
-
 // One frame of the frames-in-flight schedule.  `next`: the frame after this one if the application has already queued it — its direct stage is then issued
 // as soon as this frame's direct stage is validated, BEFORE this frame's indirect stage and filters, so the main stream never waits for the host.
 void framePipelined(rt_mgpu& M, Rank& R, const FrameCmd& c)
@@ -574,25 +569,21 @@ void framePipelined(rt_mgpu& M, Rank& R, const FrameCmd& c)
     for(auto& a : R.issued) a.store(s, std::memory_order_release);
     return;
   }
-  if(R.id == logRank()) { if(R.logT0 == 0) R.logT0 = nowUs(); }
-  MG_LOG("begin");
-  if(R.aIssued != s) { pipeDirect(M, R, c); MG_LOG("direct issued"); }
+  if(R.aIssued != s) pipeDirect(M, R, c);
   // second half of frame f-1, issued while direct(f) runs (the ids of the rotating buffers name frame f's: finishPrev undoes that for a re-run only)
   finishPrev(M, R, R.rotatedFor);
-  MG_LOG("second half of f-1 issued");
+
   pipeValidateDirect(M, R, c);
-  MG_LOG("direct validated");
-  static const int ahead = getenv("RESTIR_MGPU_AHEAD") ? atoi(getenv("RESTIR_MGPU_AHEAD")) : 1;
+
   // look-ahead: has the application queued the next frame by now?  (looked up here, a direct stage after this frame was taken from the queue)
   Cmd nextCmd; bool haveNext = false;
-  if(ahead) {
+  {
     std::lock_guard<std::mutex> l(R.qm);
     if(R.q.size() >= 2 && R.q[1].kind == Cmd::FRAMEP) { nextCmd = R.q[1]; haveNext = true; }
   }
   const FrameCmd* next = haveNext ? &nextCmd.f : nullptr;
-  if(next && next->seq == s + 1 && !(next->solo >= 0 && next->solo != R.id) && peersReadyForDirect(M, R, *next)) { pipeDirect(M, R, *next); MG_LOG("next direct issued (ahead)"); }
+  if(next && next->seq == s + 1 && !(next->solo >= 0 && next->solo != R.id) && peersReadyForDirect(M, R, *next)) pipeDirect(M, R, *next);
   pipeIndirectAndDirectFilters(M, R, c);
-  MG_LOG("indirect + filters issued");
 }
 
 void drainRank(rt_mgpu& M, Rank& R)
@@ -777,10 +768,10 @@ int rt_mgpu_create(rt_mgpu** out, int numRanks, const int* devices)
     (void)hipSetDevice(R.dev);
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    // stream priorities (RESTIR_MGPU_PRIO: 0 none, 1 indirect stream high, 2 main stream high (default)).  Measured per-rank periods of the 8-way 1080p
+    // stream priorities (0 none, 1 indirect stream high, 2 main stream high: the one used).  Measured per-rank periods of the 8-way 1080p
     // benchmark frame (profiles/r03_mgpu_period_ab.txt): slowest rank 1.91 / 1.80 / 1.63 ms for 0 / 1 / 2 — the direct stage of frame f+1 is what the
     // next frame of EVERY rank waits for
-    static const int prio = getenv("RESTIR_MGPU_PRIO") ? atoi(getenv("RESTIR_MGPU_PRIO")) : 2;
+    const int prio = 2;
     const bool can = hi < lo;
     bool ok = (can && prio == 2 ? hipStreamCreateWithPriority(&R.stream, hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking)) == hipSuccess;
     ok = ok && (can && prio == 1 ? hipStreamCreateWithPriority(&R.sInd, hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(&R.sInd, hipStreamNonBlocking)) == hipSuccess;
@@ -802,7 +793,6 @@ int rt_mgpu_create(rt_mgpu** out, int numRanks, const int* devices)
       if(hipDeviceCanAccessPeer(&can, da, db) == hipSuccess && can) { (void)hipSetDevice(da); (void)hipDeviceEnablePeerAccess(db, 0); (void)hipGetLastError(); }
     }
   M->step.init(numRanks);
-  if(const char* e = getenv("RESTIR_MGPU_PIPELINE")) M->pipeline = atoi(e) != 0;
   for(int r = 0; r < numRanks; r++) M->ranks[size_t(r)].th = std::thread(worker, M, r);
   *out = M;
   return RT_OK;

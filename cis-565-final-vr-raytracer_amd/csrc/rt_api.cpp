@@ -265,7 +265,6 @@ int rt_create(rt_ctx** out, int device)
     if(!ok) { g_createErr = "rt_create: creating the internal events failed"; rt_destroy(c); return RT_ERR_HIP; }
   }
   if(const char* e = getenv("RESTIR_OVERLAP")) c->overlap = atoi(e);
-  if(const char* e = getenv("RESTIR_LAT")) c->traversal = atoi(e) ? RT_TRAVERSAL_LATENCY : RT_TRAVERSAL_THROUGHPUT;   // A/B runs and the forced-variant parity tests
   if(hipMalloc(reinterpret_cast<void**>(&c->dCounters), 8 * sizeof(unsigned long long)) != hipSuccess) { g_createErr = "rt_create: hipMalloc failed"; delete c; return RT_ERR_OOM; }
   (void)hipMemset(c->dCounters, 0, 8 * sizeof(unsigned long long));
   *out = c;
@@ -536,11 +535,14 @@ int rt_resize(rt_ctx* c, int w, int h)
 }
 
 // Overflow part of the traversal stacks (DevScene::stackOvf): (stackTotal - stackEntries) entries for every thread of the largest traced launch of
-// this frame size, one area per stage kind.  (Re)allocated when the tree or the frame size changes; touched only by rays that go deeper than the LDS part.
+// this frame size, one area per stage kind.  Only schedules that shorten the LDS stack touch them (frames in flight, RESTIR_STACK_LDS), so they are
+// allocated when such a schedule is selected and (re)sized when the tree or the frame size changes; a serial ctx (every rt_mgpu rank of the barrier
+// schedule) holds none.  Callers have drained the ctx.
 static int ensureStackOverflow(rt_ctx* c)
 {
   freePool(c->ovfAllocs);
   c->ds.stackOvf = c->ds.stackOvfInd = nullptr; c->ds.stackOvfThreads = 0;
+  if(!(stackLdsEnv() || c->overlap == 2)) return RT_OK;
   if(!c->haveAccel || c->W <= 0 || c->ds.stackTotal <= stackLdsMin()) return RT_OK;
   const size_t tilesX = size_t(c->W + 7) / 8, tilesY = size_t(c->H + 7) / 8;
   const size_t blocks = std::max<size_t>(16384, tilesX * tilesY + 8 * tilesX + 1024);   // >= any traced grid: tileGrid() of the full frame; 4 waves per half-res tile; persistent launches
@@ -928,7 +930,9 @@ int rt_set_overlap(rt_ctx* c, int mode)
   if(!c || mode < 0 || mode > 2) return RT_ERR_INVALID_ARG;
   RT_HIP(c, hipSetDevice(c->device));
   RT_HIP(c, syncAll(c));
+  const bool hadShort = c->overlap == 2;
   c->overlap = mode;
+  if((mode == 2) != hadShort) return ensureStackOverflow(c);   // the short LDS stacks of frames in flight spill into an HBM area that serial schedules do not hold
   return RT_OK;
 }
 

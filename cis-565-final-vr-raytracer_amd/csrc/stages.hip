@@ -17,7 +17,7 @@
 //                 flush the compiler removes the per-round counter increments from the traversal loops: -1.7 % frame time.
 //   RT_LAT = 1    the traced kernels for SMALL launches (row bands of a multi-GPU frame, small images): the latency-mode traversal round of
 //                 traverse.h and two waves per SIMD worth of registers.  Only the three traced kernels are compiled; every other stage forwards to
-//                 the throughput build.  rt_api.cpp picks per launch (launch size; RESTIR_LAT=0|1 forces).  Same bits.
+//                 the throughput build.  rt_api.cpp picks per launch (launch size; rt_set_traversal forces).  Same bits.
 #ifndef RT_SKY
 #define RT_SKY 0
 #endif
@@ -203,7 +203,7 @@ RT_DEV void groupTrace(const DevScene& S, const WideLds& L, TravCounters& tc)
 }
 
 #ifndef RT_LAT_DIRECT_WAVES
-#define RT_LAT_DIRECT_WAVES 4   // 128 VGPRs: two workgroups per CU (151 VGPRs and one workgroup at 2: 15-30 % slower on every band, scripts/r03_dw4.sh)
+#define RT_LAT_DIRECT_WAVES 4   // 128 VGPRs: two workgroups per CU (151 VGPRs and one workgroup at 2: 15-30 % slower on every band, scripts/variants_ab.sh with -DRT_LAT_DIRECT_WAVES=2)
 #endif
 __global__ __launch_bounds__(512, RT_LAT_DIRECT_WAVES) void k_direct_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY)
 {
@@ -811,7 +811,11 @@ __global__ __launch_bounds__(64, RT_INDIRECT_LB) void k_indirect_stage(DevScene 
     if(__ballot((hasShadow || hasBounce) ? 1 : 0) == 0ull) break;  // wave-uniform
 #if RT_LAT
     poolPublish(WL, hasBounce, hasShadow);
+#if RT_WAVEPROF
+    { const uint64_t g0 = clock64(); groupTrace(S, WL, c.tc); c.cycClosest += uint32_t(clock64() - g0); c.cycAny++; }   // [3] cycles in the pool traces, [4] their number
+#else
     groupTrace(S, WL, c.tc);
+#endif
 #else
     tracePool(S, pool, hasBounce, hasShadow, c.stack, c.tc);
 #endif
@@ -1191,7 +1195,7 @@ hipError_t launchStage(hipStream_t stream, const DevScene& Sin, const DevFrame& 
   DevScene S = Sin;
 #if RT_LAT
   S.stackEntries = S.stackTotal;   // one column per RAY (8 per wave): the whole stack fits in LDS
-  static const int nwEnv = getenv("RESTIR_LAT_WAVES") ? std::max(1, std::min(8, atoi(getenv("RESTIR_LAT_WAVES")))) : 8;
+  const int nwEnv = 8;   // waves per workgroup of the latency kernels (3 / 4 / 6 measured: slower, profiles/r03_band_chunk_ab.txt)
   const int nWaves = nwEnv;        // waves per tile workgroup
 #else
   S.stackEntries = F.stackLds > 0 ? std::min(F.stackLds, S.stackTotal) : S.stackTotal;   // LDS part of the traversal stack for this launch

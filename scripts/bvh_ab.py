@@ -12,7 +12,7 @@ r.update(W, H); r.set_overlap(0)
 sc.updateCamera(W, H)
 for f in range(4):
     st.time = 1000 + f; sc.updateCamera(W, H); r.set_camera(sc.getCamera()); r.run(st, f)
-out = [os.environ.get("RESTIR_BVH_COLLAPSE", "dp"), "cnode=" + os.environ.get("RESTIR_BVH_CNODE", "2.3"), str(r.accel_stats()), "build %.2fs" % tb]
+out = [os.environ.get("RESTIR_BVH_COLLAPSE", "dp"), str(r.accel_stats()), "build %.2fs" % tb]
 for stage, name in ((abi.STAGE_DIRECT, "direct"), (abi.STAGE_INDIRECT, "indirect")):
     r.sync(); t0 = time.perf_counter()
     for _ in range(8): r.run_stage(st, 4, stage)

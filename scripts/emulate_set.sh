@@ -2,7 +2,7 @@
 # the emulation set of a round: N = 2, 4, 8 at 1080p and N = 4, 8 at 4K
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r03o}; mkdir -p $O
 cd $R
-for n in 2 4; do timeout 900 python bench.py --emulate-world $n --steps 30 --warmup 12 > $O/emulate${n}_1080p.json 2> $O/e.err; done
+for n in 2 4 8; do timeout 900 python bench.py --emulate-world $n --steps 30 --warmup 12 > $O/emulate${n}_1080p.json 2> $O/e.err; done
 for n in 4 8; do timeout 1800 python bench.py --emulate-world $n --width 3840 --height 2160 --steps 20 --warmup 10 > $O/emulate${n}_4k.json 2> $O/e.err; done
 for f in $O/emulate*.json; do python - $f <<'PY'
 import json,sys

@@ -10,4 +10,4 @@ print("bench", d["value"], d["unit"], d["ms_per_step"], "serial", d.get("ms_per_
 print("   serial stages", d["roofline"].get("stage_ms_per_frame"))
 PY
 timeout 900 python scripts/band_ab.py 496 512 544 560 496 528 528 576 256 368 > $O/band.txt 2>&1; grep rows $O/band.txt
-[ "$2" == "noemu" ] || bash scripts/r03_emu8.sh $T
+[ "$2" == "noemu" ] || bash scripts/emulate8.sh $T

@@ -1,5 +1,5 @@
 #!/bin/bash
-# band A/B of measurement builds: scripts/r03_variants.sh <tag> <variant> [<variant> ...]   (csrc/_ab/librestir_hip_<variant>.so; "product" = the product build)
+# band A/B of measurement builds: scripts/variants_ab.sh <tag> <variant> [<variant> ...]   (csrc/_ab/librestir_hip_<variant>.so; "product" = the product build)
 R=$GRAFT_REPO_ROOT; T=${1:-r03var}; O=$R/gpurun_out/$T; mkdir -p $O; shift
 cd $R
 B=${BANDS:-"496 512 544 560 496 528 528 576 464 528"}

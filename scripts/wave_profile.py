@@ -23,6 +23,8 @@ sc, env = make_scene(abi.PROC_BISTRO_EXT, 1.0, 1, (2048, 1024))
 st = host.default_state(W, H, sc, env)
 r = Renderer().setup(0); r.load_scene(sc.desc(env)); r.update(W, H)
 r.set_overlap(0)
+LAT = os.environ.get("WAVE_PROFILE_LAT") == "1"     # the latency build of the traced kernels instead of the throughput build
+r.set_traversal(abi.TRAVERSAL_LATENCY if LAT else abi.TRAVERSAL_THROUGHPUT)
 sc.updateCamera(W, H)
 for f in range(6):
     st.time = 1000 + f; sc.updateCamera(W, H); r.set_camera(sc.getCamera()); r.run(st, f)
@@ -100,4 +102,4 @@ for (y0, y1) in bands:
         ms = timed(lambda: r.run_stage(st, f, stage, 0, a, b))
         prof()
         r.run_stage(st, f, stage, 0, a, b); r.sync()
-        (report_wide if (os.environ.get("RESTIR_LAT") == "1" and nm == "direct") else report)(f"{nm} rows {a}..{b}", prof(), ms)
+        (report_wide if (LAT and nm == "direct") else report)(f"{nm} rows {a}..{b}", prof(), ms)
