@@ -265,7 +265,9 @@ __global__ __launch_bounds__(512, RT_LAT_DIRECT_WAVES) void k_direct_stage(DevSc
       uint32_t* acc = F.waveProf + size_t(65535) * 16;   // launch totals: cycles by phase of the triangle step, [7] = steps, [8] = cycles of rounds with a triangle step
       for(int k = 0; k < 7; k++) atomicAdd(&acc[k], c.tc.ph[k] >> 4);
       atomicAdd(&acc[7], c.tc.ph[7]);
-      atomicAdd(&acc[8], c.tc.cT >> 4); }
+      atomicAdd(&acc[8], c.tc.cT >> 4);
+      for(int k = 0; k < 3; k++) atomicAdd(&acc[9 + k], c.tc.nph[k] >> 4);
+      atomicAdd(&acc[12], c.tc.nph[3]); }
   }
 #endif
 }

@@ -30,6 +30,7 @@ struct TravCounters {
 #if RT_WAVEPROF
   uint32_t rN, rT, rC, cN, cT, cC, aTex, aOmm;   // rounds / cycles by kind (node, triangle, cooperative tail), alpha candidates by resolution
   uint32_t ph[8];                                // wide traversal: cycles by phase of the triangle step (see travTriW), [7] = steps
+  uint32_t nph[4];                               // and of the node step (travRoundW), [3] = steps
 #endif
 };
 
@@ -833,7 +834,20 @@ RT_DEV bool travRoundW(const DevScene& S, Trav& T, bool live, int j, uint2* stac
     if(nT >= nN) wantNode = false; else wantTri = false;
   }
   if(wantTri) travTriW<MODE>(S, T, j, tc);
+#if RT_WAVEPROF
+  if(wantNode) {   // ph[0..2] of node rounds: stack pop + select | node arrives | test
+    __builtin_amdgcn_s_waitcnt(0); const uint64_t q0 = clock64();
+    const uint32_t ni = travNodeSelectW(T, stack, j);
+    __builtin_amdgcn_s_waitcnt(0); const uint64_t q1 = clock64();
+    const NodeRegs N = nodeLoad(S, ni);
+    __builtin_amdgcn_s_waitcnt(0); const uint64_t q2 = clock64();
+    travNodeTestW(T, N, j);
+    const uint64_t q3 = clock64();
+    tc.nph[0] += uint32_t(q1 - q0); tc.nph[1] += uint32_t(q2 - q1); tc.nph[2] += uint32_t(q3 - q2); tc.nph[3]++;
+  }
+#else
   if(wantNode) { const NodeRegs N = nodeLoad(S, travNodeSelectW(T, stack, j)); travNodeTestW(T, N, j); }
+#endif
   return live && (travHasTris(T) || travHasNodes(T));
 }
 

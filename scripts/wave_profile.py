@@ -52,6 +52,8 @@ def report_wide(name, rec, ms):
     if acc[7] > 0:
         names = ["record+AlphaRec arrive", "intersection/box/micro-map", "texel addresses", "texels arrive", "filter+draw", "rejoin", "group minimum + update"]
         print("   triangle step, cycles per step by phase (all waves): " + ", ".join(f"{n} {16 * acc[k] / acc[7]:.0f}" for k, n in enumerate(names)) + f"; sum {16 * acc[:7].sum() / acc[7]:.0f}; whole round {16 * acc[8] / acc[7]:.0f}")
+    if acc[12] > 0:
+        print("   node step, cycles per step (all waves): " + ", ".join(f"{n} {16 * acc[9 + k] / acc[12]:.0f}" for k, n in enumerate(["stack pop + select", "node arrives", "test + reduce"])))
     rec = rec[rec[:, 2] > 0]
     if len(rec) == 0:
         print(name, "no records"); return
