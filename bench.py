@@ -579,9 +579,18 @@ def cpu_baseline(abi, host, scene, env, st, desc, W, H, frame0, di_only=False):
     mid = (H // 2 // 16) * 16
     band(max(0, mid - 32), min(H, mid + 32))                     # warm-up, 64 rows, not reported
     y0, y1 = max(0, mid - 128), min(H, mid + 128)
-    rays, dt = band(y0, y1)
-    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": o.threads, "kind": "port",
-            "sample": f"rows {y0}..{y1} of one {W}x{H} frame ({'direct stage' if di_only else 'all 12 dispatches'}, cold temporal history), after a 64-row warm-up band: "
+    # the same band, cold history each time, until >= 10 s of CPU work or 6 passes: a 256-thread pass of a few seconds moves by 2-3x with whatever else the
+    # host runs, so the MEDIAN pass is reported
+    passes, spent = [], 0.0
+    while len(passes) < 6 and (spent < 10.0 or len(passes) < 3):
+        o.resize(W, H); o.set_camera(scene.getCamera())          # (re-allocates the screen buffers: cold history again)
+        rays, dt = band(y0, y1)
+        passes.append((rays / dt, rays, dt)); spent += dt
+    passes.sort()
+    rate, rays, dt = passes[len(passes) // 2]
+    return {"value": round(rate / 1e6, 3), "unit": "Mrays/s", "cores": o.threads, "kind": "port",
+            "sample": f"rows {y0}..{y1} of one {W}x{H} frame ({'direct stage' if di_only else 'all 12 dispatches'}, cold temporal history), after a 64-row warm-up band; "
+                      f"median of {len(passes)} passes ({spent:.1f} s of CPU work, {passes[0][0] / 1e6:.3f}..{passes[-1][0] / 1e6:.3f} Mrays/s): "
                       f"{rays} rays in {dt:.2f} s => {dt * H / max(1, y1 - y0) * 1e3:.0f} ms/frame extrapolated (fixed sample since round 3; rounds 1-2 used other bands)"}
 
 
