@@ -41,4 +41,8 @@ for (y0, y1) in bands:
         td = timed(lambda: r.run_stage(st, f, abi.STAGE_DIRECT, 0, y0, y1))
         ti = timed(lambda: r.run_stage(st, f, abi.STAGE_INDIRECT, 0, y0 // 2, y1 // 2))
         line += f"  {nm}: direct {td:.3f} indirect {ti:.3f} sum {td + ti:.3f}"
+    r.set_traversal(abi.TRAVERSAL_AUTO)      # what the library picks for this launch (incl. the hybrid indirect stage)
+    td = timed(lambda: r.run_stage(st, f, abi.STAGE_DIRECT, 0, y0, y1))
+    ti = timed(lambda: r.run_stage(st, f, abi.STAGE_INDIRECT, 0, y0 // 2, y1 // 2))
+    line += f"  auto: direct {td:.3f} indirect {ti:.3f} sum {td + ti:.3f}"
     print(line, flush=True)
