@@ -3,6 +3,9 @@
 // (src/renderer.cpp:62-302, src/scene.cpp:453-508, src/accelstruct.cpp:55-65, src/hdr_sampling.cpp:79-95).
 #include <hip/hip_runtime.h>
 #include <array>
+#include <atomic>
+#include <memory>
+#include <mutex>
 #include <cmath>
 #include <cstdio>
 #include <map>
@@ -131,6 +134,17 @@ static StageLauncher stageLauncher(const rt_ctx* c, const rt_state& st, int stag
   if(c->ds.sky) return lat ? rt::sky_lat::launchStage : (c->counting ? rt::sky_cnt::launchStage : rt::sky::launchStage);
   return lat ? rt::base_lat::launchStage : (c->counting ? rt::base_cnt::launchStage : rt::base::launchStage);
 }
+
+// ---- host side of rt_build_accel, cached by scene content (buildHostAccel below) ---------------------------------------------------------------------
+struct HostAccel {
+  uint64_t key0 = 0, key1 = 0;      // content hash of everything the build reads
+  BuildOutput bo;
+  std::vector<AlphaRec> alpha;      // bgra left null: patched per device from alphaTex
+  std::vector<int32_t> alphaTex;    // texture index of every alpha record, -1 = none
+};
+static std::mutex g_accelMutex;
+static std::shared_ptr<const HostAccel> g_accelCache;   // the most recent build; dropped with the last context
+static std::atomic<int> g_liveCtx{0};
 
 static thread_local std::string g_createErr;
 
@@ -268,6 +282,7 @@ int rt_create(rt_ctx** out, int device)
   if(hipMalloc(reinterpret_cast<void**>(&c->dCounters), 8 * sizeof(unsigned long long)) != hipSuccess) { g_createErr = "rt_create: hipMalloc failed"; delete c; return RT_ERR_OOM; }
   (void)hipMemset(c->dCounters, 0, 8 * sizeof(unsigned long long));
   *out = c;
+  g_liveCtx.fetch_add(1);
   return RT_OK;
 }
 
@@ -292,6 +307,7 @@ int rt_destroy(rt_ctx* c)
   if(c->evFork) (void)hipEventDestroy(c->evFork);
   if(c->evJoin) (void)hipEventDestroy(c->evJoin);
   delete c;
+  if(g_liveCtx.fetch_sub(1) == 1) { std::lock_guard<std::mutex> one(g_accelMutex); g_accelCache.reset(); }   // the last context takes the cached host build with it
   return RT_OK;
 }
 
@@ -405,25 +421,47 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
   return RT_OK;
 }
 
-int rt_build_accel(rt_ctx* c)
+
+static void hashBytes(const void* p, size_t n, uint64_t& h0, uint64_t& h1)
 {
-  if(!c) return RT_ERR_INVALID_ARG;
-  if(!c->haveScene) return fail(c, RT_ERR_NO_SCENE, "rt_build_accel: no scene uploaded");
-  RT_HIP(c, hipSetDevice(c->device));
-  RT_HIP(c, syncAll(c));
-  freePool(c->accelAllocs);
-  c->haveAccel = false;
+  const unsigned char* b = static_cast<const unsigned char*>(p);
+  size_t i = 0;
+  for(; i + 8 <= n; i += 8) {
+    uint64_t w; memcpy(&w, b + i, 8);
+    h0 = (h0 ^ w) * 0x9E3779B97F4A7C15ull; h0 ^= h0 >> 29;
+    h1 = (h1 + w) * 0xC2B2AE3D27D4EB4Full; h1 ^= h1 >> 31;
+  }
+  uint64_t w = 0; memcpy(&w, b + i, n - i); w |= uint64_t(n) << 56;
+  h0 = (h0 ^ w) * 0x9E3779B97F4A7C15ull; h0 ^= h0 >> 29;
+  h1 = (h1 + w) * 0xC2B2AE3D27D4EB4Full; h1 ^= h1 >> 31;
+}
+#define RT_HASH_VEC(v) do { const uint64_t n_ = (v).size(); hashBytes(&n_, 8, h0, h1); if(n_) hashBytes((v).data(), n_ * sizeof((v)[0]), h0, h1); } while(0)
+static void sceneKey(const rt_ctx* c, uint64_t& h0, uint64_t& h1)
+{
+  h0 = 0x243F6A8885A308D3ull; h1 = 0x13198A2E03707344ull;
+  RT_HASH_VEC(c->primMeshes); RT_HASH_VEC(c->vertices); RT_HASH_VEC(c->indices); RT_HASH_VEC(c->instances); RT_HASH_VEC(c->materials);
+  for(size_t i = 0; i < c->devTextures.size(); i++) {
+    const DevTexture& t = c->devTextures[i];
+    const int meta[5] = {t.w, t.h, t.wrapS, t.wrapT, t.filter};
+    hashBytes(meta, sizeof(meta), h0, h1);
+    if(i < c->hostAlpha.size()) RT_HASH_VEC(c->hostAlpha[i]);
+  }
+}
+#undef RT_HASH_VEC
+static int buildHostAccel(rt_ctx* c, HostAccel& out)
+{
   rt_scene_desc d{};
   d.numPrimMeshes = uint32_t(c->primMeshes.size()); d.primMeshes = c->primMeshes.data();
   d.numVertices = c->vertices.size(); d.vertices = c->vertices.data();
   d.numIndices = c->indices.size(); d.indices = c->indices.data();
   d.numInstances = uint32_t(c->instances.size()); d.instances = c->instances.data();
-  BuildOutput bo;
+  BuildOutput& bo = out.bo;
   int threads = int(std::thread::hardware_concurrency());
   if(!buildBvh8(d, bo, threads > 0 ? threads : 1)) return fail(c, RT_ERR_INVALID_ARG, "rt_build_accel: BVH8 build failed");
   if(bo.maxDepth > STACK_MAX) return fail(c, RT_ERR_INVALID_ARG, "rt_build_accel: BVH8 deeper than the traversal stack");
   // alpha records for the triangles that go through HitTest (instances without FORCE_OPAQUE)
-  std::vector<AlphaRec> alpha(1, AlphaRec{});
+  std::vector<AlphaRec>& alpha = out.alpha; alpha.assign(1, AlphaRec{});
+  std::vector<int32_t>& alphaTex = out.alphaTex; alphaTex.assign(1, -1);
   std::map<std::array<uint32_t, 12>, std::array<uint32_t, 4>> ommCache;
   for(Tri48& T : bo.tris) {
     if(T.flags & TRI_OPAQUE) continue;
@@ -432,15 +470,16 @@ int rt_build_accel(rt_ctx* c)
     const rt_material& m = c->materials[size_t(pm.materialIndex > 0 ? pm.materialIndex : 0)];
     const uint32_t* ix = &c->indices[pm.firstIndex + 3 * ref.prim];
     AlphaRec a{};
+    int32_t tex = -1;
     const rt_vec2 t0 = c->vertices[pm.vertexOffset + ix[0]].texcoord, t1 = c->vertices[pm.vertexOffset + ix[1]].texcoord, t2 = c->vertices[pm.vertexOffset + ix[2]].texcoord;
     a.uv0x = t0.x; a.uv0y = t0.y; a.uv1x = t1.x; a.uv1y = t1.y; a.uv2x = t2.x; a.uv2y = t2.y;
     a.baseAlpha = m.pbrBaseColorFactor.w; a.cutoff = m.alphaCutoff; a.alphaMode = m.alphaMode;
     if(m.pbrBaseColorTexture > -1 && size_t(m.pbrBaseColorTexture) < c->devTextures.size()) {
       const DevTexture& t = c->devTextures[size_t(m.pbrBaseColorTexture)];
-      a.bgra = t.bgra; a.w = t.w; a.h = t.h; a.wrapS = t.wrapS; a.wrapT = t.wrapT; a.filter = t.filter;
+      tex = m.pbrBaseColorTexture; a.w = t.w; a.h = t.h; a.wrapS = t.wrapS; a.wrapT = t.wrapT; a.filter = t.filter;
     }
     T.alphaIdx = uint32_t(alpha.size());
-    alpha.push_back(a);
+    alpha.push_back(a); alphaTex.push_back(tex);
     // opacity micro-map, cached per distinct (texture, uv triple, alpha parameters)
     std::array<uint32_t, 12> key{};
     memcpy(key.data(), &a.uv0x, 8 * sizeof(float));
@@ -448,15 +487,46 @@ int rt_build_accel(rt_ctx* c)
     auto it = ommCache.find(key);
     if(it == ommCache.end()) {
       std::array<uint32_t, 4> o{};
-      const std::vector<uint8_t>* al = (a.bgra && size_t(m.pbrBaseColorTexture) < c->hostAlpha.size()) ? &c->hostAlpha[size_t(m.pbrBaseColorTexture)] : nullptr;
+      const std::vector<uint8_t>* al = (tex >= 0 && size_t(tex) < c->hostAlpha.size()) ? &c->hostAlpha[size_t(m.pbrBaseColorTexture)] : nullptr;
       buildOpacityMap(a, al, o.data());
       it = ommCache.emplace(key, o).first;
     }
     memcpy(T.omm, it->second.data(), sizeof(T.omm));
   }
+  return RT_OK;
+}
+
+int rt_build_accel(rt_ctx* c)
+{
+  if(!c) return RT_ERR_INVALID_ARG;
+  if(!c->haveScene) return fail(c, RT_ERR_NO_SCENE, "rt_build_accel: no scene uploaded");
+  RT_HIP(c, hipSetDevice(c->device));
+  RT_HIP(c, syncAll(c));
+  freePool(c->accelAllocs);
+  c->haveAccel = false;
+  // Host products (BVH8, alpha records, opacity micro-maps): built once per distinct scene in this process and shared by every context that uploads
+  // the same scene — the N ranks of an rt_mgpu context, or an application's contexts on several devices (1.4-1.6 s per build at 2.8 M triangles).
+  std::shared_ptr<const HostAccel> ha;
+  {
+    std::lock_guard<std::mutex> one(g_accelMutex);   // also: one multi-threaded host build at a time
+    uint64_t k0, k1;
+    sceneKey(c, k0, k1);
+    if(g_accelCache && g_accelCache->key0 == k0 && g_accelCache->key1 == k1) ha = g_accelCache;
+    else {
+      auto fresh = std::make_shared<HostAccel>();
+      fresh->key0 = k0; fresh->key1 = k1;
+      const int rc = buildHostAccel(c, *fresh);
+      if(rc) return rc;
+      ha = fresh; g_accelCache = ha;
+    }
+  }
+  const BuildOutput& bo = ha->bo;
   int rc;
-  if((rc = upload(c, c->accelAllocs, alpha.data(), alpha.size(), &c->ds.alphaRec))) return rc;
-  {  // the latency build's copy, addressable without the triangle record (one dependent access less per alpha candidate); 64 B per triangle
+  {
+    std::vector<AlphaRec> alpha = ha->alpha;   // texture addresses are per device
+    for(size_t i = 0; i < alpha.size(); i++) if(ha->alphaTex[i] >= 0) alpha[i].bgra = c->devTextures[size_t(ha->alphaTex[i])].bgra;
+    if((rc = upload(c, c->accelAllocs, alpha.data(), alpha.size(), &c->ds.alphaRec))) return rc;
+    // the latency build's copy, addressable without the triangle record (one dependent access less per alpha candidate); 64 B per triangle
     std::vector<AlphaRec> byTri(bo.tris.size(), AlphaRec{});
     for(size_t i = 0; i < bo.tris.size(); i++) if(!(bo.tris[i].flags & TRI_OPAQUE)) byTri[i] = alpha[bo.tris[i].alphaIdx];
     if((rc = upload(c, c->accelAllocs, byTri.data(), byTri.size(), &c->ds.alphaByTri))) return rc;
