@@ -31,10 +31,14 @@ for ci in range(cases):
     eye, center, up, fov = sc.cameraPose(); sc.updateCamera(W, H)
     info = dict(case=ci, kind=int(kind), W=W, H=H, world=world, restir=st.ReSTIRState, depth=st.maxDepth, den=st.denoise, balance=balance, frames=frames, lift=lift)
     ok = True
+    queued = bool(rng.integers(0, 2))     # compare only the last frame: the frames before it stay queued (frames in flight, look-ahead issue of the next direct stage)
+    info["queued"] = queued
     for f in range(frames):
         st.time = 3000 + f
         sc.setCamera(eye + vel * f, center + np.array([0, lift * f, 0], dtype=np.float32), up, fov); sc.updateCamera(W, H)
         cam = sc.getCamera(); ref.set_camera(cam); m.set_camera(cam); ref.run(st, f); m.run(st, f)
+        if queued and f < frames - 1:
+            continue
         bufs = [b for b in frame_buffers(f) if b not in (abi.BUF_DENOISE_DIR_A, abi.BUF_DENOISE_DIR_B, abi.BUF_DENOISE_IND_A, abi.BUF_DENOISE_IND_B)]
         if st.ReSTIRState in (2, 4): bufs.append(abi.BUF_DIRECT_RESV_TEMP)
         for b in bufs:
