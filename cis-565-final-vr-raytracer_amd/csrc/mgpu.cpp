@@ -679,9 +679,27 @@ struct DeviceGuard {   // entry points called on the application's thread leave 
   DeviceGuard() { if(hipGetDevice(&dev) != hipSuccess) dev = -1; }
   ~DeviceGuard() { if(dev >= 0) (void)hipSetDevice(dev); }
 };
+// Every entry point starts here.  An error of an earlier call (reported by that call) must not poison this one: the workers are let run dry (with `abort`
+// set they no longer wait for each other), every device is drained, and the per-rank error codes, the abort flag and the frames-in-flight bookkeeping are
+// reset; the screen-space history is dropped because a frame that failed half-way leaves it inconsistent.  (Round-3 advisor: the codes were sticky, and a
+// context that had seen one recoverable failure — e.g. rt_mgpu_upload_scene with a bad description — stayed unusable until it was destroyed.)
 void beginCall(rt_mgpu* M)
 {
-  if(firstError(M) == RT_OK && !M->abort.load()) { std::lock_guard<std::mutex> l(M->errLock); M->err.clear(); }
+  if(firstError(M) != RT_OK || M->abort.load()) {
+    waitIdle(M);
+    for(Rank& R : M->ranks) {
+      (void)hipSetDevice(R.dev);
+      (void)hipDeviceSynchronize();
+      R.rc = RT_OK;
+      for(auto& a : R.issued) a.store(-1);
+      R.havePrev = false; R.aIssued = -1;
+    }
+    M->abort = false;
+    M->pipeActive = false; M->seq = 0; M->lastFrames = -2;
+    M->haveHistory = false;
+  }
+  std::lock_guard<std::mutex> l(M->errLock);
+  M->err.clear();
 }
 
 void equalBands(rt_mgpu* M)

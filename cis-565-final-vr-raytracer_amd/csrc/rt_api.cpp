@@ -264,10 +264,11 @@ int rt_create(rt_ctx** out, int device)
   if(hipSetDevice(device) != hipSuccess) { g_createErr = "rt_create: hipSetDevice failed"; return RT_ERR_HIP; }
   rt_ctx* c = new(std::nothrow) rt_ctx();
   if(!c) { g_createErr = "rt_create: out of host memory"; return RT_ERR_OOM; }
+  g_liveCtx.fetch_add(1);   // counted from here on: every exit below goes through rt_destroy, which un-counts it
   c->device = device;
   {
     bool ok = hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) == hipSuccess;
-    if(!ok) { g_createErr = "rt_create: hipStreamCreate failed"; delete c; return RT_ERR_HIP; }
+    if(!ok) { g_createErr = "rt_create: hipStreamCreate failed"; rt_destroy(c); return RT_ERR_HIP; }
     c->stream = c->ownStream;
     for(int i = 0; i < 4; i++) {
       ok = ok && hipEventCreateWithFlags(&c->evD[i], hipEventDisableTiming) == hipSuccess;
@@ -279,10 +280,9 @@ int rt_create(rt_ctx** out, int device)
     if(!ok) { g_createErr = "rt_create: creating the internal events failed"; rt_destroy(c); return RT_ERR_HIP; }
   }
   if(const char* e = getenv("RESTIR_OVERLAP")) c->overlap = atoi(e);
-  if(hipMalloc(reinterpret_cast<void**>(&c->dCounters), 8 * sizeof(unsigned long long)) != hipSuccess) { g_createErr = "rt_create: hipMalloc failed"; delete c; return RT_ERR_OOM; }
+  if(hipMalloc(reinterpret_cast<void**>(&c->dCounters), 8 * sizeof(unsigned long long)) != hipSuccess) { g_createErr = "rt_create: hipMalloc failed"; rt_destroy(c); return RT_ERR_OOM; }
   (void)hipMemset(c->dCounters, 0, 8 * sizeof(unsigned long long));
   *out = c;
-  g_liveCtx.fetch_add(1);
   return RT_OK;
 }
 
@@ -693,6 +693,12 @@ int rt_run_stage(rt_ctx* c, const rt_state* st, int frames, int stage, int level
   if(rc) return rc;
   if(stage < 0 || stage >= RT_STAGE_COUNT) return fail(c, RT_ERR_INVALID_ARG, "rt_run_stage: unknown stage");
   if(rowBegin < 0 || (rowBegin & 7)) return fail(c, RT_ERR_INVALID_ARG, "rt_run_stage: rowBegin must be a non-negative multiple of 8");
+  {  // levels: the filter chains have 4 / 5, the direct stage its two halves in the spatial modes, every other stage only level 0
+    const bool spatial = st->ReSTIRState == RT_RESTIR_SPATIAL || st->ReSTIRState == RT_RESTIR_SPATIOTEMPORAL;
+    const int maxLevel = stage == RT_STAGE_DENOISE_DIRECT ? 3 : (stage == RT_STAGE_DENOISE_INDIRECT ? 4 : ((stage == RT_STAGE_DIRECT && spatial) ? 2 : 0));
+    if(level < 0 || level > maxLevel)
+      return fail(c, RT_ERR_INVALID_ARG, "rt_run_stage: level out of range for this stage (RT_STAGE_DIRECT levels 1 / 2 exist in the spatial modes only)");
+  }
   RT_HIP(c, hipSetDevice(c->device));
   RT_HIP(c, joinInFlight(c));
   DevFrame F = makeFrame(c, frames);
@@ -700,6 +706,7 @@ int rt_run_stage(rt_ctx* c, const rt_state* st, int frames, int stage, int level
   // (stage kinds share no scratch: a caller may spread them over several streams, tiled.PipelinedTiledFrame does)
   const hipError_t e = stageLauncher(c, *st, stage, rowBegin, rowEnd)(c->stream, c->ds, F, *st, c->cam, stage, level, rowBegin, rowEnd);
   if(e == hipErrorInvalidValue) return fail(c, RT_ERR_INVALID_ARG, "rt_run_stage: level out of range for this stage (RT_STAGE_DIRECT levels 1 / 2 exist in the spatial modes only)");
+  if(e == hipErrorInvalidConfiguration) return fail(c, RT_ERR_HIP, "rt_run_stage: the traversal-stack overflow area is missing or too small for this launch (internal sizing error)");
   RT_HIP(c, e);
   return RT_OK;
 }

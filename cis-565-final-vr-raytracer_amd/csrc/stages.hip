@@ -1225,14 +1225,14 @@ hipError_t launchStage(hipStream_t stream, const DevScene& Sin, const DevFrame& 
       if(level != 2) hipLaunchKernelGGL(k_direct_stage, grid, dim3(64 * nWaves), wideLdsBytes(S.stackEntries, nWaves), stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY);
       if(level != 1 && spatial) return rt::RT_FORWARD::launchStage(stream, Sin, F, st, cam, stage, 2, rowBegin, rowEnd);
 #else
-      if(needOvf && grid.x * 64u > S.stackOvfThreads) return hipErrorInvalidValue;
+      if(needOvf && grid.x * 64u > S.stackOvfThreads) return hipErrorInvalidConfiguration;   // overflow area missing / too small: an internal sizing error, not the caller's
       if(level != 2) hipLaunchKernelGGL(k_direct_stage, grid, block, lds, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY);
       if(level != 1 && spatial) hipLaunchKernelGGL(k_direct_spatial, grid, block, 0, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY);
 #endif
       break;
 #if !RT_LAT
     case RT_STAGE_DIRECT_GEN:
-      if(needOvf && grid.x * 64u > S.stackOvfThreads) return hipErrorInvalidValue;
+      if(needOvf && grid.x * 64u > S.stackOvfThreads) return hipErrorInvalidConfiguration;   // overflow area missing / too small: an internal sizing error, not the caller's
       hipLaunchKernelGGL(k_direct_gen, grid, block, lds, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY);
       break;
 #endif
@@ -1255,7 +1255,7 @@ hipError_t launchStage(hipStream_t stream, const DevScene& Sin, const DevFrame& 
       const unsigned genericBlocks = grid.x << subShift;
       const unsigned sbBlocks = sbK > 0 ? 8u * unsigned((cap + sbK - 1) / sbK) : 0u;
       const size_t poolBytes = std::max<size_t>(POOL_BYTES, size_t(sbK) * 64 * 33);
-      if(needOvf && (genericBlocks + sbBlocks) * 64u > S.stackOvfThreads) return hipErrorInvalidValue;
+      if(needOvf && (genericBlocks + sbBlocks) * 64u > S.stackOvfThreads) return hipErrorInvalidConfiguration;
       hipLaunchKernelGGL(k_indirect_stage, dim3(genericBlocks + sbBlocks), block, lds + poolBytes, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY, cap,
                          (const uint32_t*)F.tileOrder, (const uint32_t*)(F.qcount + 192), subShift, sbK, int(genericBlocks));
 #endif

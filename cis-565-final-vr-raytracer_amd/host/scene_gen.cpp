@@ -78,6 +78,25 @@ struct Builder {
     uint32_t a = vert(p0, n, 0, 0, t), b = vert(p1, n, uvScale, 0, t), c = vert(p2, n, uvScale, uvScale, t), d = vert(p3, n, 0, uvScale, t);
     tri(a, b, c); tri(a, c, d);
   }
+  // experiment (RESTIR_SCENE_TESS_LEAVES=n, profiles/r04_leaf_blocks_ab.txt): the same cut-out quad as n x n sub-quads, without the sub-quads whose texels are
+  // all transparent — what clipping alpha-masked geometry to its opaque part could buy in traversal steps.  A different scene (other triangle ids), never a default.
+  void quadTessellated(V3 p0, V3 p1, V3 p2, V3 p3, V3 n, int nsub, const TextureImage& tex)
+  {
+    if(dot(cross(p1 - p0, p2 - p0), n) < 0) std::swap(p1, p3);
+    V3 t = normalize(p1 - p0);
+    for(int j = 0; j < nsub; j++)
+      for(int i = 0; i < nsub; i++) {
+        const float s0 = float(i) / nsub, s1 = float(i + 1) / nsub, t0 = float(j) / nsub, t1 = float(j + 1) / nsub;
+        bool any = false;
+        const int x0 = std::max(0, int(s0 * tex.width) - 2), x1 = std::min(tex.width - 1, int(s1 * tex.width) + 2);
+        const int y0 = std::max(0, int(t0 * tex.height) - 2), y1 = std::min(tex.height - 1, int(t1 * tex.height) + 2);
+        for(int y = y0; y <= y1 && !any; y++) for(int x = x0; x <= x1; x++) if(tex.bgra[(size_t(y) * tex.width + x) * 4 + 3] != 0) { any = true; break; }
+        if(!any) continue;
+        auto P = [&](float s, float tt) { return p0 + (p1 - p0) * s + (p3 - p0) * tt; };
+        uint32_t a = vert(P(s0, t0), n, s0, t0, t), b = vert(P(s1, t0), n, s1, t0, t), c = vert(P(s1, t1), n, s1, t1, t), d = vert(P(s0, t1), n, s0, t1, t);
+        tri(a, b, c); tri(a, c, d);
+      }
+  }
   // axis-aligned box, optionally rotated about Y, faces outward (inward when `inside`)
   void box(V3 c, V3 h, float rotY = 0.f, bool inside = false, float uvScale = 1.f)
   {
@@ -367,7 +386,9 @@ GltfScene makeBistro(bool interior, float scale, uint32_t seed)
         V3 n = normalize(V3{B.rng.range(-1, 1), B.rng.range(-0.3f, 1), B.rng.range(-1, 1)});
         V3 t1 = normalize(cross(n, V3{0.3f, 1, 0.2f})), t2 = cross(n, t1);
         float sz = B.rng.range(0.12f, 0.22f);
-        B.quad(c - t1 * sz - t2 * sz, c + t1 * sz - t2 * sz, c + t1 * sz + t2 * sz, c - t1 * sz + t2 * sz, n);
+        static const int tess = getenv("RESTIR_SCENE_TESS_LEAVES") ? atoi(getenv("RESTIR_SCENE_TESS_LEAVES")) : 0;
+        if(tess > 1) B.quadTessellated(c - t1 * sz - t2 * sz, c + t1 * sz - t2 * sz, c + t1 * sz + t2 * sz, c - t1 * sz + t2 * sz, n, tess, B.g.textures[size_t(B.g.materials[size_t(P.leaf)].baseColorTexture)]);
+        else B.quad(c - t1 * sz - t2 * sz, c + t1 * sz - t2 * sz, c + t1 * sz + t2 * sz, c - t1 * sz + t2 * sz, n);
       }
       treeMesh[t] = B.endMesh();
     }

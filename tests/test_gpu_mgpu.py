@@ -128,3 +128,28 @@ def test_mgpu_bad_arguments():
     m.run(st, 0)
     with pytest.raises(RtError):
         MultiGpuRenderer().setup(_devices(2)).update(16, 16)   # fewer 16-row stripes than ranks
+
+
+def test_mgpu_recovers_after_a_failed_call():
+    """An error is reported by the call that caused it and must not poison the context (round-3 advisor: the per-rank codes were sticky): a scene the
+    validation rejects, then the good scene on the SAME context renders the single-GPU frame."""
+    import copy
+    from restir_amd.renderer import Renderer, MultiGpuRenderer, RtError
+    W, H = 160, 96
+    sc, env = make_scene(abi.PROC_SPONZA, 0.01, 1, (128, 64))
+    st = host.default_state(W, H, sc, env)
+    desc = sc.desc(env)
+    cams = _cams(sc, W, H, 3, 0.03)
+    m = MultiGpuRenderer().setup(_devices(3))
+    bad = copy.copy(desc)
+    bad.numMaterials = 0                                   # rt_upload_scene: "missing geometry/material arrays"
+    with pytest.raises(RtError):
+        m.load_scene(bad)
+    m.load_scene(desc); m.update(W, H)                     # same context, good scene
+    ref = Renderer().setup(0); ref.load_scene(desc); ref.update(W, H)
+    for f in range(3):
+        st.time = 50 + f
+        ref.set_camera(cams[f]); ref.run(st, f); m.set_camera(cams[f]); m.run(st, f)
+    for b in (abi.BUF_GBUFFER0, abi.BUF_DIRECT_RESV0, abi.BUF_DIRECT_RESULT0, abi.BUF_INDIRECT_RESULT0):
+        assert np.array_equal(m.readback(b), ref.readback(b)), abi.BUFFER_NAMES[b]
+    m.destroy(); ref.destroy()
