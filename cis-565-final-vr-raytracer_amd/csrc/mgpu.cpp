@@ -129,6 +129,7 @@ struct rt_mgpu {
   std::vector<float> stripeCost;       // smoothed cost per 16-row stripe
   bool haveHistory = false, balance = true, serialize = false, gatherResults = true, pipeline = true;
   int solo = -1;
+  std::vector<uint8_t> peerOk;         // [puller rank * n + owner rank]: direct peer access from the puller's device to the owner's is enabled (rt_mgpu_create)
   int64_t seq = 0; int lastFrames = -2; bool pipeActive = false;
   int histHalo = HIST_HALO_MIN; uint32_t fallbacksSeen = 0; int calmFrames = 0; bool lastDenoise = false;
   rt_scene_camera cam{}; const rt_scene_desc* desc = nullptr;
@@ -200,8 +201,14 @@ void pullRowsOn(rt_mgpu& M, Rank& R, hipStream_t strm, int buf, int a, int b, co
       const int rows = evenOnly ? (hi - lo + 1) / 2 : hi - lo;
       if(rows <= 0) continue;
       const size_t off = size_t(lo) * pitch, stride = evenOnly ? 2 * pitch : pitch, w = widthBytes > 0 ? std::min(widthBytes, pitch) : pitch;
-      // (unified addressing + peer access: a 2-D device-to-device copy may cross devices)
-      MG_HIP(hipMemcpy2DAsync(static_cast<char*>(dst) + off, stride, static_cast<char*>(src) + off, stride, w, size_t(rows), Q.dev == R.dev ? hipMemcpyDeviceToDevice : hipMemcpyDefault, strm), "hipMemcpy2DAsync");
+      if(Q.dev == R.dev || M.peerOk[size_t(R.id) * size_t(M.n) + size_t(q)]) {
+        // (unified addressing + peer access: a 2-D device-to-device copy may cross devices)
+        MG_HIP(hipMemcpy2DAsync(static_cast<char*>(dst) + off, stride, static_cast<char*>(src) + off, stride, w, size_t(rows), Q.dev == R.dev ? hipMemcpyDeviceToDevice : hipMemcpyDefault, strm), "hipMemcpy2DAsync");
+      } else {
+        // no peer access between the two devices: hipMemcpyPeerAsync still works (staged by the runtime), a cross-device 2-D default copy may not — row by row
+        for(int y = 0; y < rows; y++)
+          MG_HIP(hipMemcpyPeerAsync(static_cast<char*>(dst) + off + size_t(y) * stride, R.dev, static_cast<char*>(src) + off + size_t(y) * stride, Q.dev, w, strm), "hipMemcpyPeerAsync (row)");
+      }
       (R.accSlot >= 0 ? R.pulledBy[R.accSlot] : R.pulled)[kind] += w * size_t(rows);
       continue;
     }
@@ -803,12 +810,18 @@ int rt_mgpu_create(rt_mgpu** out, int numRanks, const int* devices)
     rt_set_overlap(R.ctx, 0);   // stages are issued one by one through rt_run_stage
   }
   // direct xGMI copies between distinct devices (already-enabled is not an error)
+  M->peerOk.assign(size_t(numRanks) * size_t(numRanks), 0);
   for(int a = 0; a < numRanks; a++)
     for(int b = 0; b < numRanks; b++) {
       const int da = M->ranks[size_t(a)].dev, db = M->ranks[size_t(b)].dev;
-      if(da == db) continue;
+      if(da == db) { M->peerOk[size_t(a) * size_t(numRanks) + size_t(b)] = 1; continue; }
       int can = 0;
-      if(hipDeviceCanAccessPeer(&can, da, db) == hipSuccess && can) { (void)hipSetDevice(da); (void)hipDeviceEnablePeerAccess(db, 0); (void)hipGetLastError(); }
+      if(hipDeviceCanAccessPeer(&can, da, db) == hipSuccess && can) {
+        (void)hipSetDevice(da);
+        const hipError_t e = hipDeviceEnablePeerAccess(db, 0);
+        (void)hipGetLastError();
+        if(e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) M->peerOk[size_t(a) * size_t(numRanks) + size_t(b)] = 1;
+      }
     }
   M->step.init(numRanks);
   for(int r = 0; r < numRanks; r++) M->ranks[size_t(r)].th = std::thread(worker, M, r);

@@ -214,6 +214,34 @@ static void buildOpacityMap(const AlphaRec& a, const std::vector<uint8_t>* alpha
 
 static int fail(rt_ctx* c, int code, const char* msg) { c->err = msg; return code; }
 
+// CU-partitioned streams (experiment, round 4: profiles/r04_cu_mask_ab.txt).  RESTIR_CU_SPLIT="a-b,c-d,e-f": the main (direct stage), indirect and filter
+// streams of rt_render_frame's overlapped schedules are created with hipExtStreamCreateWithCUMask and may use compute units [a,b) / [c,d) / [e,f) of EVERY XCD
+// (32 per XCD on MI355X; mask bit i selects CU i / 8 of XCD i % 8 — scripts/probe/cu_mask_probe.hip).  Unset: ordinary streams, the whole chip.
+static bool cuSplitRange(int which, int& lo, int& hi)
+{
+  static int r[3][2]; static int have = -1;
+  if(have < 0) {
+    have = 0;
+    if(const char* e = getenv("RESTIR_CU_SPLIT"))
+      if(sscanf(e, "%d-%d,%d-%d,%d-%d", &r[0][0], &r[0][1], &r[1][0], &r[1][1], &r[2][0], &r[2][1]) == 6) have = 1;
+  }
+  if(!have) return false;
+  lo = std::max(0, std::min(32, r[which][0])); hi = std::max(lo + 1, std::min(32, r[which][1]));
+  return !(lo == 0 && hi == 32);
+}
+static hipError_t createStream(hipStream_t* s, int which, bool high)
+{
+  int lo, hi;
+  if(cuSplitRange(which, lo, hi)) {
+    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for(int b = 8 * lo; b < 8 * hi; b++) mask[b >> 5] |= 1u << (b & 31);
+    return hipExtStreamCreateWithCUMask(s, 8, mask);
+  }
+  int plo = 0, phi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
+  return (high && phi < plo) ? hipStreamCreateWithPriority(s, hipStreamNonBlocking, phi) : hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+
 template <class T> static int upload(rt_ctx* c, std::vector<void*>& pool, const T* src, size_t count, const T** out)
 {
   void* d = nullptr;
@@ -267,7 +295,7 @@ int rt_create(rt_ctx** out, int device)
   g_liveCtx.fetch_add(1);   // counted from here on: every exit below goes through rt_destroy, which un-counts it
   c->device = device;
   {
-    bool ok = hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) == hipSuccess;
+    bool ok = createStream(&c->ownStream, 0, false) == hipSuccess;
     if(!ok) { g_createErr = "rt_create: hipStreamCreate failed"; rt_destroy(c); return RT_ERR_HIP; }
     c->stream = c->ownStream;
     for(int i = 0; i < 4; i++) {
@@ -644,10 +672,9 @@ static hipError_t ensureOverlapStreams(rt_ctx* c)
   (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
   static const int mode = getenv("RESTIR_PRIO") ? atoi(getenv("RESTIR_PRIO")) : 2;
   const bool can = hi < lo;
-  auto mk = [&](hipStream_t* s, bool high) { return (can && high) ? hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(s, hipStreamNonBlocking); };
   hipError_t e = hipSuccess;
-  if(!c->sideStream) e = mk(&c->sideStream, mode == 1 || mode == 3);
-  if(e == hipSuccess && !c->indStream) e = mk(&c->indStream, mode == 1 || mode == 2);
+  if(!c->sideStream) e = createStream(&c->sideStream, 2, can && (mode == 1 || mode == 3));
+  if(e == hipSuccess && !c->indStream) e = createStream(&c->indStream, 1, can && (mode == 1 || mode == 2));
   return e;
 }
 

@@ -56,8 +56,11 @@ namespace RT_VARIANT {
 // ------------------------------------------------------------------------------------------------------------
 // launch bounds of the two traced kernels, re-measured in round 2 under the final schedule (frames in flight, ms/frame, same box):
 // (direct, indirect) waves per SIMD = (5,5) 3.155, (4,5) 3.121, (4,4) 3.29, (5,4) 3.59, (3,5) 3.16, (4,6) 3.15  =>  (4, 5)
+// and again in round 4 on the build whose traversal stacks and filters had given LDS back (profiles/r04_launch_bounds_ab.txt, two boxes):
+// (4,5) 2.987 / 2.993, (5,5) 2.901 / 2.893, (6,5) 2.891, (5,4) 2.923, (4,4) 2.995, (5,6) 2.904, (6,6) 2.920  =>  (5, 5): 96 VGPRs and 31 spilled
+// values (60 B of scratch per lane, none of it inside a traversal loop) buy a fifth wave per SIMD.
 #ifndef RT_DIRECT_LB
-#define RT_DIRECT_LB 4
+#define RT_DIRECT_LB 5
 #endif
 // ReSTIRDirect (direct_stage.comp:150-270) cut at its one shadow ray, so that the ray can be traced by whatever the build uses (the lane's own
 // traversal loop in the throughput build, the workgroup's ray pool in the latency build) while both builds share every line of shading:

@@ -183,6 +183,9 @@ bool decodePng(const uint8_t* d, size_t n, TextureImage& img)
     if(uint32_t(passes[k][0]) >= w || uint32_t(passes[k][1]) >= h || !pw || !ph) continue;
     total += (rowBytes(pw) + 1) * ph;
   }
+  // deflate expands by at most 1032 : 1 (a stored length-258 match per ~2 bits): a header that promises more than the IDAT stream can hold is rejected BEFORE
+  // the multi-GB buffers it asks for are allocated (round-3 advisor: a 100-byte PNG claiming 16384 x 16384 x 64 bpp forced ~4 GB of zero-filled vectors)
+  if(total > idat.size() * size_t(1032) + 1024) return false;
   std::vector<uint8_t> raw(total);
   uLongf rawLen = uLongf(raw.size());
   if(uncompress(raw.data(), &rawLen, idat.data(), uLong(idat.size())) != Z_OK || rawLen != raw.size()) return false;
