@@ -32,12 +32,69 @@ import math
 from . import abi
 
 _COLOR_BYTES = 16
-HIST_HALO = 32                      # full-res rows of last-frame history kept from each neighbour (multiple of 16)
+# Full-res rows of last-frame history kept from each neighbour.  Adaptive, the rule of csrc/mgpu.cpp (HIST_HALO_MIN / MAX / CALM): HIST_HALO_MIN rows while no
+# temporal lookup leaves band + halo, doubled (up to HIST_HALO_MAX) for the frames after one did, halved again after HIST_HALO_CALM frames without; a lookup
+# outside is always caught (exact fallback), so the width only trades bytes against fallbacks.  HIST_HALO = <n> forces a fixed width (tests: 0).
+HIST_HALO = None
+HIST_HALO_MIN, HIST_HALO_MAX, HIST_HALO_CALM = 16, 64, 16
 DIRECT_GROW = (32, 24, 16, 0)       # rows added on each side of the band for A-Trous level l's output (multiples of 8)
 INDIRECT_GROW = (64, 56, 48, 32, 0)
 HALO_DIRECT_COLOR = 40              # >= DIRECT_GROW[0] + 2
 HALO_INDIRECT_COLOR = 72            # half-res rows, >= INDIRECT_GROW[0] + 2
+# G-buffer rows the nine filter passes read beyond the band: the direct chain reaches DIRECT_GROW[0] + 2 rows (every row), the indirect chain
+# INDIRECT_GROW[0] + 2 half-res rows = 132 full-res rows, of which it reads the EVEN ones only (loadThisGeometry(2q), denoise_common.glsl:42-55)
+HALO_GBUFFER_FULL = 40
 HALO_GBUFFER = 144                  # full-res rows, >= 2 * (INDIRECT_GROW[0] + 2) and a multiple of 16
+HALO_KINDS = ("history", "filter", "spatial", "moved", "gather", "fallback")   # byte accounting by purpose (same names as rt_mgpu_stats::haloBytesKind)
+
+
+class Halo:
+    """One item of a halo exchange: fill `halo` rows of `tensor` (row pitch `pitch`, rows partitioned by `part`, clipped to [0, limit)) above and below this
+    rank's band from the ranks that own them.  inner: rows closer than this to the band are NOT part of the item (an outer ring); even: even rows only;
+    width: only the first `width` bytes of a row (the half-resolution temporaries live in full-size allocations).  Strided / partial items travel through a
+    packed staging tensor (a send / recv needs contiguous memory)."""
+    __slots__ = ("tensor", "pitch", "part", "halo", "limit", "inner", "even", "width")
+
+    def __init__(self, tensor, pitch, part, halo, limit, inner=0, even=False, width=None):
+        self.tensor, self.pitch, self.part, self.halo, self.limit = tensor, pitch, part, halo, limit
+        self.inner, self.even, self.width = inner, even, (None if width is None or width >= pitch else int(width))
+
+    def need(self, r):
+        """row segments rank r needs: [(lo, hi)] above and below its band"""
+        y0, y1 = self.part[r], self.part[r + 1]
+        if y1 <= y0:
+            return []
+        return [(max(0, y0 - self.halo), max(0, y0 - self.inner)), (min(self.limit, y1 + self.inner), min(self.limit, y1 + self.halo))]
+
+    def rows(self, a, b):
+        """(first row, row count, row step) of the rows of [a, b) this item moves"""
+        if self.even:
+            a = (a + 1) & ~1
+            return a, max(0, (b - a + 1) // 2), 2
+        return a, max(0, b - a), 1
+
+    def nbytes(self, a, b):
+        _, n, _ = self.rows(a, b)
+        return n * (self.width if self.width is not None else self.pitch)
+
+
+class Pending:
+    """Works of one batched exchange plus the unpacking of its staged (strided / partial-width) receives.  wait() may be called once per consuming stream:
+    the first call waits for the transfers and unpacks on the current stream, later calls (other streams) wait for that unpacking."""
+    def __init__(self, comm, works, unpack, keep=()):
+        self.comm, self.works, self.unpack, self.keep, self.event, self.done = comm, works, unpack, list(keep), None, False
+
+    def wait(self):
+        if self.done:
+            if self.event is not None:
+                self.comm.torch.cuda.current_stream().wait_event(self.event)
+            return
+        self.comm._wait_works(self.works)
+        for dst, src in self.unpack:
+            dst.copy_(src)
+        if self.comm.nccl and (self.works or self.unpack):   # a later wait on another stream orders that stream after transfer + unpacking
+            self.event = self.comm.torch.cuda.Event(); self.event.record(self.comm.torch.cuda.current_stream())
+        self.done, self.works, self.unpack, self.keep = True, [], [], []
 
 
 def band_height(H, world):
@@ -87,17 +144,12 @@ def plan_bands(H, world, stripe_cost, prev=None, max_move=None):
     return [min(H, b * 16) for b in nb[:-1]] + [H]
 
 
-def _need(part, r, halo, limit):
-    """row segments rank r needs around its band: [(lo, hi)] above and below, clipped"""
-    y0, y1 = part[r], part[r + 1]
-    return [(max(0, y0 - halo), y0), (y1, min(limit, y1 + halo))]
-
-
 class LocalComm:
     """world == 1: every exchange is a no-op."""
     rank, world = 0, 1
-    def all_gather_rows(self, tensor, pitch, part, async_op=False): return None
-    def halo_exchange(self, items, async_op=False): return []
+    rx_bytes = dict.fromkeys(HALO_KINDS, 0)
+    def all_gather_rows(self, tensor, pitch, part, async_op=False, kind="fallback"): return None
+    def halo_exchange(self, items, async_op=False, kind="filter"): return []
     def gather_rows_to(self, tensor, pitch, part, dst=0, async_op=False): return None
     def any_flag(self, flag): return bool(flag)
     def all_gather_floats(self, values): return [list(values)]
@@ -116,56 +168,78 @@ class TorchComm:
         self.nccl = dist.get_backend(group) == "nccl"
         self._flag = torch.zeros(1, dtype=torch.int32, device="cuda" if self.nccl else "cpu")
         self._done = {}
+        self.rx_bytes = dict.fromkeys(HALO_KINDS, 0)   # bytes this rank has received, by purpose (TiledFrame snapshots it per frame)
 
     # Every exchange is expressed on an arbitrary row partition `part` (world + 1 boundaries): rank q owns rows [part[q], part[q+1]).
     # A rank receives the rows it needs from whoever owns them and sends the rows others need from its own band — one batched
     # send/recv; both sides enumerate the segments of a pair in the same order (the receiver's need list), which is what NCCL's
     # in-order matching of a group requires.  Bands may be narrower than a halo (a halo then spans several ranks).
-    def _batch(self, ops, async_op):
+    def _batch(self, ops, unpack, async_op):
         works = self.dist.batch_isend_irecv(ops) if ops else []
-        works = [w for w in works if w is not None]
+        p = Pending(self, [w for w in works if w is not None], unpack, keep=[op.tensor for op in ops])   # packed send buffers live until the exchange is waited for
         if not async_op:
-            for w in works:
-                w.wait()
-            return []
-        return works
+            p.wait()
+            return None
+        return p
 
-    def _pair_ops(self, ops, tensor, pitch, part, need_of, limit):
-        P2P, me = self.dist.P2POp, self.rank
+    def _view(self, item, a, b):
+        """the rows of [a, b) the item moves, as a 2-D (rows, bytes) view of its tensor"""
+        a, n, step = item.rows(a, b)
+        if n <= 0:
+            return None
+        v = item.tensor[a * item.pitch:(a + (n - 1) * step + 1) * item.pitch].view(-1, item.pitch)[::step]
+        return v if item.width is None else v[:, :item.width]
+
+    def _pair_ops(self, ops, unpack, item, need_of, kind):
+        """sends / receives of one item between this rank and every other; both sides enumerate the segments of a pair in the same order"""
+        P2P, me, part = (self.dist.P2POp if self.dist is not None else None), self.rank, item.part
+        packed = item.even or item.width is not None
         for q in range(self.world):
             if q == me:
                 continue
             for (lo, hi) in need_of(me):                     # what I receive from q
-                a, b = max(lo, part[q]), min(hi, part[q + 1], limit)
-                if b > a:
-                    ops.append(P2P(self.dist.irecv, tensor[a * pitch:b * pitch], q, group=self.group))
+                a, b = max(lo, part[q]), min(hi, part[q + 1], item.limit)
+                v = self._view(item, a, b) if b > a else None
+                if v is None:
+                    continue
+                self.rx_bytes[kind] += item.nbytes(a, b)
+                if P2P is None:
+                    continue                                 # CountingComm: the accounting is all there is
+                if packed:
+                    stage = self.torch.empty(v.shape, dtype=v.dtype, device=v.device)
+                    unpack.append((v, stage))
+                    ops.append(P2P(self.dist.irecv, stage, q, group=self.group))
+                else:
+                    ops.append(P2P(self.dist.irecv, v.reshape(-1), q, group=self.group))
             for (lo, hi) in need_of(q):                      # what q receives from me
-                a, b = max(lo, part[me]), min(hi, part[me + 1], limit)
-                if b > a:
-                    ops.append(P2P(self.dist.isend, tensor[a * pitch:b * pitch], q, group=self.group))
+                a, b = max(lo, part[me]), min(hi, part[me + 1], item.limit)
+                v = self._view(item, a, b) if b > a else None
+                if v is None or P2P is None:
+                    continue
+                ops.append(P2P(self.dist.isend, v.contiguous() if packed else v.reshape(-1), q, group=self.group))
 
-    def all_gather_rows(self, tensor, pitch, part, async_op=False):
-        ops = []
-        self._pair_ops(ops, tensor, pitch, part, lambda r: [(0, part[-1])], part[-1])
-        w = self._batch(ops, async_op)
-        return w if async_op else None
+    def all_gather_rows(self, tensor, pitch, part, async_op=False, kind="fallback"):
+        ops, unpack = [], []
+        item = Halo(tensor, pitch, part, part[-1], part[-1])
+        self._pair_ops(ops, unpack, item, lambda r: [(0, part[-1])], kind)
+        return self._batch(ops, unpack, async_op)
 
-    def halo_exchange(self, items, async_op=False):
-        """items: [(tensor, pitch, part, halo, limit)].  For every item fill the `halo` rows above and below this rank's band (clipped to
-        [0, limit)) from the ranks that own them, all items in ONE batched send/recv.  Returns the list of pending works."""
-        ops = []
-        for (tensor, pitch, part, halo, limit) in items:
-            if halo <= 0:
+    def halo_exchange(self, items, async_op=False, kind="filter"):
+        """items: Halo objects.  For every item fill its rows above and below this rank's band from the ranks that own them, all items in ONE batched
+        send/recv.  Returns a Pending (async_op) or None."""
+        ops, unpack = [], []
+        for it in items:
+            if it.halo <= it.inner:
                 continue
-            self._pair_ops(ops, tensor, pitch, part, lambda r, part=part, halo=halo, limit=limit: _need(part, r, halo, limit), limit)
-        return self._batch(ops, async_op)
+            self._pair_ops(ops, unpack, it, it.need, kind)
+        return self._batch(ops, unpack, async_op)
 
     def gather_rows_to(self, tensor, pitch, part, dst=0, async_op=False):
         # NCCL has no in-place gather primitive; grouped send/recv to dst: only dst's links carry the traffic
-        ops = []
-        self._pair_ops(ops, tensor, pitch, part, lambda r: [(0, part[-1])] if r == dst else [], part[-1])
-        w = self._batch(ops, async_op)
-        return w if async_op else None
+        ops, unpack = [], []
+        item = Halo(tensor, pitch, part, part[-1], part[-1])
+        self._pair_ops(ops, unpack, item, lambda r: [(0, part[-1])] if r == dst else [], "gather")
+        return self._batch(ops, unpack, async_op)
 
     def all_gather_floats(self, values):
         """every rank's list of floats, by rank (host side; used outside the timed region to plan the band heights)"""
@@ -180,23 +254,65 @@ class TorchComm:
         return bool(int(self._flag.item()))
 
     def wait(self, work):
-        """NCCL: makes the CURRENT stream wait for the operation (may be called once per consuming stream).  gloo: blocks the
-        host; a second wait on a finished point-to-point work can hang there, so finished works are remembered."""
+        """NCCL: makes the CURRENT stream wait for the exchange (may be called once per consuming stream).  gloo: blocks the host."""
         if work is None:
             return
         for w in (work if isinstance(work, (list, tuple)) else [work]):
-            if w is None:
-                continue
-            if self.nccl:
+            if w is not None:
                 w.wait()
-            elif id(w) not in self._done:
-                w.wait()
-                self._done[id(w)] = w          # keeps the object alive so that the id stays unique
-                if len(self._done) > 4096:
-                    self._done.clear()
+
+    def _wait_works(self, works):
+        for w in works:
+            w.wait()
 
     def barrier(self):
         self.dist.barrier(group=self.group)
+
+
+class CountingComm(TorchComm):
+    """The exchange plan of rank `rank` of a `world`-rank job without any transport: every halo_exchange / all_gather is enumerated exactly as TorchComm does
+    and only its received bytes are counted (rx_bytes).  With CountingBackend below this prices a frame's communication for any size / partition on a host
+    without GPUs (steady_halo_bytes; tests/test_tiled_gloo.py holds it to the bytes a real gloo run receives)."""
+    def __init__(self, rank, world):
+        import torch
+        self.torch, self.dist, self.group, self.rank, self.world, self.nccl = torch, None, None, rank, world, False
+        self._done = {}
+        self.rx_bytes = dict.fromkeys(HALO_KINDS, 0)
+    def _batch(self, ops, unpack, async_op): return None
+    def all_gather_floats(self, values): return [list(values) for _ in range(self.world)]
+    def any_flag(self, flag): return bool(flag)
+    def barrier(self): pass
+
+
+class CountingBackend:
+    """backend of a TiledFrame that renders nothing: buffers are shape-only (meta) tensors of the real sizes"""
+    _ELEM = {abi.BUF_GBUFFER0: 16, abi.BUF_GBUFFER1: 16, abi.BUF_DIRECT_RESV0: 36, abi.BUF_DIRECT_RESV1: 36, abi.BUF_DIRECT_RESV_TEMP: 36, abi.BUF_LIGHT_ID0: 4,
+             abi.BUF_LIGHT_ID1: 4, abi.BUF_INDIRECT_RESV0: 76, abi.BUF_INDIRECT_RESV1: 76}
+    def __init__(self, width, height):
+        import torch
+        self.torch, self.W, self.H, self._c = torch, width, height, {}
+    def run_stage(self, *a): pass
+    def set_history_rows(self, r0, r1): pass
+    def history_miss(self): return False
+    def history_miss_stage(self, stage): return False
+    def tensor(self, buf):
+        if buf not in self._c:
+            half = buf in (abi.BUF_INDIRECT_RESV0, abi.BUF_INDIRECT_RESV1)
+            pitch = (self.W // 2 if half else self.W) * self._ELEM.get(buf, 16)
+            self._c[buf] = (self.torch.empty(pitch * (self.H + 128), dtype=self.torch.uint8, device="meta"), pitch)
+        return self._c[buf]
+
+
+def steady_halo_bytes(width, height, world, rank, part=None, pipelined=True, denoise=1, restir=None, frames=3):
+    """bytes rank `rank` receives per steady-state frame of a `world`-way row tiling, by purpose (no GPU, no process group)"""
+    class _St:
+        pass
+    st = _St(); st.denoise = denoise; st.ReSTIRState = abi.RESTIR_TEMPORAL if restir is None else restir
+    fr = (PipelinedTiledFrame if pipelined else TiledFrame)(CountingBackend(width, height), CountingComm(rank, world), width, height, part)
+    fr._copy_state = lambda s_: s_
+    for f in range(frames):
+        fr.render_frame(st, f)
+    return dict(fr.halo_bytes)
 
 
 class TiledFrame:
@@ -212,7 +328,38 @@ class TiledFrame:
         self._result_pending = []
         self.history_fallbacks = 0  # frames that needed the full history (statistics)
         self._last_frames = None    # frame index of the last render_frame (set_partition redistributes its history)
+        self._halo = HIST_HALO_MIN if HIST_HALO is None else int(HIST_HALO)   # history halo of the NEXT frame's temporal lookups (adaptive, see HIST_HALO)
+        self._halo_cur = self._halo # ... and of the frame being rendered (its history rows were exchanged with this width)
+        self._calm, self._fb_seen = 0, 0
+        self.halo_bytes = dict.fromkeys(HALO_KINDS, 0)   # bytes this rank received for the last complete frame, by purpose
+        self._rx_mark = dict(comm.rx_bytes)
         self._apply_partition(part if part is not None else equal_partition(height, comm.world))
+
+    def _next_halo(self):
+        """History halo of the next frame, decided once per frame from the fallbacks seen so far — identical on every rank (the miss flags are reduced over
+        the ranks), same rule as csrc/mgpu.cpp."""
+        self._halo_cur = self._halo
+        if HIST_HALO is not None:
+            self._halo = int(HIST_HALO)
+        elif self.history_fallbacks != self._fb_seen:
+            self._fb_seen, self._calm, self._halo = self.history_fallbacks, 0, min(HIST_HALO_MAX, max(HIST_HALO_MIN, self._halo * 2))
+        else:
+            self._calm += 1
+            if self._calm >= HIST_HALO_CALM:
+                self._calm, self._halo = 0, max(HIST_HALO_MIN, self._halo // 2)
+        return self._halo
+
+    def _account(self):
+        """close the byte accounting of a frame"""
+        now = self.comm.rx_bytes
+        self.halo_bytes = {k: now[k] - self._rx_mark.get(k, 0) for k in HALO_KINDS}
+        self._rx_mark = dict(now)
+
+    def _gbuffer_halo(self, g, gp, hist):
+        """the G-buffer rows the nine filter passes (and, up to `hist` rows, the next frame's temporal lookups) read beyond the band: every row close to the
+        band, even rows only further out"""
+        full = max(HALO_GBUFFER_FULL, hist)
+        return [Halo(g, gp, self.part, full, self.H), Halo(g, gp, self.part, HALO_GBUFFER, self.H, inner=full, even=True)]
 
     def _apply_partition(self, part):
         part = [int(p) for p in part]
@@ -238,7 +385,7 @@ class TiledFrame:
                             (abi.BUF_LIGHT_ID0 + (cur ^ 1), self.part), (abi.BUF_INDIRECT_RESV0 + (cur ^ 1), self.parth),
                             (abi.BUF_DIRECT_RESV_TEMP, self.part)):
                 t, p = self._t(buf)
-                self.comm.all_gather_rows(t, p, pt)
+                self.comm.all_gather_rows(t, p, pt, kind="moved")
             fn = getattr(self.b, "sync_all", None)
             if fn:
                 fn()
@@ -286,7 +433,7 @@ class TiledFrame:
         if self.comm.world > 1 and state.ReSTIRState in (abi.RESTIR_SPATIAL, abi.RESTIR_SPATIOTEMPORAL):
             self._run(state, frames, abi.STAGE_DIRECT, 1, self.y0, self.y1, self.H)
             t, p = self._t(abi.BUF_DIRECT_RESV_TEMP)
-            self.comm.halo_exchange([(t, p, self.part, 2, self.H)])
+            self.comm.halo_exchange([Halo(t, p, self.part, 2, self.H)], kind="spatial")
             self._run(state, frames, abi.STAGE_DIRECT, 2, self.y0, self.y1, self.H)
         else:
             self._run(state, frames, abi.STAGE_DIRECT, 0, self.y0, self.y1, self.H)
@@ -305,14 +452,14 @@ class TiledFrame:
 
         # ---- ray-traced stages on the band, with exact fallback when temporal reuse leaves band + history halo ------------
         if not single:
-            b.set_history_rows(max(0, self.y0 - HIST_HALO), min(self.H, self.y1 + HIST_HALO))
+            b.set_history_rows(max(0, self.y0 - self._halo), min(self.H, self.y1 + self._halo))
         self._traced_stages(state, frames)
         if not single and c.any_flag(b.history_miss()):
             self.history_fallbacks += 1
             for buf, pt in ((abi.BUF_GBUFFER0 + last, self.part), (abi.BUF_DIRECT_RESV0 + last, self.part), (abi.BUF_LIGHT_ID0 + last, self.part),
                             (abi.BUF_INDIRECT_RESV0 + last, self.parth)):
                 t, p = self._t(buf)
-                c.all_gather_rows(t, p, pt)
+                c.all_gather_rows(t, p, pt, kind="fallback")
             b.set_history_rows(0, self.H)
             self._traced_stages(state, frames)
             b.history_miss()  # clear
@@ -323,9 +470,9 @@ class TiledFrame:
             g, gp = self._t(abi.BUF_GBUFFER0 + cur)
             dcol, _ = self._t(abi.BUF_DIRECT_RESULT0 + cur)
             icol = self._icol(frames)
-            c.halo_exchange([(g, gp, self.part, HALO_GBUFFER, self.H),
-                             (dcol, pitch, self.part, HALO_DIRECT_COLOR, self.H),
-                             (icol, pitch, self.parth, HALO_INDIRECT_COLOR, self.Hh)])
+            c.halo_exchange(self._gbuffer_halo(g, gp, 0) +
+                            [Halo(dcol, pitch, self.part, HALO_DIRECT_COLOR, self.H),
+                             Halo(icol, pitch, self.parth, HALO_INDIRECT_COLOR, self.Hh, width=(self.W // 2) * _COLOR_BYTES)], kind="filter")
         if state.denoise > 0:
             for l in range(4):
                 g_ = 0 if single else DIRECT_GROW[l]
@@ -338,19 +485,25 @@ class TiledFrame:
         # ---- for the next frame: history halo; for the display: result bands to rank 0 (both asynchronous) -----------------
         if not single:
             items = []
-            for buf in (abi.BUF_GBUFFER0 + cur, abi.BUF_DIRECT_RESV0 + cur, abi.BUF_LIGHT_ID0 + cur):
+            hh = self._next_halo()
+            # (with the filters on, the rows of this frame's G-buffer within HALO_GBUFFER_FULL of the band are already here: the filter exchange brought them)
+            g_have = HALO_GBUFFER_FULL if state.denoise > 0 else 0
+            t, p = self._t(abi.BUF_GBUFFER0 + cur)
+            items.append(Halo(t, p, self.part, hh, self.H, inner=min(g_have, hh)))
+            for buf in (abi.BUF_DIRECT_RESV0 + cur, abi.BUF_LIGHT_ID0 + cur):
                 t, p = self._t(buf)
-                items.append((t, p, self.part, HIST_HALO, self.H))
+                items.append(Halo(t, p, self.part, hh, self.H))
             t, p = self._t(abi.BUF_INDIRECT_RESV0 + cur)
-            items.append((t, p, self.parth, HIST_HALO // 2, self.Hh))
-            self._pending = c.halo_exchange(items, async_op=True)
+            items.append(Halo(t, p, self.parth, hh // 2, self.Hh))
+            self._pending = c.halo_exchange(items, async_op=True, kind="history")
+            self._account()
             c.wait(self._result_pending)
             self._result_pending = []
             for buf in (abi.BUF_DIRECT_RESULT0 + cur, abi.BUF_INDIRECT_RESULT0 + cur):
                 t, p = self._t(buf)
                 w = c.gather_rows_to(t, p, self.part, dst=0, async_op=True)
-                if w:
-                    self._result_pending += list(w)
+                if w is not None:
+                    self._result_pending.append(w)
 
     def finish(self):
         """Wait for everything in flight (call before reading results / at the end of a timed region)."""
@@ -443,7 +596,7 @@ class PipelinedTiledFrame(TiledFrame):
             self._wait_ev(("done", f - 2)); self._wait_ev(("I", f - 2))     # storage of dcol(f) / G(f) is free again
             c.wait(self._wR.pop(cur, None))                                   # ... and the result band of f-2 has left
             c.wait(self._wD)                                                  # neighbours' history rows of f-1
-            b.set_history_rows(max(0, self.y0 - HIST_HALO), min(self.H, self.y1 + HIST_HALO))
+            b.set_history_rows(max(0, self.y0 - self._halo), min(self.H, self.y1 + self._halo))
             self._direct(state, f)
             # ---- 2. second half of frame f-1, issued while direct(f) runs: the host's wait for indirect(f-1)'s flag overlaps
             #         with direct(f) instead of following it
@@ -453,27 +606,28 @@ class PipelinedTiledFrame(TiledFrame):
                 self._drain()
                 for buf in (abi.BUF_GBUFFER0 + last, abi.BUF_DIRECT_RESV0 + last, abi.BUF_LIGHT_ID0 + last):
                     t, p = self._t(buf)
-                    c.all_gather_rows(t, p, self.part)
+                    c.all_gather_rows(t, p, self.part, kind="fallback")
                 b.set_history_rows(0, self.H)
                 self._direct(state, f)
                 self._miss(abi.STAGE_DIRECT)  # clear
-            items = []
+            # the history halo of frame f+1 is decided here: every exchange that feeds its temporal lookups (X_D(f) below, X_I(f) in _finish_prev) uses it
+            hh = self._next_halo()
             g, gp = self._t(abi.BUF_GBUFFER0 + cur)
-            items.append((g, gp, self.part, HALO_GBUFFER if state.denoise > 0 else HIST_HALO, self.H))
+            items = self._gbuffer_halo(g, gp, hh) if state.denoise > 0 else [Halo(g, gp, self.part, hh, self.H)]
             for buf in (abi.BUF_DIRECT_RESV0 + cur, abi.BUF_LIGHT_ID0 + cur):
                 t, p = self._t(buf)
-                items.append((t, p, self.part, HIST_HALO, self.H))
+                items.append(Halo(t, p, self.part, hh, self.H))
+            self._wD_prev = self._wD
+            self._wD = [c.halo_exchange(items, async_op=True, kind="history" if state.denoise == 0 else "filter")]
             if state.denoise > 0:
                 dcol, _ = self._t(abi.BUF_DIRECT_RESULT0 + cur)
-                items.append((dcol, self.W * _COLOR_BYTES, self.part, HALO_DIRECT_COLOR, self.H))
-            self._wD_prev = self._wD
-            self._wD = c.halo_exchange(items, async_op=True)
+                self._wD.append(c.halo_exchange([Halo(dcol, self.W * _COLOR_BYTES, self.part, HALO_DIRECT_COLOR, self.H)], async_op=True, kind="filter"))
             self._record(("D", f))
         # ---- 3. indirect(f) on the ind stream -----------------------------------------------------------------------------------
         with self._stream("ind"):
             self._wait_ev(("D", f)); self._wait_ev(("done", f - 1))            # this G-buffer band; the noisy-indirect scratch is free
             c.wait(self._wD_prev); c.wait(self._wI)                           # G(f-1) / indirect-reservoir history rows
-            b.set_history_rows(max(0, self.y0 - HIST_HALO), min(self.H, self.y1 + HIST_HALO))
+            b.set_history_rows(max(0, self.y0 - self._halo_cur), min(self.H, self.y1 + self._halo_cur))
             self._run(state, f, abi.STAGE_INDIRECT, 0, self.h0, self.h1, self.Hh)
             self._validated = False
             if getattr(b, "rotate", None) is None:
@@ -489,6 +643,7 @@ class PipelinedTiledFrame(TiledFrame):
                 for l in range(4):
                     self._run(state, f, abi.STAGE_DENOISE_DIRECT, l, self.y0 - DIRECT_GROW[l], self.y1 + DIRECT_GROW[l], self.H)
         self._prev = (self._copy_state(state), f, self._camera())
+        self._account()
 
     def _finish_prev(self):
         if self._prev is None:
@@ -502,13 +657,12 @@ class PipelinedTiledFrame(TiledFrame):
         with self._stream("ind"):
             if not self._validated:
                 self._validate_indirect(state, f)
-            items = []
             t, p = self._t(abi.BUF_INDIRECT_RESV0 + cur)
-            items.append((t, p, self.parth, HIST_HALO // 2, self.Hh))
+            self._wI = [c.halo_exchange([Halo(t, p, self.parth, self._halo // 2, self.Hh)], async_op=True, kind="history")]
             if state.denoise > 0:
                 icol = self._icol(f)
-                items.append((icol, self.W * _COLOR_BYTES, self.parth, HALO_INDIRECT_COLOR, self.Hh))
-            self._wI = c.halo_exchange(items, async_op=True)
+                self._wI.append(c.halo_exchange([Halo(icol, self.W * _COLOR_BYTES, self.parth, HALO_INDIRECT_COLOR, self.Hh, width=(self.W // 2) * _COLOR_BYTES)],
+                                                async_op=True, kind="filter"))
             self._record(("Ix", f))
         with self._stream("side"):
             self._wait_ev(("Ix", f)); self._wait_ev(("I", f))
@@ -522,8 +676,8 @@ class PipelinedTiledFrame(TiledFrame):
             for buf in (abi.BUF_DIRECT_RESULT0 + cur, abi.BUF_INDIRECT_RESULT0 + cur):
                 t, p = self._t(buf)
                 w = c.gather_rows_to(t, p, self.part, dst=0, async_op=True)
-                if w:
-                    works += list(w)
+                if w is not None:
+                    works.append(w)
             self._wR[cur] = works
         self._set_camera(now)
 
@@ -542,7 +696,7 @@ class PipelinedTiledFrame(TiledFrame):
             self._rotate(newer)            # undo: the boundary ids point at frame f's G-buffers / motion vectors again
         for buf, pt in ((abi.BUF_GBUFFER0 + last, self.part), (abi.BUF_INDIRECT_RESV0 + last, self.parth)):
             t, p = self._t(buf)
-            c.all_gather_rows(t, p, pt)
+            c.all_gather_rows(t, p, pt, kind="fallback")
         b.set_history_rows(0, self.H)
         self._run(state, f, abi.STAGE_INDIRECT, 0, self.h0, self.h1, self.Hh)
         self._miss(abi.STAGE_INDIRECT)     # clear
