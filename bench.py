@@ -88,6 +88,10 @@ def main():
     ap.add_argument("--band-rounds", type=int, default=8, help="N > 1: planning rounds of the cost-weighted band heights before the warm-up")
     ap.add_argument("--no-period", action="store_true", help="--emulate-world: skip the frames-in-flight period pass")
     ap.add_argument("--period-rounds", type=int, default=4, help="--emulate-world: re-planning rounds of the band heights on the measured per-rank periods")
+    ap.add_argument("--native", action="store_true", help="N > 1: ONE process drives the N devices through the native context (rt_mgpu_*, csrc/mgpu.cpp: frames in flight per rank, "
+                                                         "event-ordered peer pulls) instead of one process per GPU over RCCL; same JSON line plus the measured link time of every pull group")
+    ap.add_argument("--devices", type=str, default="", help="--native: explicit device list, e.g. 0,1,2,3; a list with repeats (0,0) runs several ranks on one device — a functional check "
+                                                            "of the host (tests/test_gpu_bench_cli.py), reported with n_gpus = the number of DISTINCT devices")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -104,6 +108,17 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    # --gpus N means N devices, whoever launched this process.  A plain `python bench.py --gpus 8` (no WORLD_SIZE) used to render on ONE device and print
+    # "n_gpus": 1 (round-3 verdict): it now refuses when fewer than N devices are visible and otherwise launches the N ranks itself.
+    if args.gpus > 1 and torch.cuda.device_count() < args.gpus and not (args.native and args.devices):
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} device(s) visible on this host — refusing to report a {args.gpus}-GPU number "
+                         f"from fewer devices (use --emulate-world {args.gpus} for the one-device per-rank instrument)")
+    if args.gpus > 1 and args.native:
+        if rank != 0:
+            return None                      # (launched under torch.distributed.run: the native host is ONE process, rank 0's)
+        return native_world(args, abi, host, Renderer, torch)
+    if args.gpus > 1 and world == 1:
+        return self_launch(args)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -404,6 +419,133 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks the way the driver does (torch.distributed.run, one rank per GPU, RCCL) and pass
+    rank 0's JSON line through."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def native_world(args, abi, host, Renderer, torch):
+    """N > 1 through the native context: ONE process, one worker thread + rt_ctx + three streams per device, frames in flight per rank, every exchange a
+    hipMemcpyPeerAsync pull ordered by events (csrc/mgpu.cpp) — the host round 3 optimised, on N REAL devices.  Same metric and JSON as the RCCL host."""
+    from restir_amd.renderer import MultiGpuRenderer, LINK_GROUPS
+    n = args.gpus
+    devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(n))
+    if len(devices) != n or any(d < 0 or d >= torch.cuda.device_count() for d in devices):
+        raise SystemExit(f"--devices {args.devices}: needs {n} indices below {torch.cuda.device_count()}")
+    distinct = len(set(devices))
+    cfg = CONFIGS[args.config]
+    W, H = args.width or cfg["size"][0], args.height or cfg["size"][1]
+    orbit = args.moving_camera or cfg.get("orbit", False)
+    if cfg.get("di_only"):
+        raise SystemExit("--native: config 2 is the direct stage alone (one launch per step); it has no row-tiled form")
+    scene = host.Scene().makeProcedural(getattr(abi, cfg["kind"]), args.scale, 1)
+    env = None
+    if cfg["env"]:
+        env = host.HdrSampling(); env.makeSyntheticSky(cfg["env"][0], cfg["env"][1], 5e4, 7)
+    st = host.default_state(W, H, scene, env)
+    for k, v in cfg.get("state", {}).items():
+        setattr(st, k, v)
+    desc = scene.desc(env)
+    m = MultiGpuRenderer().setup(devices)
+    t0 = time.time(); m.load_scene(desc); build_s = time.time() - t0
+    m.update(W, H)
+    m.set_balance(0 if args.equal_bands else 1)
+    eye0, center0, up0, fov0 = scene.cameraPose()
+    scene.updateCamera(W, H)
+
+    def camera(f):
+        st.time = 1000 + f
+        if orbit:
+            a = np.deg2rad(0.5 * (f + 1))
+            rot = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], dtype=np.float32)
+            scene.setCamera(center0 + rot @ (eye0 - center0), center0, up0, fov0)
+        scene.updateCamera(W, H)
+        return scene.getCamera()
+
+    f = 0
+    for _ in range(args.warmup + 8 * 2):      # the balancer moves a boundary by at most two stripes per frame: give it the frames the RCCL host's planning rounds get
+        m.set_camera(camera(f)); m.run(st, f); f += 1
+    m.sync()
+    if not args.equal_bands:
+        m.set_balance(2)                       # the partition is then fixed, like the RCCL host's: nothing of the planning runs in the timed region
+    for _ in range(4):
+        m.set_camera(camera(f)); m.run(st, f); f += 1
+    m.sync()
+    first_timed = f
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        m.set_camera(camera(f)); m.run(st, f); f += 1
+    m.sync()
+    elapsed = time.perf_counter() - t0
+    stats, links = m.stats(), m.link_stats()
+    bands = [(int(stats.bandBegin[r]), int(stats.bandEnd[r])) for r in range(n)]
+    # rays of the same frames: the tiled frame is bit-identical to the single-GPU one, so its rays are counted there (instrumented kernels, device 0, untimed)
+    r = Renderer().setup(0); r.load_scene(desc); r.update(W, H)
+    n_count = min(4, args.steps)
+    for k in range(2):
+        r.set_camera(camera(first_timed - 2 + k)); r.run(st, first_timed - 2 + k)
+    r.set_counting(True)
+    for k in range(n_count):
+        r.set_camera(camera(first_timed + k)); r.run(st, first_timed + k)
+    r.sync(); cnt = r.counters(); r.set_counting(False)
+    rays_per_frame = float(cnt.closestHitRays + cnt.anyHitRays) / n_count
+    ms_per_step = elapsed / args.steps * 1e3
+    out = {"metric": "Mrays/s (ClosestHit+AnyHit ray queries per second) of the " + ("1080p ReSTIR DI+GI+denoise frame" if args.config == 4 else f"config-{args.config} frame") + "; ms_per_step = ms/frame",
+           "value": round(rays_per_frame * args.steps / elapsed / 1e6, 2), "unit": "Mrays/s", "n_gpus": distinct, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"config {args.config}: {cfg['name']} procedural scene, {scene.getStat()['instancedTriangles']} triangles, {W}x{H}, {cfg['pipeline']}, "
+                                  + ("camera orbiting 0.5 deg / frame" if orbit else "static camera"),
+                      "baseline_config": args.config, "width": W, "height": H, "scene_scale": args.scale,
+                      "parallelism": f"row-tiled x{n}: ONE process, native context (rt_mgpu_*): a worker thread, an rt_ctx and three streams per device, frames in flight per rank, "
+                                     f"event-ordered hipMemcpyPeerAsync pulls; " + ("equal-height bands" if args.equal_bands else f"cost-weighted bands {bands}"),
+                      "rays_per_frame": round(rays_per_frame), "fps": round(1e3 / ms_per_step, 2), "bvh8_build_s": round(build_s, 2)},
+           "ranks": n, "history_fallbacks": int(stats.historyFallbacks),
+           "halo_bytes_per_rank": [int(sum(stats.haloBytesRankKind[q][k] for k in range(4))) for q in range(n)]}
+    # the links, measured: every rank's four pull groups of the last timed frame, HIP events on the stream that carried them
+    lk = {"devices": [int(links.devices[q]) for q in range(n)], "peer_access": [[int(links.peerAccess[a][b]) for b in range(n)] for a in range(n)], "groups": list(LINK_GROUPS),
+          "pull_ms": [[round(float(links.pullMs[q][g]), 4) for g in range(4)] for q in range(n)], "pull_bytes": [[int(links.pullBytes[q][g]) for g in range(4)] for q in range(n)]}
+    tot_b = sum(sum(x) for x in lk["pull_bytes"]); tot_ms = sum(sum(x) for x in lk["pull_ms"])
+    lk["GBps_while_pulling"] = round(tot_b / max(1e-9, tot_ms * 1e-3) / 1e9, 2) if tot_ms > 0 else None
+    lk["slowest_rank_pull_ms"] = round(max(sum(x) for x in lk["pull_ms"]), 4)
+    out["links"] = lk
+    if distinct < n:
+        out["note"] = f"{n} ranks on {distinct} device(s): a functional check of the native host, NOT a benchmark result"
+    # roofline of the dominant kernel of rank 0's band, launched alone on device 0 (same per-unit figures as the N = 1 line, DESIGN.md 8)
+    try:
+        y0, y1 = bands[0]
+        fdom = first_timed + min(2, args.steps - 1)
+        r.set_camera(camera(fdom))
+        cur = torch.cuda.Stream(); r.set_stream(cur.cuda_stream)
+        r.run_stage(st, fdom, abi.STAGE_DIRECT, 0, y0, y1); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(cur)
+        for _ in range(5):
+            r.run_stage(st, fdom, abi.STAGE_DIRECT, 0, y0, y1)
+        e1.record(cur); torch.cuda.synchronize()
+        dur_ms = e0.elapsed_time(e1) / 5
+        r.set_counting(True); r.run_stage(st, fdom, abi.STAGE_DIRECT, 0, y0, y1); r.sync()
+        cb = r.counters(); r.set_counting(False)
+        b_screen = SCREEN_BYTES[0] * W * (y1 - y0)
+        b_trav = cb.nodesVisited * NODE_B + cb.trisTested * TRI_B + cb.hitsShaded * HIT_B + cb.risCandidates * RIS_B
+        ach = (b_screen + b_trav) / (dur_ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": None, "bound_note": "no counter pass exists for a row band: a band-sized launch is bound by the dependent steps of its slowest rays (DESIGN.md 7), neither by bytes nor by issue slots",
+                           "kernel": "direct_stage (rank 0's band, rows %d..%d, launched alone)" % (y0, y1), "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": round(b_screen + b_trav),
+                           "screen_bytes": round(b_screen), "traversal_bytes": round(b_trav), "launch_ms": round(dur_ms, 4)}
+    except Exception as e:  # the headline number must not depend on this extra pass
+        out["roofline"] = {"bound": None, "error": repr(e)}
+    print(json.dumps(out), flush=True)
+    m.destroy(); r.destroy()
+    return None
 
 
 # xGMI model for the emulation (the link time of a pull is not measurable on one device): one link per neighbour, 153.6 GB/s bidirectional per link

@@ -114,6 +114,13 @@ struct Rank {
   uint64_t pulledBy[2][HK_COUNT] = {};
   uint64_t lastPulled[HK_COUNT] = {};    // ... of the latest COMPLETE frame: what rt_mgpu_get_stats reports
   int accSlot = -1;                      // >= 0: pullRowsOn accounts to pulledBy[accSlot]
+  // link timing (frames in flight): the four pull groups of a frame bracketed by events on the stream that carries them — history rows (main), indirect-reservoir
+  // history (ind), direct filter halo (side), indirect filter halo (side) — and their bytes; rt_mgpu_get_link_stats reports the latest complete frame
+  enum { LG_HISTORY = 0, LG_HISTORY_IND, LG_FILTER_DIRECT, LG_FILTER_INDIRECT, LG_COUNT };
+  hipEvent_t tl[RING][2 * LG_COUNT] = {};
+  uint64_t grpBytes[RING][LG_COUNT] = {};
+  int grp = -1, grpSlot = 0;             // >= 0: pullRowsOn also accounts to grpBytes[grpSlot][grp]
+  float linkMs[LG_COUNT] = {}; uint64_t linkBytes[LG_COUNT] = {};
   Rank() { for(auto& a : issued) a.store(-1); }
 };
 
@@ -210,12 +217,14 @@ void pullRowsOn(rt_mgpu& M, Rank& R, hipStream_t strm, int buf, int a, int b, co
           MG_HIP(hipMemcpyPeerAsync(static_cast<char*>(dst) + off + size_t(y) * stride, R.dev, static_cast<char*>(src) + off + size_t(y) * stride, Q.dev, w, strm), "hipMemcpyPeerAsync (row)");
       }
       (R.accSlot >= 0 ? R.pulledBy[R.accSlot] : R.pulled)[kind] += w * size_t(rows);
+      if(R.grp >= 0) R.grpBytes[R.grpSlot][R.grp] += w * size_t(rows);
       continue;
     }
     const size_t off = size_t(lo) * pitch, len = size_t(hi - lo) * pitch;
     if(Q.dev == R.dev) MG_HIP(hipMemcpyAsync(static_cast<char*>(dst) + off, static_cast<char*>(src) + off, len, hipMemcpyDeviceToDevice, strm), "hipMemcpyAsync");
     else MG_HIP(hipMemcpyPeerAsync(static_cast<char*>(dst) + off, R.dev, static_cast<char*>(src) + off, Q.dev, len, strm), "hipMemcpyPeerAsync");
     (R.accSlot >= 0 ? R.pulledBy[R.accSlot] : R.pulled)[kind] += len;
+    if(R.grp >= 0) R.grpBytes[R.grpSlot][R.grp] += len;
   }
 }
 void pullRows(rt_mgpu& M, Rank& R, int buf, int a, int b, const std::vector<int>& part, int kind) { pullRowsOn(M, R, R.stream, buf, a, b, part.data(), kind); }
@@ -389,7 +398,22 @@ void harvestTiming(Rank& R, int64_t seq)
   float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
   if(hipEventElapsedTime(&a, t[0], t[1]) == hipSuccess && hipEventElapsedTime(&b, t[2], t[3]) == hipSuccess) R.tracedMs = a + b;
   if(hipEventElapsedTime(&c, t[4], t[5]) == hipSuccess && hipEventElapsedTime(&d, t[6], t[7]) == hipSuccess) R.filterMs = c + d;
+  for(int g = 0; g < Rank::LG_COUNT; g++) {
+    float ms = 0.f;
+    R.linkBytes[g] = R.grpBytes[seq % RING][g];
+    R.linkMs[g] = (R.linkBytes[g] && hipEventElapsedTime(&ms, R.tl[seq % RING][2 * g], R.tl[seq % RING][2 * g + 1]) == hipSuccess) ? ms : 0.f;
+  }
 }
+// bracket a group of pulls on `strm` for the link statistics
+struct LinkGroup {
+  rt_mgpu& M; Rank& R; hipStream_t strm; int g, slot;
+  LinkGroup(rt_mgpu& M_, Rank& R_, hipStream_t s, int g_, int slot_) : M(M_), R(R_), strm(s), g(g_), slot(slot_)
+  {
+    R.grpBytes[slot][g] = 0; R.grp = g; R.grpSlot = slot;
+    (void)hipEventRecord(R.tl[slot][2 * g], strm);
+  }
+  ~LinkGroup() { (void)hipEventRecord(R.tl[slot][2 * g + 1], strm); R.grp = -1; }
+};
 
 // second half of frame p = prevCmd: validate its indirect stage, then (side stream) the indirect filter halo, 5 levels, compose; rank 0 gathers
 void finishPrev(rt_mgpu& M, Rank& R, int rotatedFrames /* frames value the G-buffer ids were last rotated for, or -1 */)
@@ -426,7 +450,7 @@ void finishPrev(rt_mgpu& M, Rank& R, int rotatedFrames /* frames value the G-buf
   MG_CHECK(rt_set_stream(R.ctx, R.sSide), "rt_set_stream");
   waitAll(M, R, R.sSide, Rank::E_I, p, true);
   MG_HIP(hipEventRecord(R.tm[slot][6], R.sSide), "hipEventRecord");
-  if(multi && c.st.denoise > 0) pullFilterHaloIndirect(M, R, R.sSide, f, h0, h1, c.bands);
+  if(multi && c.st.denoise > 0) { LinkGroup lg(M, R, R.sSide, Rank::LG_FILTER_INDIRECT, slot); pullFilterHaloIndirect(M, R, R.sSide, f, h0, h1, c.bands); }
   recordIssued(M, R, Rank::E_XI, p, R.sSide);
   if(c.st.denoise > 0) {
     runStage(M, R, c.st, f, RT_STAGE_DENOISE_INDIRECT, 0, h0 - (multi ? INDIRECT_GROW[0] : 0), h1 + (multi ? INDIRECT_GROW[0] : 0), Hh);   // IndA -> IndB
@@ -461,6 +485,7 @@ void pipeDirect(rt_mgpu& M, Rank& R, const FrameCmd& c)
   R.accSlot = int(s & 1);
   for(auto& p : R.pulledBy[s & 1]) p = 0;
   harvestTiming(R, s - 3);
+  for(auto& b : R.grpBytes[slot]) b = 0;
   MG_CHECK(rt_rotate_buffers(R.ctx, f), "rt_rotate_buffers");   // G-buffer x3, motion x2: direct(f) must not overwrite what indirect(f-1) still reads
   R.rotatedFor = f;
   { void* p = nullptr; size_t b = 0, pitch = 0; MG_CHECK(rt_device_ptr(R.ctx, RT_BUF_GBUFFER0 + cur, &p, &b, &pitch), "rt_device_ptr"); R.gptr[slot] = p; }
@@ -471,6 +496,7 @@ void pipeDirect(rt_mgpu& M, Rank& R, const FrameCmd& c)
   MG_CHECK(rt_set_stream(R.ctx, R.stream), "rt_set_stream");
   MG_CHECK(rt_set_camera(R.ctx, &c.cam), "rt_set_camera");
   if(multi && c.haveHistory) {
+    LinkGroup lg(M, R, R.stream, Rank::LG_HISTORY, slot);
     const int gs = s >= 1 ? int((s - 1) % RING) : -1;   // (first frame after a restart: everything is drained, the boundary ids name last frame's buffers on every rank)
     const int HIST_HALO = c.histHalo;
     // The G-buffer rows next to the band came with the filter halo of f-1 when the partition did not move — IF that pull (this rank's SIDE stream) has been
@@ -529,6 +555,7 @@ void pipeIndirectAndDirectFilters(rt_mgpu& M, Rank& R, const FrameCmd& c)
   if(s >= 2) MG_HIP(hipStreamWaitEvent(R.sInd, R.evp[Rank::E_DONE][(s - 2) % RING], 0), "hipStreamWaitEvent");   // ... and filtered here
   MG_CHECK(rt_set_stream(R.ctx, R.sInd), "rt_set_stream");
   if(multi && c.haveHistory) {
+    LinkGroup lg(M, R, R.sInd, Rank::LG_HISTORY_IND, slot);
     pullRowsOn(M, R, R.sInd, RT_BUF_INDIRECT_RESV0 + last, h0 - c.histHalo / 2, h1 + c.histHalo / 2, c.prev, HK_HISTORY);
     pullRowsOn(M, R, R.sInd, RT_BUF_INDIRECT_RESV0 + cur, h0, h1, c.prev, HK_MOVED);
   }
@@ -539,6 +566,7 @@ void pipeIndirectAndDirectFilters(rt_mgpu& M, Rank& R, const FrameCmd& c)
   waitAll(M, R, R.sSide, Rank::E_D, s, true);
   MG_HIP(hipEventRecord(R.tm[slot][4], R.sSide), "hipEventRecord");
   if(multi && c.st.denoise > 0) {
+    LinkGroup lg(M, R, R.sSide, Rank::LG_FILTER_DIRECT, slot);
     pullFilterHaloDirect(M, R, R.sSide, cur, y0, y1, c.bands, slot);
   }
   recordIssued(M, R, Rank::E_X, s, R.sSide);
@@ -741,6 +769,7 @@ void destroyRank(Rank& R)
   for(auto& e : R.ev) if(e) (void)hipEventDestroy(e);
   for(auto& k : R.evp) for(auto& e : k) if(e) (void)hipEventDestroy(e);
   for(auto& k : R.tm) for(auto& e : k) if(e) (void)hipEventDestroy(e);
+  for(auto& k : R.tl) for(auto& e : k) if(e) (void)hipEventDestroy(e);
   for(hipStream_t s : {R.stream, R.sInd, R.sSide, R.sCopy}) if(s) (void)hipStreamDestroy(s);
   R.ctx = nullptr;
 }
@@ -805,6 +834,7 @@ int rt_mgpu_create(rt_mgpu** out, int numRanks, const int* devices)
     for(auto& e : R.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     for(auto& k : R.evp) for(auto& e : k) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     for(auto& k : R.tm) for(auto& e : k) ok = ok && hipEventCreate(&e) == hipSuccess;
+    for(auto& k : R.tl) for(auto& e : k) ok = ok && hipEventCreate(&e) == hipSuccess;
     if(!ok) return bail(RT_ERR_HIP);
     rt_set_stream(R.ctx, R.stream);
     rt_set_overlap(R.ctx, 0);   // stages are issued one by one through rt_run_stage
@@ -984,6 +1014,26 @@ int rt_mgpu_get_stats(rt_mgpu* M, rt_mgpu_stats* out)
   return RT_OK;
 }
 const char* rt_mgpu_last_error(rt_mgpu* M) { return (M && !M->err.empty()) ? M->err.c_str() : ""; }
+
+// What the links did for the latest complete frame of the frames-in-flight schedule: the four pull groups of every rank, event-timed on the stream that
+// carried them, with their bytes; plus the device of every rank and whether the puller has direct peer access to the owner (xGMI on an MI355X node).
+int rt_mgpu_get_link_stats(rt_mgpu* M, rt_mgpu_link_stats* out)
+{
+  if(!M || !out) return RT_ERR_INVALID_ARG;
+  DeviceGuard guard;
+  const bool wasActive = M->pipeActive;
+  (void)drainAll(M);
+  memset(out, 0, sizeof(*out));
+  out->numRanks = M->n;
+  for(int r = 0; r < M->n; r++) {
+    Rank& R = M->ranks[size_t(r)];
+    if(wasActive) harvestTiming(R, M->seq - 1);
+    out->devices[r] = R.dev;
+    for(int q = 0; q < M->n; q++) out->peerAccess[r][q] = M->peerOk[size_t(r) * size_t(M->n) + size_t(q)];
+    for(int g = 0; g < Rank::LG_COUNT; g++) { out->pullMs[r][g] = R.linkMs[g]; out->pullBytes[r][g] = R.linkBytes[g]; }
+  }
+  return RT_OK;
+}
 
 // Assemble a buffer of the LAST rendered frame from the ranks that own its rows (caller-side layout == rt_readback's).
 int rt_mgpu_readback(rt_mgpu* M, int buffer, void* dst, size_t bytes)

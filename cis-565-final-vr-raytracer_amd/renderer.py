@@ -17,7 +17,7 @@ ABI_SYMBOLS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "r
                "rt_render_frame", "rt_run_stage", "rt_readback", "rt_upload_history", "rt_buffer_bytes", "rt_device_ptr",
                "rt_set_counting", "rt_get_counters", "rt_sync", "rt_last_error", "rt_abi_version", "rt_set_traversal", "rt_set_history_rows", "rt_history_miss", "rt_set_overlap", "rt_tonemap", "rt_set_sun_and_sky", "rt_pick", "rt_trace_rays", "rt_history_miss_stage", "rt_rotate_buffers", "rt_select_frame", "rt_measure_valu_peak",
                "rt_mgpu_create", "rt_mgpu_destroy", "rt_mgpu_upload_scene", "rt_mgpu_resize", "rt_mgpu_set_camera", "rt_mgpu_render_frame", "rt_mgpu_readback",
-               "rt_mgpu_sync", "rt_mgpu_set_balance", "rt_mgpu_set_serialize", "rt_mgpu_set_pipeline", "rt_mgpu_set_gather", "rt_mgpu_set_solo", "rt_mgpu_set_bands", "rt_mgpu_get_stats", "rt_mgpu_last_error", "rt_mgpu_plan_bands"]
+               "rt_mgpu_sync", "rt_mgpu_set_balance", "rt_mgpu_set_serialize", "rt_mgpu_set_pipeline", "rt_mgpu_set_gather", "rt_mgpu_set_solo", "rt_mgpu_set_bands", "rt_mgpu_get_stats", "rt_mgpu_get_link_stats", "rt_mgpu_last_error", "rt_mgpu_plan_bands"]
 
 
 def hip_lib():
@@ -259,6 +259,13 @@ class MgpuStats(C.Structure):  # rt_mgpu_stats
                 ("bandBegin", C.c_int32 * 16), ("bandEnd", C.c_int32 * 16), ("tracedMs", C.c_float * 16), ("filterMs", C.c_float * 16), ("haloBytesKind", C.c_uint64 * 6), ("haloBytesRankKind", (C.c_uint64 * 6) * 16)]
 
 
+class MgpuLinkStats(C.Structure):  # rt_mgpu_link_stats (ABI 2.1)
+    _fields_ = [("numRanks", C.c_int32), ("devices", C.c_int32 * 16), ("peerAccess", (C.c_uint8 * 16) * 16), ("pullMs", (C.c_float * 4) * 16), ("pullBytes", (C.c_uint64 * 4) * 16)]
+
+
+LINK_GROUPS = ("history", "history_indirect", "filter_direct", "filter_indirect")
+
+
 class MultiGpuRenderer:
     """rt_mgpu_*: one process drives N devices (csrc/mgpu.cpp) — the Renderer interface over the native row-tiled frame."""
     def __init__(self):
@@ -317,6 +324,10 @@ class MultiGpuRenderer:
     def stats(self):
         s = MgpuStats()
         self._chk(hip_lib().rt_mgpu_get_stats(self._h, C.byref(s)), "rt_mgpu_get_stats")
+        return s
+    def link_stats(self):
+        s = MgpuLinkStats()
+        self._chk(hip_lib().rt_mgpu_get_link_stats(self._h, C.byref(s)), "rt_mgpu_get_link_stats")
         return s
     def readback(self, buf):
         W, H = self.size

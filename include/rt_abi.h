@@ -463,6 +463,18 @@ int rt_mgpu_set_pipeline(rt_mgpu* m, int on);     /* 1 (default): frames in flig
 int rt_mgpu_set_gather(rt_mgpu* m, int on);       /* 1 (default): rank 0 pulls the result bands every frame (display rank); 0: results stay with their owners */
 int rt_mgpu_set_solo(rt_mgpu* m, int rank);       /* measurement aid: only `rank` renders (its pulls read the idle ranks' stale rows): the PERIOD of one rank on a GPU to itself; -1 = off */
 int rt_mgpu_get_stats(rt_mgpu* m, rt_mgpu_stats* out);
+/* Link statistics of the latest complete frame of the frames-in-flight schedule (ABI 2.1): every rank's four pull groups — 0 history rows (main stream),
+ * 1 indirect-reservoir history (indirect stream), 2 direct filter halo, 3 indirect filter halo (filter stream) — timed with HIP events on the stream that
+ * carried them, and their bytes; the device of every rank; peerAccess[puller][owner] = 1 when the puller's device has direct peer access to the owner's
+ * (xGMI on an MI355X node; 0 = staged by the runtime).  This is the measured point bench.py's xgmi_model stands in for on a one-GPU box. */
+typedef struct {
+  int32_t numRanks;
+  int32_t devices[RT_MGPU_MAX_RANKS];
+  uint8_t peerAccess[RT_MGPU_MAX_RANKS][RT_MGPU_MAX_RANKS];
+  float pullMs[RT_MGPU_MAX_RANKS][4];
+  uint64_t pullBytes[RT_MGPU_MAX_RANKS][4];
+} rt_mgpu_link_stats;
+int rt_mgpu_get_link_stats(rt_mgpu* m, rt_mgpu_link_stats* out);
 /* The partition rule on its own (pure host arithmetic): boundaries (numRanks + 1 rows, multiples of 16) that equalise the summed cost of the
  * 16-row stripes; with prevBands a boundary moves at most maxMoveStripes stripes (< 0: unlimited); every rank keeps >= one stripe. */
 int rt_mgpu_plan_bands(int height, int numRanks, const float* stripeCost, const int* prevBands, int maxMoveStripes, int* outBands);
@@ -477,10 +489,10 @@ int rt_measure_valu_peak(rt_ctx* ctx, int variant, int wavesPerSimd, double* wav
 int rt_sync(rt_ctx* ctx);
 /* Last error message of this ctx (or of rt_create when ctx == NULL). Never NULL. */
 const char* rt_last_error(rt_ctx* ctx);
-/* ABI version: (major<<16)|minor.  2.0 (round 3): rt_set_pipeline -> rt_set_traversal; RT_STAGE_DIRECT levels 1 / 2 are rejected outside the
+/* ABI version: (major<<16)|minor.  2.1 (round 4): + rt_mgpu_get_link_stats.  2.0 (round 3): rt_set_pipeline -> rt_set_traversal; RT_STAGE_DIRECT levels 1 / 2 are rejected outside the
  * spatial modes; 1.1 would have been round 2's additions (rt_mgpu_*, rt_measure_valu_peak, the `level` halves of RT_STAGE_DIRECT). */
 #define RT_ABI_VERSION_MAJOR 2u
-#define RT_ABI_VERSION_MINOR 0u
+#define RT_ABI_VERSION_MINOR 1u
 uint32_t rt_abi_version(void);
 
 #ifdef __cplusplus
