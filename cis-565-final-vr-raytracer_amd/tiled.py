@@ -78,6 +78,16 @@ class Halo:
         return n * (self.width if self.width is not None else self.pitch)
 
 
+def halo_view(item, a, b, tensor=None):
+    """the rows of [a, b) the item moves, as a 2-D (rows, bytes) view of its tensor (or of `tensor`: another rank's copy of the same buffer)"""
+    a, n, step = item.rows(a, b)
+    if n <= 0:
+        return None
+    t = item.tensor if tensor is None else tensor
+    v = t[a * item.pitch:(a + (n - 1) * step + 1) * item.pitch].view(-1, item.pitch)[::step]
+    return v if item.width is None else v[:, :item.width]
+
+
 class Pending:
     """Works of one batched exchange plus the unpacking of its staged (strided / partial-width) receives.  wait() may be called once per consuming stream:
     the first call waits for the transfers and unpacks on the current stream, later calls (other streams) wait for that unpacking."""
@@ -183,12 +193,7 @@ class TorchComm:
         return p
 
     def _view(self, item, a, b):
-        """the rows of [a, b) the item moves, as a 2-D (rows, bytes) view of its tensor"""
-        a, n, step = item.rows(a, b)
-        if n <= 0:
-            return None
-        v = item.tensor[a * item.pitch:(a + (n - 1) * step + 1) * item.pitch].view(-1, item.pitch)[::step]
-        return v if item.width is None else v[:, :item.width]
+        return halo_view(item, a, b)
 
     def _pair_ops(self, ops, unpack, item, need_of, kind):
         """sends / receives of one item between this rank and every other; both sides enumerate the segments of a pair in the same order"""

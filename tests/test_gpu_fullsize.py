@@ -85,33 +85,37 @@ class ThreadComm:
     """In-process stand-in for torch.distributed on ONE GPU: ranks are threads, collectives are device-to-device copies
     between the ranks' own contexts (every rank has full-size private buffers, as on a real node)."""
     def __init__(self, rank, world, shared):
+        from restir_amd import tiled
         self.rank, self.world, self.s = rank, world, shared
+        self.rx_bytes = dict.fromkeys(tiled.HALO_KINDS, 0)
     def _sync(self):
         import torch
         self.s["renderers"][self.rank].sync(); torch.cuda.synchronize(); self.s["barrier"].wait()
-    def _copy_needed(self, tensor, pitch, part, need, limit):
-        """rows in `need` (list of (lo, hi)) that other ranks own, copied from their buffers (all ranks call with the same arguments)"""
+    nccl = False
+    def _copy_items(self, items, need_of):
+        """the rows every item needs from other ranks' buffers (all ranks call with the same item list => the barriers line up); strided / partial-width
+        items go through the same views the RCCL transport packs and unpacks"""
         import torch
-        self.s["slot"][self.rank] = tensor
-        self._sync()
-        for (lo, hi) in need:
-            for p in range(self.world):
-                if p == self.rank:
-                    continue
-                a, b = max(lo, part[p]), min(hi, part[p + 1], limit)
-                if b > a:
-                    tensor[a * pitch:b * pitch].copy_(self.s["slot"][p][a * pitch:b * pitch])
-        torch.cuda.synchronize(); self.s["barrier"].wait()
-    def all_gather_rows(self, tensor, pitch, part, async_op=False):
-        self._copy_needed(tensor, pitch, part, [(0, part[-1])], part[-1])
-        return None
-    def halo_exchange(self, items, async_op=False):
         from restir_amd import tiled
-        for (tensor, pitch, part, halo, limit) in items:   # every rank passes the same item list => barriers line up
-            if halo <= 0:
-                continue
-            self._copy_needed(tensor, pitch, part, tiled._need(part, self.rank, halo, limit), limit)
-        return []
+        self.s["slot"][self.rank] = [it.tensor for it in items]
+        self._sync()
+        for i, it in enumerate(items):
+            for (lo, hi) in need_of(it):
+                for p in range(self.world):
+                    if p == self.rank:
+                        continue
+                    a, b = max(lo, it.part[p]), min(hi, it.part[p + 1], it.limit)
+                    dst = tiled.halo_view(it, a, b) if b > a else None
+                    if dst is not None:
+                        dst.copy_(tiled.halo_view(it, a, b, self.s["slot"][p][i]))
+        torch.cuda.synchronize(); self.s["barrier"].wait()
+    def all_gather_rows(self, tensor, pitch, part, async_op=False, kind="fallback"):
+        from restir_amd import tiled
+        self._copy_items([tiled.Halo(tensor, pitch, part, part[-1], part[-1])], lambda it: [(0, part[-1])])
+        return None
+    def halo_exchange(self, items, async_op=False, kind="filter"):
+        self._copy_items([it for it in items], lambda it: it.need(self.rank) if it.halo > it.inner else [])
+        return None
     def gather_rows_to(self, tensor, pitch, part, dst=0, async_op=False): return self.all_gather_rows(tensor, pitch, part)
     def all_gather_floats(self, values):
         self.s.setdefault("floats", [None] * self.world)[self.rank] = list(values)
