@@ -133,7 +133,6 @@ def test_mgpu_bad_arguments():
 def test_mgpu_recovers_after_a_failed_call():
     """An error is reported by the call that caused it and must not poison the context (round-3 advisor: the per-rank codes were sticky): a scene the
     validation rejects, then the good scene on the SAME context renders the single-GPU frame."""
-    import copy
     from restir_amd.renderer import Renderer, MultiGpuRenderer, RtError
     W, H = 160, 96
     sc, env = make_scene(abi.PROC_SPONZA, 0.01, 1, (128, 64))
@@ -141,7 +140,7 @@ def test_mgpu_recovers_after_a_failed_call():
     desc = sc.desc(env)
     cams = _cams(sc, W, H, 3, 0.03)
     m = MultiGpuRenderer().setup(_devices(3))
-    bad = copy.copy(desc)
+    bad = type(desc).from_buffer_copy(desc)               # same arrays, one field broken
     bad.numMaterials = 0                                   # rt_upload_scene: "missing geometry/material arrays"
     with pytest.raises(RtError):
         m.load_scene(bad)
