@@ -55,6 +55,51 @@ def lib_sha256_16():
         return hashlib.sha256(fh.read()).hexdigest()[:16]
 
 
+def workload_key(config, orbit):
+    return f"config{config}" + ("_moving" if orbit and config != 5 else "")
+
+
+def pmc_entry(key, kname):
+    """(per-launch counters of kernel `kname` for workload `key`, the whole file) from profiles/pmc_traffic.json — only if they were collected on THIS build of
+    the library (scripts/pmc.sh stamps the file with the library hash); otherwise (None, file-or-None): counters of another build are history, not measurement."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            pmc = json.load(fh)
+    except (OSError, ValueError):
+        return None, None
+    if pmc.get("_lib_sha256_16") != lib_sha256_16():
+        return None, pmc
+    w = pmc.get("workloads", {}).get(key)
+    if w is None and key == "config4":
+        w = pmc          # (the layout of rounds 2-3: the headline workload at top level)
+    return (w.get(kname) if w else None), pmc
+
+
+def label_bound(roof, t, dur_ms, peak_mix, alg_bytes):
+    """`bound` follows the counters of THIS workload on THIS build, or is null: the three fractions of the dominant kernel side by side at top level."""
+    roof["frac_algorithmic"] = roof.get("frac")
+    roof["frac_hbm_counter"] = roof["frac_valu"] = None
+    if not t:
+        roof["bound"] = None
+        roof["bound_evidence"] = "no counter pass of this workload on this build (scripts/pmc.sh <tag> <key> <bench args>): the label is withheld rather than defaulted"
+        return
+    traffic = 2 * t["FETCH_SIZE_KB"] * 1024 + t["WRITE_SIZE_KB"] * 1024
+    roof["traffic"] = round(traffic)
+    roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch, separate run)"
+    hb = traffic / (dur_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    roof["hbm_counter"] = {"bytes_per_launch": round(traffic), "achieved": round(traffic / (dur_ms * 1e-3) / 1e9, 2), "frac": round(hb, 5),
+                           "counter_over_algorithmic": round(traffic / max(1.0, alg_bytes), 4)}
+    roof["frac_hbm_counter"] = round(hb, 5)
+    if t.get("INSTS_VALU") and peak_mix:
+        roof["frac_valu"] = round(t["INSTS_VALU"] / (dur_ms * 1e-3) / peak_mix, 4)
+        roof["bound"] = "valu" if roof["frac_valu"] > hb else "hbm"
+        roof["bound_evidence"] = (f"VALU issue at {roof['frac_valu']:.2f} of the ceiling measured in this run vs HBM at {hb:.3f} of 8 TB/s (counter bytes of this workload); "
+                                  "no MFMA on this path; frac / frac_algorithmic count per-lane touches that L1 / L2 mostly serve")
+    else:
+        roof["bound"] = None
+        roof["bound_evidence"] = "HBM counters present, VALU counters or ceiling missing"
+
+
 def di_only_roofline(r, abi, st, W, H, first_timed, n_count, ms_per_step):
     """config 2: the direct stage is the whole step.  Algorithmic bytes as for the headline line; the launch time is the step time (one launch per step)."""
     r.set_counting(True)
@@ -66,9 +111,18 @@ def di_only_roofline(r, abi, st, W, H, first_timed, n_count, ms_per_step):
     b_screen = SCREEN_BYTES[0] * W * H
     b_trav = (c2.nodesVisited * NODE_B + c2.trisTested * TRI_B + c2.hitsShaded * HIT_B + c2.risCandidates * RIS_B) / float(n_count)
     ach = (b_screen + b_trav) / (ms_per_step * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "direct_stage", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+    roof = {"bound": None, "kernel": "direct_stage", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
             "algorithmic_bytes_per_launch": round(b_screen + b_trav), "screen_bytes": round(b_screen), "traversal_bytes": round(b_trav), "launch_ms": round(ms_per_step, 4),
-            "note": "launch_ms = wall clock per step (launch-to-launch, one direct-stage launch per step): a 512x512 launch is bound by launch rate and latency, not by bandwidth"}
+            "note": "launch_ms = wall clock per step (launch-to-launch, one direct-stage launch per step): a 512x512 launch is bound by launch rate and latency, not by bandwidth "
+                    "(a 36-triangle scene never leaves the caches: `frac` counts per-lane touches, not bytes that crossed the fabric)"}
+    t, _ = pmc_entry("config2", "k_direct_stage")
+    peak = None
+    try:
+        peak = r.measure_valu_peak(0, 8)
+    except Exception:
+        pass
+    label_bound(roof, t, ms_per_step, peak, b_screen + b_trav)
+    return roof
 
 
 def main():
@@ -318,31 +372,18 @@ def main():
         dur_ms = stage_ms[dom] / launches
         achieved = (b_screen + b_trav) / (dur_ms * 1e-3) / 1e9
         kname = {0: "k_direct_stage", 1: "k_indirect_stage", 2: "k_denoise_lds<false, true>", 3: "k_denoise_lds<true, true>", 4: "k_compose"}[dom]
-        out["roofline"] = {"bound": "hbm", "kernel": STAGE_NAMES[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        out["roofline"] = {"bound": None, "kernel": STAGE_NAMES[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                            "algorithmic_bytes_per_launch": round(b_screen + b_trav), "screen_bytes": round(b_screen), "traversal_bytes": round(b_trav),
                            "launch_ms": round(dur_ms, 4), "stage_ms_per_frame": {STAGE_NAMES[i]: round(stage_ms[i], 4) for i in range(5)},
                            "note": "achieved / frac: ALGORITHMIC bytes (per-lane node / triangle / hit / candidate touches x SURVEY 8(d) sizes + screen traffic) "
                                    "over the launch time in the timed region; most of those touches are served by L1 / L2 — `hbm_counter` is what crossed the fabric"}
-        # HBM traffic of the same kernel from the PMC passes (scripts/pmc.sh: separate rocprofv3 --pmc runs of this command;
-        # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950's FETCH_SIZE counts wide reads at half their size — MI355X_MICROARCH.md,
-        # HBM section — so it is doubled; WRITE_SIZE is taken as reported).  The file is refreshed with the profiles.
-        t = None
-        try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as fh:
-                pmc = json.load(fh)
-            t = pmc.get(kname)
-            # the counters were collected on ONE build of the library: a different build makes them history, not measurement
-            out["roofline"]["traffic_lib"] = pmc.get("_lib_sha256_16")
-            out["roofline"]["traffic_stale"] = pmc.get("_lib_sha256_16") != lib_sha256_16()
-            if t and (args.config != 4 or orbit):
-                t = None          # collected on the static config-4 frame only
-            if t:
-                traffic = 2 * t["FETCH_SIZE_KB"] * 1024 + t["WRITE_SIZE_KB"] * 1024
-                out["roofline"]["traffic"] = round(traffic)
-                out["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch, separate run)"
-        except (OSError, ValueError, KeyError):
-            pmc = None
+        # HBM traffic and VALU instructions of the same kernel from the PMC passes of THIS workload (scripts/pmc.sh: separate rocprofv3 --pmc runs of this
+        # command; FETCH_SIZE / WRITE_SIZE are in KiB; gfx950's FETCH_SIZE counts wide reads at half their size — MI355X_MICROARCH.md, HBM section — so it is
+        # doubled; WRITE_SIZE is taken as reported).  Counters of another build or another workload are not used: the label is then null.
+        t, pmc = pmc_entry(workload_key(args.config, orbit), kname)
+        out["roofline"]["traffic_lib"] = pmc.get("_lib_sha256_16") if pmc else None
+        out["roofline"]["traffic_stale"] = bool(pmc) and pmc.get("_lib_sha256_16") != lib_sha256_16()
         sdur = None
         if serial_ms is not None:  # same kernel, same bytes, launched alone (no other frame's kernels beside it)
             sdur = serial_ms[dom] / launches
@@ -350,15 +391,10 @@ def main():
                                          "frac": round((b_screen + b_trav) / (sdur * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                                          "stage_ms_per_frame": {STAGE_NAMES[i]: round(serial_ms[i], 4) for i in range(5)},
                                          "frame_ms": round(sum(serial_ms), 4)}
-        if out["roofline"]["traffic"]:
-            tr = out["roofline"]["traffic"]
-            out["roofline"]["hbm_counter"] = {"bytes_per_launch": tr, "achieved": round(tr / (dur_ms * 1e-3) / 1e9, 2), "frac": round(tr / (dur_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                                              "counter_over_algorithmic": round(tr / (b_screen + b_trav), 4)}
-            if sdur:
-                out["roofline"]["hbm_counter"]["serial_frac"] = round(tr / (sdur * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
         # What the kernel is actually close to: VALU instruction issue.  The ceiling is MEASURED in this run on this device
         # (rt_measure_valu_peak, csrc/microbench.hip: a chain-free loop of the kernels' instruction mix, 8 waves per SIMD), the
         # kernel's wave-level instruction count comes from the same PMC passes (SQ_INSTS_VALU per launch).
+        peak_mix = None
         try:
             peak_mix = r.measure_valu_peak(0, 8)
             peak_fma = r.measure_valu_peak(1, 8)
@@ -372,17 +408,19 @@ def main():
                              "source": "profiles/pmc_traffic.json (SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU per launch)"})
                 if sdur:
                     valu["serial_frac"] = round(t["INSTS_VALU"] / (sdur * 1e-3) / peak_mix, 4)
-                fr = pmc.get("_frame") if pmc else None
+                w = (pmc.get("workloads", {}).get(workload_key(args.config, orbit)) or pmc) if pmc else None
+                fr = w.get("_frame") if w else None
                 if fr and args.emulate_world <= 1:
                     valu.update({"frame_wave_insts": round(fr["INSTS_VALU"]), "frame_frac": round(fr["INSTS_VALU"] / (out["ms_per_step"] * 1e-3) / peak_mix, 4)})
             out["roofline"]["valu"] = valu
-            # the label follows the evidence: whichever ceiling the launch is closer to
-            hb = out["roofline"].get("hbm_counter", {}).get("frac")
-            if valu.get("frac") is not None and hb is not None:
-                out["roofline"]["bound"] = "valu" if valu["frac"] > hb else "hbm"
-                out["roofline"]["bound_evidence"] = f"VALU issue at {valu['frac']:.2f} of the measured ceiling vs HBM at {hb:.3f} of 8 TB/s (counter bytes); no MFMA on this path"
         except Exception as e:  # the headline number must not depend on this extra pass
             out["roofline"]["valu"] = {"error": repr(e)}
+        label_bound(out["roofline"], t, dur_ms, peak_mix, b_screen + b_trav)
+        if t and sdur:
+            out["roofline"]["hbm_counter"]["serial_frac"] = round(out["roofline"]["traffic"] / (sdur * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+            if t.get("WRITE_SIZE_KB_full_lds_stack"):
+                out["roofline"]["hbm_counter"]["write_bytes"] = round(t["WRITE_SIZE_KB"] * 1024)
+                out["roofline"]["hbm_counter"]["write_bytes_with_whole_stack_in_lds"] = round(t["WRITE_SIZE_KB_full_lds_stack"] * 1024)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(abi, host, scene, env, st, desc, W, H, first_timed)
     if rank == 0 and frame is not None and out is not None and "roofline" not in out:
@@ -409,11 +447,12 @@ def main():
             b_screen = SCREEN_BYTES[0] * W * (y1 - y0)
             b_trav = cb.nodesVisited * NODE_B + cb.trisTested * TRI_B + cb.hitsShaded * HIT_B + cb.risCandidates * RIS_B
             ach = (b_screen + b_trav) / (dur_ms * 1e-3) / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "direct_stage (this rank's band, rows %d..%d, launched alone)" % (y0, y1), "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+            out["roofline"] = {"bound": None, "bound_evidence": "no counter pass exists for a row band; a band-sized launch is bound by the dependent steps of its slowest rays (DESIGN.md 7)",
+                               "kernel": "direct_stage (this rank's band, rows %d..%d, launched alone)" % (y0, y1), "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": round(b_screen + b_trav),
                                "screen_bytes": round(b_screen), "traversal_bytes": round(b_trav), "launch_ms": round(dur_ms, 4)}
         except Exception as e:  # the headline number must not depend on this extra pass
-            out["roofline"] = {"bound": "hbm", "error": repr(e)}
+            out["roofline"] = {"bound": None, "error": repr(e)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

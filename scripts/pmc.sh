@@ -1,48 +1,73 @@
 #!/bin/bash
-# PMC passes for the frame kernels (run on the GPU box): scripts/pmc.sh <tag>
-# Counters are collected in their own runs (no trace domains besides kernel dispatch), one group per pass.
-TAG=${1:-pmc}
+# PMC passes for the frame kernels (run on the GPU box): scripts/pmc.sh <tag> [<workload key> [bench.py arguments ...]]
+#   scripts/pmc.sh r04/pmc                              the headline workload (config 4, static camera)   -> key "config4"
+#   scripts/pmc.sh r04/pmc3 config3 --config 3          any other bench.py workload under its own key
+# Counters are collected in their own runs (no trace domains besides kernel dispatch), one group per pass, every pass under `timeout`.
+# The per-kernel figures go to <out>/summary.txt and are MERGED into profiles/pmc_traffic.json under workloads[<key>] (the file is stamped with the hash of the
+# library the counters were collected on; entries of another build are dropped).  bench.py reads the entry of the workload it runs.
+TAG=${1:-pmc}; KEY=${2:-config4}; shift; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-run() { rocprofv3 --pmc $2 --output-format csv -d $OUT -o $1 -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --profile-run > /dev/null 2>&1; }
-run sq1 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM"
-run sq2 "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_INST_LEVEL_VMEM SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
-run sq3 "SQ_LEVEL_WAVES SQ_CYCLES SQ_INSTS_BRANCH SQ_IFETCH SQ_INST_CYCLES_VMEM_RD SQ_LDS_IDX_ACTIVE"
-run tcc1 "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"
-run tcc2 "FETCH_SIZE"
-run tcc3 "WRITE_SIZE"
-python - <<PY
-import csv, glob, collections, os
+run() { local name=$1 ctrs=$2; shift; shift; env "$@" timeout 300 rocprofv3 --pmc $ctrs --output-format csv -d $OUT -o $name -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --profile-run $BENCH_ARGS > /dev/null 2>&1; }
+BENCH_ARGS="$*"
+run sq1 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM" X_=1
+run sq2 "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_INST_LEVEL_VMEM SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" X_=1
+run sq3 "SQ_LEVEL_WAVES SQ_CYCLES SQ_INSTS_BRANCH SQ_IFETCH SQ_INST_CYCLES_VMEM_RD SQ_LDS_IDX_ACTIVE" X_=1
+run sq4 "SQ_INSTS_VMEM_WR SQ_INSTS_VMEM SQ_INSTS_FLAT SQ_INSTS_SMEM" X_=1      # (scratch_ and global_ accesses are FLAT-encoded: SQ_INSTS_FLAT holds both)
+run tcc1 "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" X_=1
+run tcc2 "FETCH_SIZE" X_=1
+run tcc3 "WRITE_SIZE" X_=1
+# the same write counter with the WHOLE traversal stack in LDS (no HBM overflow area): the difference is what the short stacks of the frames in flight write
+run tcc3full "WRITE_SIZE" RESTIR_STACK_LDS=64
+python - "$KEY" "$BENCH_ARGS" <<PY
+import csv, glob, collections, os, sys, json, hashlib
 out = "$OUT"
+key, bench_args = sys.argv[1], sys.argv[2]
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.Counter()
 for f in glob.glob(out + "/*counter_collection.csv"):
+    full = "tcc3full" in os.path.basename(f)
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"].split("(")[0]
-        agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
-        calls[(k, row["Counter_Name"])] += 1
+        c = row["Counter_Name"] + ("_FULL_LDS_STACK" if full else "")
+        agg[k][c] += float(row["Counter_Value"])
+        calls[(k, c)] += 1
 with open(out + "/summary.txt", "w") as fo:
+    fo.write("workload: %s (bench.py %s)\n" % (key, bench_args))
     for k, d in sorted(agg.items()):
         if not k.startswith(("rt::", "void rt::")): continue
         fo.write(k + "\n")
         for c, v in sorted(d.items()):
-            fo.write("   %-28s %16.1f per launch (%d launches)\n" % (c, v / calls[(k, c)], calls[(k, c)]))
-import json
-def key(k):   # kernel name with its template arguments, without namespaces: k_denoise_lds<false, true>
+            fo.write("   %-36s %16.1f per launch (%d launches)\n" % (c, v / calls[(k, c)], calls[(k, c)]))
+def kname(k):   # kernel name with its template arguments, without namespaces: k_denoise_lds<false, true>
     k = k.replace("void ", "")
     head = k.split("<")[0]
     return head.split("::")[-1] + k[len(head):]
-traffic = {key(k): {"FETCH_SIZE_KB": d.get("FETCH_SIZE", 0) / max(1, calls[(k, "FETCH_SIZE")]),
-                                                              "WRITE_SIZE_KB": d.get("WRITE_SIZE", 0) / max(1, calls[(k, "WRITE_SIZE")]),
-                                                              "INSTS_VALU": d.get("SQ_INSTS_VALU", 0) / max(1, calls[(k, "SQ_INSTS_VALU")]),
-                                                              "THREAD_CYCLES_VALU": d.get("SQ_THREAD_CYCLES_VALU", 0) / max(1, calls[(k, "SQ_THREAD_CYCLES_VALU")])}
+def per(k, d, c): return d.get(c, 0) / max(1, calls[(k, c)])
+traffic = {kname(k): {"FETCH_SIZE_KB": per(k, d, "FETCH_SIZE"), "WRITE_SIZE_KB": per(k, d, "WRITE_SIZE"), "WRITE_SIZE_KB_full_lds_stack": per(k, d, "WRITE_SIZE_FULL_LDS_STACK"),
+                      "INSTS_VALU": per(k, d, "SQ_INSTS_VALU"), "THREAD_CYCLES_VALU": per(k, d, "SQ_THREAD_CYCLES_VALU"),
+                      "INSTS_VMEM_WR": per(k, d, "SQ_INSTS_VMEM_WR"), "INSTS_VMEM_RD": per(k, d, "SQ_INSTS_VMEM_RD"), "INSTS_FLAT": per(k, d, "SQ_INSTS_FLAT"),
+                      "WAIT_ANY": per(k, d, "SQ_WAIT_ANY"), "WAVE_CYCLES": per(k, d, "SQ_WAVE_CYCLES"),
+                      "L2_HIT": per(k, d, "TCC_HIT_sum"), "L2_REQ": per(k, d, "TCC_REQ_sum")}
            for k, d in agg.items() if k.startswith(("rt::", "void rt::")) and "_cnt::" not in k}   # not the instrumented (counting) variants
 frames = max(1, calls[("rt::base::k_direct_stage", "SQ_INSTS_VALU")])
 traffic["_frame"] = {"INSTS_VALU": sum(d.get("SQ_INSTS_VALU", 0) for k, d in agg.items() if k.startswith(("rt::base::", "void rt::base::"))) / frames,
                      "note": "sum over the kernels of one frame (count-free variants), SQ_INSTS_VALU per launch x launches per frame"}
-import hashlib
-lib = os.path.join(os.environ["GRAFT_REPO_ROOT"], "cis-565-final-vr-raytracer_amd", "csrc", "librestir_hip.so")
-traffic["_lib_sha256_16"] = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]   # bench.py marks these numbers stale for any other build
-json.dump(traffic, open(out + "/pmc_traffic.json", "w"), indent=1)
+traffic["_bench_args"] = bench_args
+root = os.environ["GRAFT_REPO_ROOT"]
+lib = os.path.join(root, "cis-565-final-vr-raytracer_amd", "csrc", "librestir_hip.so")
+sha = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]   # bench.py marks these numbers stale for any other build
+path = os.path.join(root, "profiles", "pmc_traffic.json")
+try:
+    allw = json.load(open(path))
+    if allw.get("_lib_sha256_16") != sha or "workloads" not in allw: allw = {}
+except (OSError, ValueError):
+    allw = {}
+allw.setdefault("workloads", {})[key] = traffic
+allw["_lib_sha256_16"] = sha
+if key == "config4":   # the headline workload also at top level (the layout rounds 2-3 committed)
+    for k, v in traffic.items(): allw[k] = v
+json.dump(allw, open(path, "w"), indent=1)
+json.dump(allw, open(out + "/pmc_traffic.json", "w"), indent=1)
 print(open(out + "/summary.txt").read())
 PY
