@@ -83,12 +83,7 @@ struct DevFrame {
   int32_t histRow0, histRow1;
   uint32_t* histMiss;
   int32_t stackLds;                 // traversal stack entries per lane kept in LDS by this frame's traced launches (0 = the whole stack); the rest sits in DevScene::stackOvf
-  // Hybrid direct stage (round 4): the tiles of a LARGE launch that took longest in the last frame run on the latency build (eight lanes per ray) beside the
-  // throughput launch of all the others.  tileCost: wave time of the tile's last throughput-build run (cycles, decayed while the tile is on the latency
-  // build); tileHeavy: this frame's flags; heavyList[0] = number of heavy tiles, [1..] their global tile indices (tile row * tilesX + tile column).
-  int32_t hybrid;                   // 0: plain launch; 1: the throughput kernel skips flagged tiles; 2: the latency kernel runs the listed tiles
-  uint32_t* tileCost; uint8_t* tileHeavy; uint32_t* heavyList;
-  int32_t heavyCap; int32_t pad4;
+  int32_t pad4;
 };
 
 }  // namespace rt

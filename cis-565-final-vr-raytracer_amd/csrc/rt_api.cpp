@@ -26,8 +26,6 @@ struct rt_ctx {
   hipStream_t sideStream = nullptr;           // direct A-Trous runs here, concurrently with the indirect stage
   hipStream_t indStream = nullptr;            // overlap 2: the indirect stage of frame f runs here, next to direct(f+1) on `stream`
   hipEvent_t evFork = nullptr, evJoin = nullptr;
-  hipStream_t auxStream = nullptr;            // hybrid direct stage: the latency-build launch of the heavy tiles runs here, beside the throughput launch
-  hipEvent_t evHybFork = nullptr, evHybJoin = nullptr;
   // overlap 2 (frames in flight): ring of per-frame dependency events — direct done / indirect done / frame done
   hipEvent_t evD[4] = {}, evI[4] = {}, evDone[4] = {};
   uint64_t seq = 0;          // frames submitted through the pipelined path since the last join
@@ -92,7 +90,6 @@ static hipError_t syncAll(rt_ctx* c)
   hipError_t e = hipStreamSynchronize(c->stream);
   if(e == hipSuccess && c->indStream) e = hipStreamSynchronize(c->indStream);
   if(e == hipSuccess && c->sideStream) e = hipStreamSynchronize(c->sideStream);
-  if(e == hipSuccess && c->auxStream) e = hipStreamSynchronize(c->auxStream);
   c->inFlight = false; c->seq = 0;
   return e;
 }
@@ -337,9 +334,6 @@ int rt_destroy(rt_ctx* c)
   if(c->sideStream) (void)hipStreamDestroy(c->sideStream);
   if(c->evFork) (void)hipEventDestroy(c->evFork);
   if(c->evJoin) (void)hipEventDestroy(c->evJoin);
-  if(c->auxStream) (void)hipStreamDestroy(c->auxStream);
-  if(c->evHybFork) (void)hipEventDestroy(c->evHybFork);
-  if(c->evHybJoin) (void)hipEventDestroy(c->evHybJoin);
   delete c;
   if(g_liveCtx.fetch_sub(1) == 1) { std::lock_guard<std::mutex> one(g_accelMutex); g_accelCache.reset(); }   // the last context takes the cached host build with it
   return RT_OK;
@@ -629,11 +623,6 @@ int rt_resize(rt_ctx* c, int w, int h)
   RT_SCRATCH(postRowSums, size_t(h) * 6, double); RT_SCRATCH(postMean, 8, float);
   RT_SCRATCH(postMipD, n + 64, float4); RT_SCRATCH(postMipI, n + 64, float4);   // levels 1..7 (n/3 texels; up to n for one-pixel-wide images)
   RT_SCRATCH(tileOrder, (size_t(w / 2 + 7) / 8) * (size_t(h / 2 + 7) / 8 + 16 * 2) + 64 + 4096, uint32_t);   // 8 per-XCD lists: tiles + one chunk of slack each
-  {  // hybrid direct stage: per-tile cost, flags, list of heavy tiles (at most an eighth of the tiles)
-    const size_t nt = (size_t(w + 7) / 8) * (size_t(h + 7) / 8);
-    X.heavyCap = int32_t(std::max<size_t>(64, nt / 8));
-    RT_SCRATCH(tileCost, nt + 64, uint32_t); RT_SCRATCH(tileHeavy, nt + 64, uint8_t); RT_SCRATCH(heavyList, size_t(X.heavyCap) + 1, uint32_t);
-  }
 #if RT_WAVEPROF
   RT_SCRATCH(waveProf, WAVEPROF_RECORDS * 16, uint32_t);
 #endif
@@ -689,45 +678,6 @@ static hipError_t ensureOverlapStreams(rt_ctx* c)
   return e;
 }
 
-// ---- hybrid direct stage (round 4) ---------------------------------------------------------------------------------------------------------------------
-// A launch above the RT_TRAVERSAL_AUTO threshold runs on the throughput build, whose slowest tiles (rays grazing the street through foliage) set its tail: a
-// node round costs ~3000 cycles there against ~1100 on the latency build.  The hybrid gives the tail to the latency build: the tiles whose wave took longest
-// in the LAST frame (k_direct_classify: above the (100 - pct) percentile and above twice the mean) run eight lanes per ray on an auxiliary stream, beside the
-// throughput launch of all the others.  Same per-pixel code on the same pixels: the frame is bit-identical whatever the selection (a selection made from
-// stale or missing costs only costs time).  RESTIR_HYBRID_PCT (per cent of the launch's tiles, default 0 = off until measured), RESTIR_HYBRID_MIN_TILES.
-static float hybridPct() { static const float v = getenv("RESTIR_HYBRID_PCT") ? float(atof(getenv("RESTIR_HYBRID_PCT"))) : 0.0f; return v; }
-static int hybridMinTiles() { static const int v = getenv("RESTIR_HYBRID_MIN_TILES") ? atoi(getenv("RESTIR_HYBRID_MIN_TILES")) : 2048; return v; }
-static hipError_t launchStageAuto(rt_ctx* c, hipStream_t strm, const DevFrame& F0, const rt_state& st, int stage, int level, int rowBegin, int rowEnd)
-{
-  const StageLauncher L = stageLauncher(c, st, stage, rowBegin, rowEnd);
-  const bool thr = L == rt::base::launchStage || L == rt::sky::launchStage;
-  const int r1 = (rowEnd <= 0 || rowEnd > st.size.y) ? st.size.y : rowEnd, r0 = std::max(0, rowBegin);
-  const long tiles = long((st.size.x + 7) / 8) * long((std::max(0, r1 - r0) + 7) / 8);
-  if(!(stage == RT_STAGE_DIRECT && thr && c->traversal == RT_TRAVERSAL_AUTO && hybridPct() > 0.0f && level != 2 && tiles >= hybridMinTiles() && F0.tileCost))
-    return L(strm, c->ds, F0, st, c->cam, stage, level, rowBegin, rowEnd);
-  if(!c->auxStream) {
-    hipError_t e = hipStreamCreateWithFlags(&c->auxStream, hipStreamNonBlocking);
-    if(e == hipSuccess) e = hipEventCreateWithFlags(&c->evHybFork, hipEventDisableTiming);
-    if(e == hipSuccess) e = hipEventCreateWithFlags(&c->evHybJoin, hipEventDisableTiming);
-    if(e != hipSuccess) return e;
-  }
-  const bool sky = c->ds.sky != nullptr;
-  const bool spatial = st.ReSTIRState == RT_RESTIR_SPATIAL || st.ReSTIRState == RT_RESTIR_SPATIOTEMPORAL;
-  DevFrame F = F0;
-  hipError_t e = (sky ? rt::sky::launchDirectClassify : rt::base::launchDirectClassify)(strm, F, st, r0, r1, int(hybridPct() * 10.0f));
-  if(e != hipSuccess) return e;
-  if((e = hipEventRecord(c->evHybFork, strm)) != hipSuccess) return e;
-  if((e = hipStreamWaitEvent(c->auxStream, c->evHybFork, 0)) != hipSuccess) return e;
-  F.hybrid = 2;   // heavy tiles: latency build, auxiliary stream (issued first: they are the long ones)
-  if((e = (sky ? rt::sky_lat::launchStage : rt::base_lat::launchStage)(c->auxStream, c->ds, F, st, c->cam, RT_STAGE_DIRECT, spatial ? 1 : 0, r0, r1)) != hipSuccess) return e;
-  if((e = hipEventRecord(c->evHybJoin, c->auxStream)) != hipSuccess) return e;
-  F.hybrid = 1;   // everything else: throughput build
-  if((e = L(strm, c->ds, F, st, c->cam, RT_STAGE_DIRECT, spatial ? 1 : 0, r0, r1)) != hipSuccess) return e;
-  if((e = hipStreamWaitEvent(strm, c->evHybJoin, 0)) != hipSuccess) return e;
-  if(spatial && level == 0) e = L(strm, c->ds, F0, st, c->cam, RT_STAGE_DIRECT, 2, r0, r1);   // the merge pass needs every tile's cached reservoir
-  return e;
-}
-
 static DevFrame makeFrame(rt_ctx* c, int frames)
 {
   selectFrame(c, frames);
@@ -752,7 +702,6 @@ static DevFrame makeFrame(rt_ctx* c, int frames)
   F.surf = X.surf; F.status = X.status; F.qcount = X.qcount; F.waveProf = X.waveProf;
   F.histRow0 = c->histRow0; F.histRow1 = c->histRow1; F.histMiss = X.qcount + 250;
   F.geomN = X.geomN; F.geomP = X.geomP; F.geomNh = X.geomNh; F.geomPh = X.geomPh; F.tileOrder = X.tileOrder; F.postRowSums = X.postRowSums; F.postMean = X.postMean;
-  F.tileCost = X.tileCost; F.tileHeavy = X.tileHeavy; F.heavyList = X.heavyList; F.heavyCap = X.heavyCap; F.hybrid = 0;
   return F;
 }
 
@@ -782,7 +731,7 @@ int rt_run_stage(rt_ctx* c, const rt_state* st, int frames, int stage, int level
   DevFrame F = makeFrame(c, frames);
   if(stage == RT_STAGE_INDIRECT) F.histMiss = c->scratch.qcount + 251;  // per-stage-kind flag (rt_history_miss_stage)
   // (stage kinds share no scratch: a caller may spread them over several streams, tiled.PipelinedTiledFrame does)
-  const hipError_t e = launchStageAuto(c, c->stream, F, *st, stage, level, rowBegin, rowEnd);
+  const hipError_t e = stageLauncher(c, *st, stage, rowBegin, rowEnd)(c->stream, c->ds, F, *st, c->cam, stage, level, rowBegin, rowEnd);
   if(e == hipErrorInvalidValue) return fail(c, RT_ERR_INVALID_ARG, "rt_run_stage: level out of range for this stage (RT_STAGE_DIRECT levels 1 / 2 exist in the spatial modes only)");
   if(e == hipErrorInvalidConfiguration) return fail(c, RT_ERR_HIP, "rt_run_stage: the traversal-stack overflow area is missing or too small for this launch (internal sizing error)");
   RT_HIP(c, e);
@@ -815,7 +764,7 @@ int rt_render_frame(rt_ctx* c, const rt_state* st, int frames)
   const DevFrame F = makeFrame(c, frames);
   int k = 0, lastMain = 0, lastSide = 0, lastInd = 0;
   auto run = [&](hipStream_t strm, int stage, int level) -> int {
-    hipError_t e = launchStageAuto(c, strm, F, *st, stage, level, 0, 0);
+    hipError_t e = stageLauncher(c, *st, stage, 0, 0)(strm, c->ds, F, *st, c->cam, stage, level, 0, 0);
     if(e != hipSuccess) { c->err = std::string("launchStage: ") + hipGetErrorString(e); return RT_ERR_HIP; }
     e = hipEventRecord(E.ev[k], strm);
     if(e != hipSuccess) { c->err = std::string("hipEventRecord: ") + hipGetErrorString(e); return RT_ERR_HIP; }

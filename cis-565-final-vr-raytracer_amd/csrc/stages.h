@@ -12,10 +12,6 @@ constexpr int STACK_MAX = 64;  // LDS traversal stack entries per lane (8 B each
   hipError_t launchStage(hipStream_t stream, const DevScene& S, const DevFrame& F, const rt_state& st, const rt_scene_camera& cam, int stage, int level, \
                          int rowBegin, int rowEnd);                                                                                                     \
   }
-#define RT_DECL_CLASSIFY(ns) namespace ns { hipError_t launchDirectClassify(hipStream_t stream, const DevFrame& F, const rt_state& st, int rowBegin, int rowEnd, int pctX10); }
-RT_DECL_CLASSIFY(base)
-RT_DECL_CLASSIFY(sky)
-#undef RT_DECL_CLASSIFY
 RT_DECL_LAUNCH(base)
 RT_DECL_LAUNCH(sky)
 RT_DECL_LAUNCH(base_cnt)

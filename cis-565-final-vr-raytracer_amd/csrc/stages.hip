@@ -211,13 +211,7 @@ RT_DEV void groupTrace(const DevScene& S, const WideLds& L, TravCounters& tc)
 __global__ __launch_bounds__(512, RT_LAT_DIRECT_WAVES) void k_direct_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY)
 {
   extern __shared__ uint2 s_stack[];
-  TileCoord tile;
-  if(F.hybrid == 2) {   // the heavy tiles of a large launch (rt_api.cpp launchDirectHybrid): one workgroup per list entry
-    if(blockIdx.x >= F.heavyList[0]) return;
-    const uint32_t gt = F.heavyList[1 + blockIdx.x];
-    tile.y = int(gt / uint32_t(tilesX)) - (rowBegin >> 3); tile.x = int(gt % uint32_t(tilesX)); tile.valid = true;
-    if(threadIdx.x == 0) F.tileCost[gt] -= F.tileCost[gt] >> 3;   // not re-measured here (another kernel, other cycles): the cost decays until the tile is measured again
-  } else tile = tileOf(tilesX, tilesY);
+  const TileCoord tile = tileOf(tilesX, tilesY);
   if(!tile.valid) return;
   const int wave = int(threadIdx.x) >> 6, lane = int(threadIdx.x) & 63;
   const WideLds L = wideLds(s_stack, S.stackEntries, int(blockDim.x) >> 6);
@@ -290,9 +284,6 @@ __global__ __launch_bounds__(64, RT_DIRECT_LB) void k_direct_stage(DevScene S, D
   const TileCoord tile = tileOf(tilesX, tilesY);
   if(!tile.valid) return;
   const int lane = int(threadIdx.x);
-  const uint32_t gt = uint32_t((rowBegin >> 3) + tile.y) * uint32_t(tilesX) + uint32_t(tile.x);
-  if(F.hybrid == 1 && F.tileHeavy[gt]) return;   // runs on the latency build beside this launch
-  const uint64_t hyb_t0 = F.hybrid ? clock64() : 0ull;
   const i2 px{tile.x * 8 + (lane & 7), rowBegin + tile.y * 8 + (lane >> 3)};
   if(px.x >= st.size.x || px.y >= rowEnd) return;
 
@@ -308,45 +299,9 @@ __global__ __launch_bounds__(64, RT_DIRECT_LB) void k_direct_stage(DevScene S, D
   const bool occluded = wantShadow && c.AnyHit(shadowRay, shadowDist);
   directPost(c, F, st, cam, px, K, occluded);
   flushCounters(F, c);
-  if(F.hybrid && lane == int(__ffsll((long long)__ballot(1))) - 1) F.tileCost[gt] = uint32_t(min((unsigned long long)(clock64() - hyb_t0), 0xffffffffull));   // the wave's time: next frame's cost of this tile
 #if RT_WAVEPROF
   waveProfFlush(F, c, tile.x, tile.y, prof_c0, prof_w0);
 #endif
-}
-
-// Which tiles of the launch go to the latency build: the ones whose last-frame cost lies above the (100 - pct) percentile AND above twice the mean — a launch
-// without a tail (sky, a uniform wall) keeps every tile on the throughput build.  One workgroup; 256-bucket histogram of cost / max.
-__global__ __launch_bounds__(1024) void k_direct_classify(DevFrame F, int tile0, int nTiles, int pctX10)
-{
-  __shared__ uint32_t s_hist[256];
-  __shared__ uint32_t s_max, s_cut, s_n;
-  __shared__ unsigned long long s_sum;
-  const int t = int(threadIdx.x);
-  if(t < 256) s_hist[t] = 0u;
-  if(t == 0) { s_max = 1u; s_n = 0u; s_sum = 0ull; }
-  __syncthreads();
-  uint32_t mx = 0u; unsigned long long sm = 0ull;
-  for(int i = t; i < nTiles; i += 1024) { const uint32_t c = F.tileCost[tile0 + i]; mx = max(mx, c); sm += c; }
-  atomicMax(&s_max, mx); atomicAdd(&s_sum, sm);
-  __syncthreads();
-  const float scale = 255.0f / float(s_max);
-  for(int i = t; i < nTiles; i += 1024) atomicAdd(&s_hist[min(255, int(float(F.tileCost[tile0 + i]) * scale))], 1u);
-  __syncthreads();
-  if(t == 0) {
-    const uint32_t target = min(uint32_t(F.heavyCap), uint32_t((long long)nTiles * pctX10 / 1000));
-    const uint32_t floorBucket = uint32_t(min(255.0f, 2.0f * float(s_sum / (unsigned long long)max(1, nTiles)) * scale));
-    uint32_t acc = 0u; int b = 255;
-    for(; b > int(floorBucket); b--) { if(acc + s_hist[b] > target) break; acc += s_hist[b]; }
-    s_cut = uint32_t(b);   // heavy: bucket > cut
-  }
-  __syncthreads();
-  for(int i = t; i < nTiles; i += 1024) {
-    const bool heavy = uint32_t(min(255, int(float(F.tileCost[tile0 + i]) * scale))) > s_cut;
-    F.tileHeavy[tile0 + i] = heavy ? 1 : 0;
-    if(heavy) { const uint32_t k = atomicAdd(&s_n, 1u); if(k < uint32_t(F.heavyCap)) F.heavyList[1 + k] = uint32_t(tile0 + i); else F.tileHeavy[tile0 + i] = 0; }
-  }
-  __syncthreads();
-  if(t == 0) F.heavyList[0] = min(s_n, uint32_t(F.heavyCap));
 }
 #endif
 
@@ -1235,16 +1190,6 @@ static void launchDenoiseLevel(hipStream_t stream, const DevFrame& F, const rt_s
 }
 #endif
 
-#if !RT_LAT
-// heavy-tile selection for the hybrid direct stage (rt_api.cpp launchDirectHybrid): rows [rowBegin, rowEnd) of the full-resolution tile grid
-hipError_t launchDirectClassify(hipStream_t stream, const DevFrame& F, const rt_state& st, int rowBegin, int rowEnd, int pctX10)
-{
-  const int tilesX = (st.size.x + 7) / 8, tilesY = (rowEnd - rowBegin + 7) / 8;
-  hipLaunchKernelGGL(k_direct_classify, dim3(1), dim3(1024), 0, stream, F, (rowBegin >> 3) * tilesX, tilesX * tilesY, pctX10);
-  return hipGetLastError();
-}
-#endif
-
 hipError_t launchStage(hipStream_t stream, const DevScene& Sin, const DevFrame& F, const rt_state& st, const rt_scene_camera& cam, int stage, int level,
                        int rowBegin, int rowEnd)
 {
@@ -1280,7 +1225,7 @@ hipError_t launchStage(hipStream_t stream, const DevScene& Sin, const DevFrame& 
       // (row-tiled multi-GPU frames with spatial reuse): 0 = the whole stage, 1 = k_direct_stage only, 2 = k_direct_spatial only
       if(level < 0 || level > 2 || (level != 0 && !spatial)) return hipErrorInvalidValue;
 #if RT_LAT
-      if(level != 2) hipLaunchKernelGGL(k_direct_stage, F.hybrid == 2 ? dim3(unsigned(F.heavyCap)) : grid, dim3(64 * nWaves), wideLdsBytes(S.stackEntries, nWaves), stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY);
+      if(level != 2) hipLaunchKernelGGL(k_direct_stage, grid, dim3(64 * nWaves), wideLdsBytes(S.stackEntries, nWaves), stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY);
       if(level != 1 && spatial) return rt::RT_FORWARD::launchStage(stream, Sin, F, st, cam, stage, 2, rowBegin, rowEnd);
 #else
       if(needOvf && grid.x * 64u > S.stackOvfThreads) return hipErrorInvalidConfiguration;   // overflow area missing / too small: an internal sizing error, not the caller's
