@@ -604,8 +604,18 @@ def emulate_world(args, abi, host, scene, env, st, desc, single, W, H, device):
     n = args.emulate_world
     single.update(W, H)
     scene.updateCamera(W, H)
+    orbit = args.moving_camera or CONFIGS[args.config].get("orbit", False)
+    eye0, center0, up0, fov0 = scene.cameraPose()
+
+    def pose(sc, f):   # SURVEY 8(d) config 5 / --moving-camera: the camera orbits its centre of interest, 0.5 degrees per frame (same path as the N = 1 line)
+        if orbit:
+            a = np.deg2rad(0.5 * (f + 1))
+            rot = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], dtype=np.float32)
+            sc.setCamera(center0 + rot @ (eye0 - center0), center0, up0, fov0)
+
     def cam(f):
         st.time = 1000 + f
+        pose(scene, f)
         scene.updateCamera(W, H)
         return scene.getCamera()
     # single-GPU references on the same frames: serial sum of kernels and the frames-in-flight rate
@@ -629,13 +639,14 @@ def emulate_world(args, abi, host, scene, env, st, desc, single, W, H, device):
     m = MultiGpuRenderer().setup([device] * n)
     m.load_scene(desc); m.update(W, H)
     m.set_serialize(True); m.set_balance(0 if args.equal_bands else 1)
-    scene2 = host.Scene().makeProcedural(abi.PROC_BISTRO_EXT, args.scale, 1)
+    scene2 = host.Scene().makeProcedural(getattr(abi, CONFIGS[args.config]["kind"]), args.scale, 1)   # (a second instance: its camera history is the tiled run's own)
     scene2.updateCamera(W, H)
     acc = np.zeros((n, 2)); halo = 0; kinds = np.zeros(6); bands = None
     f = 0
     def frame():
         nonlocal f
         st.time = 1000 + f
+        pose(scene2, f)
         scene2.updateCamera(W, H)
         m.set_camera(scene2.getCamera()); m.run(st, f)
         f += 1
