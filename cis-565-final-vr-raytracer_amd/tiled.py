@@ -53,11 +53,12 @@ class Halo:
     rank's band from the ranks that own them.  inner: rows closer than this to the band are NOT part of the item (an outer ring); even: even rows only;
     width: only the first `width` bytes of a row (the half-resolution temporaries live in full-size allocations).  Strided / partial items travel through a
     packed staging tensor (a send / recv needs contiguous memory)."""
-    __slots__ = ("tensor", "pitch", "part", "halo", "limit", "inner", "even", "width")
+    __slots__ = ("tensor", "pitch", "part", "halo", "limit", "inner", "even", "width", "kind")
 
-    def __init__(self, tensor, pitch, part, halo, limit, inner=0, even=False, width=None):
+    def __init__(self, tensor, pitch, part, halo, limit, inner=0, even=False, width=None, kind=None):
         self.tensor, self.pitch, self.part, self.halo, self.limit = tensor, pitch, part, halo, limit
         self.inner, self.even, self.width = inner, even, (None if width is None or width >= pitch else int(width))
+        self.kind = kind   # accounting purpose of this item (HALO_KINDS); None: the exchange's
 
     def need(self, r):
         """row segments rank r needs: [(lo, hi)] above and below its band"""
@@ -207,7 +208,7 @@ class TorchComm:
                 v = self._view(item, a, b) if b > a else None
                 if v is None:
                     continue
-                self.rx_bytes[kind] += item.nbytes(a, b)
+                self.rx_bytes[item.kind or kind] += item.nbytes(a, b)
                 if P2P is None:
                     continue                                 # CountingComm: the accounting is all there is
                 if packed:
@@ -621,12 +622,12 @@ class PipelinedTiledFrame(TiledFrame):
             items = self._gbuffer_halo(g, gp, hh) if state.denoise > 0 else [Halo(g, gp, self.part, hh, self.H)]
             for buf in (abi.BUF_DIRECT_RESV0 + cur, abi.BUF_LIGHT_ID0 + cur):
                 t, p = self._t(buf)
-                items.append(Halo(t, p, self.part, hh, self.H))
-            self._wD_prev = self._wD
-            self._wD = [c.halo_exchange(items, async_op=True, kind="history" if state.denoise == 0 else "filter")]
+                items.append(Halo(t, p, self.part, hh, self.H, kind="history"))
             if state.denoise > 0:
                 dcol, _ = self._t(abi.BUF_DIRECT_RESULT0 + cur)
-                self._wD.append(c.halo_exchange([Halo(dcol, self.W * _COLOR_BYTES, self.part, HALO_DIRECT_COLOR, self.H)], async_op=True, kind="filter"))
+                items.append(Halo(dcol, self.W * _COLOR_BYTES, self.part, HALO_DIRECT_COLOR, self.H))
+            self._wD_prev = self._wD
+            self._wD = c.halo_exchange(items, async_op=True, kind="history" if state.denoise == 0 else "filter")   # ONE batched send / recv per exchange
             self._record(("D", f))
         # ---- 3. indirect(f) on the ind stream -----------------------------------------------------------------------------------
         with self._stream("ind"):
@@ -663,11 +664,11 @@ class PipelinedTiledFrame(TiledFrame):
             if not self._validated:
                 self._validate_indirect(state, f)
             t, p = self._t(abi.BUF_INDIRECT_RESV0 + cur)
-            self._wI = [c.halo_exchange([Halo(t, p, self.parth, self._halo // 2, self.Hh)], async_op=True, kind="history")]
+            items = [Halo(t, p, self.parth, self._halo // 2, self.Hh, kind="history")]
             if state.denoise > 0:
                 icol = self._icol(f)
-                self._wI.append(c.halo_exchange([Halo(icol, self.W * _COLOR_BYTES, self.parth, HALO_INDIRECT_COLOR, self.Hh, width=(self.W // 2) * _COLOR_BYTES)],
-                                                async_op=True, kind="filter"))
+                items.append(Halo(icol, self.W * _COLOR_BYTES, self.parth, HALO_INDIRECT_COLOR, self.Hh, width=(self.W // 2) * _COLOR_BYTES))
+            self._wI = c.halo_exchange(items, async_op=True, kind="filter")
             self._record(("Ix", f))
         with self._stream("side"):
             self._wait_ev(("Ix", f)); self._wait_ev(("I", f))
