@@ -47,7 +47,8 @@ struct DevScene {
   // overflow part of the traversal stacks: (stackTotal - stackEntries) entries per thread of a launch, thread = blockIdx.x * blockDim.x + threadIdx.x.
   // Two areas, because a direct-kind and an indirect-kind kernel can be in flight together; the launchers point stackOvf at the one of their stage.
   uint2* stackOvf; uint2* stackOvfInd;
-  uint32_t stackOvfThreads; uint32_t pad3;
+  uint32_t stackOvfThreads;
+  int32_t gangMax;                  // latency build: at most this many live rays in a wave whose pool is dry -> its idle ray slots work for them (traverse.h gangTail); 0 = off
 };
 
 // per-pixel scratch record (internal; never crosses the ABI)

@@ -111,13 +111,22 @@ typedef hipError_t (*StageLauncher)(hipStream_t, const DevScene&, const DevFrame
 // a row band of a multi-GPU frame or a small image is bound by the dependent steps of its slowest rays, and the latency build shortens the step).
 // RT_TRAVERSAL_AUTO decides by the number of 8x8 tiles of the launch; the thresholds are where the two builds measured equal on the benchmark scene
 // (profiles/r03_band_chunk_ab.txt, profiles/r03_lat_wide_ab.txt):
-//   launches that run alone (rt_set_overlap 0/1; the barrier schedule of rt_mgpu): direct stage up to 1440 tiles (48 rows of 1080p), indirect stage up to
-//     1536 half-res tiles (~200 rows of 1080p);
+//   launches that run alone (rt_set_overlap 0/1; the barrier schedule of rt_mgpu): direct stage up to 2000 tiles (64 rows of 1080p), indirect stage up to
+//     2000 half-res tiles (256 rows of 1080p) — round 4, with gang mode in the latency build (round 3: 1440 / 1536; gpurun_out/r04_band_thresholds.txt);
 //   launches that share the CUs with the kernels of another frame (rt_set_overlap 2; frames in flight in rt_mgpu): 512 / 640 — eight lanes per ray buy a
 //     short chain with 2-4x the lane-cycles, which a co-running kernel would have used.
 // The counting build is a throughput build.  Bit-identical either way.  RESTIR_LAT_TILES / RESTIR_LAT_TILES_IND override both cases (experiments).
-static int latTilesDirect(bool shared) { static const int v = getenv("RESTIR_LAT_TILES") ? atoi(getenv("RESTIR_LAT_TILES")) : -1; return v >= 0 ? v : (shared ? 512 : 1440); }
-static int latTilesIndirect(bool shared) { static const int v = getenv("RESTIR_LAT_TILES_IND") ? atoi(getenv("RESTIR_LAT_TILES_IND")) : -1; return v >= 0 ? v : (shared ? 640 : 1536); }
+static int envInt(const char* name) { const char* e = getenv(name); return e ? atoi(e) : -1; }
+static int latTilesDirect(bool shared)
+{
+  static const int alone = envInt("RESTIR_LAT_TILES"), sh = envInt("RESTIR_LAT_TILES_SHARED");
+  return shared ? (sh >= 0 ? sh : (alone >= 0 ? alone : 512)) : (alone >= 0 ? alone : 2000);
+}
+static int latTilesIndirect(bool shared)
+{
+  static const int alone = envInt("RESTIR_LAT_TILES_IND"), sh = envInt("RESTIR_LAT_TILES_IND_SHARED");
+  return shared ? (sh >= 0 ? sh : (alone >= 0 ? alone : 640)) : (alone >= 0 ? alone : 2000);
+}
 static StageLauncher stageLauncher(const rt_ctx* c, const rt_state& st, int stage, int rowBegin, int rowEnd)
 {
   bool lat = false;
@@ -571,6 +580,7 @@ int rt_build_accel(rt_ctx* c)
   c->ds.stackEntries = c->ds.stackTotal;   // the launchers shorten it per launch (DevFrame::stackLds)
   c->ds.triPad = bo.pad;
   { const char* e = getenv("RESTIR_COOP"); c->ds.coopLive = e ? std::max(0, std::min(64, atoi(e))) : 4; }
+  { const char* e = getenv("RESTIR_GANG"); c->ds.gangMax = e ? std::max(0, std::min(7, atoi(e))) : 4; }   // latency build: gang mode for the last rays of a wave (traverse.h)
   c->numNodes = bo.nodes.size(); c->numTris = bo.tris.size(); c->maxDepth = bo.maxDepth;
   RT_HIP(c, hipDeviceSynchronize());
   c->haveAccel = true;

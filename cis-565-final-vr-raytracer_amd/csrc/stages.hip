@@ -175,16 +175,17 @@ RT_DEV void directPost(Ctx& c, const DevFrame& F, const rt_state& st, const rt_s
 // ---- latency build: a workgroup of NW waves per 8x8 tile.  Wave 0 owns the 64 pixels (everything that is not traversal runs there, one lane per pixel,
 // exactly the code of the throughput build); rays go through the workgroup's LDS pool and every wave traces them eight lanes per ray (tracePoolWide).
 struct WideLds { uint2* stacks; float4* pool; unsigned char* list; uint32_t* ctrl; };   // ctrl: [0] rays listed, [1] cursor, [2] wave 0 has finished
+__host__ __device__ inline size_t wideWaveStride(int stackEntries) { return size_t(stackEntries) * WIDE_RAYS + GANG_BOX_UINT2; }   // per wave: 8 stack columns + the gang mailbox (uint2 units)
 RT_DEV WideLds wideLds(uint2* base, int stackEntries, int nWaves)
 {
   WideLds L;
   L.stacks = base;
-  L.pool = reinterpret_cast<float4*>(base + size_t(nWaves) * stackEntries * WIDE_RAYS);
+  L.pool = reinterpret_cast<float4*>(base + size_t(nWaves) * wideWaveStride(stackEntries));
   L.list = reinterpret_cast<unsigned char*>(L.pool + 128 * POOL_SLOT_F4);
   L.ctrl = reinterpret_cast<uint32_t*>(L.list + 128);
   return L;
 }
-inline size_t wideLdsBytes(int stackEntries, int nWaves) { return size_t(nWaves) * stackEntries * WIDE_RAYS * sizeof(uint2) + 128 * 32 + 128 + 16; }
+inline size_t wideLdsBytes(int stackEntries, int nWaves) { return size_t(nWaves) * wideWaveStride(stackEntries) * sizeof(uint2) + 128 * 32 + 128 + 16; }
 // wave 0, all 64 lanes: list the slots its lanes filled (slot 2 * lane: closest-hit ray, 2 * lane + 1: any-hit ray)
 RT_DEV void poolPublish(const WideLds& L, bool hasC, bool hasS)
 {
@@ -201,7 +202,7 @@ RT_DEV void groupTrace(const DevScene& S, const WideLds& L, TravCounters& tc)
 {
   __syncthreads();
   const int wave = int(threadIdx.x) >> 6;
-  tracePoolWide(S, L.pool, L.list, int(L.ctrl[0]), &L.ctrl[1], L.stacks + size_t(wave) * S.stackEntries * WIDE_RAYS, tc);
+  tracePoolWide(S, L.pool, L.list, int(L.ctrl[0]), &L.ctrl[1], L.stacks + size_t(wave) * wideWaveStride(S.stackEntries), tc);
   __syncthreads();
 }
 
@@ -720,7 +721,7 @@ __global__ __launch_bounds__(64, RT_INDIRECT_LB) void k_indirect_stage(DevScene 
     for(;;) {
       __syncthreads();
       if(WL.ctrl[2] != 0u) break;
-      tracePoolWide(S, WL.pool, WL.list, int(WL.ctrl[0]), &WL.ctrl[1], WL.stacks + size_t(int(threadIdx.x) >> 6) * S.stackEntries * WIDE_RAYS, htc);
+      tracePoolWide(S, WL.pool, WL.list, int(WL.ctrl[0]), &WL.ctrl[1], WL.stacks + size_t(int(threadIdx.x) >> 6) * wideWaveStride(S.stackEntries), htc);
       __syncthreads();
     }
     return;
@@ -1199,7 +1200,7 @@ hipError_t launchStage(hipStream_t stream, const DevScene& Sin, const DevFrame& 
 #endif
   DevScene S = Sin;
 #if RT_LAT
-  S.stackEntries = S.stackTotal;   // one column per RAY (8 per wave): the whole stack fits in LDS
+  S.stackEntries = S.stackTotal + (S.gangMax > 0 ? GANG_EXTRA : 0);   // one column per RAY (8 per wave): the whole stack fits in LDS (+ the room gang mode expands into)
   const int nwEnv = 8;   // waves per workgroup of the latency kernels (3 / 4 / 6 measured: slower, profiles/r03_band_chunk_ab.txt)
   const int nWaves = nwEnv;        // waves per tile workgroup
 #else

@@ -851,6 +851,153 @@ RT_DEV bool travRoundW(const DevScene& S, Trav& T, bool live, int j, uint2* stac
   return live && (travHasTris(T) || travHasNodes(T));
 }
 
+// ---- gang mode: the tail of a wave ------------------------------------------------------------------------------------------------------------------
+// When the pool is dry and a wave still holds a few long rays, its other ray slots idle while those rays walk on, one dependent step at a time: the tail of
+// a tile — and of a small launch — is the chain of its slowest ray (370 steps through the foliage of the benchmark scene).  In gang mode the idle groups of
+// the wave become WORKERS of the live rays: a ray's pending work lives entirely on its LDS stack column, every worker (the owner group included) takes a
+// DIFFERENT pending child of it per round — worker i the i-th nearest of the top two stack entries —, tests that node's eight children with its eight
+// lanes, pushes the hit group back and tests its node's leaf triangles itself; after a triangle round the workers of a ray merge their best hits through an
+// LDS mailbox (minimum over (t, id); any-hit: any accepted).  A round then advances a ray by up to eight nodes instead of one.  Verdicts are functions of
+// (ray, triangle), the closest hit a minimum over (t, id), boxes are only culled against hits already found: the result does not depend on the order the
+// nodes are visited in, so the frame is bit-identical with and without (tests: every latency-build parity case).  S.gangMax = 0 switches it off.
+constexpr int GANG_BOX_UINT2 = 16;   // per wave, behind its stacks: 8 x float4 mailbox
+constexpr int GANG_SCAN = 2;         // stack entries a round looks at for pending children
+constexpr int GANG_EXTRA = 20;       // stack entries per ray on top of the tree's own bound: the room parallel expansion may use
+RT_DEV uint32_t leaderBits(unsigned long long m) { return uint32_t(((m & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56); }   // lanes 0, 8, .., 56 -> bits 0..7
+RT_DEV int nthSetBitFromTop(uint32_t v, int n)   // position of the n-th (0 = highest) set bit of v; v has more than n bits set
+{
+  for(int k = 0; k < n; k++) v &= ~(1u << (31 - __clz(int(v))));
+  return 31 - __clz(int(v));
+}
+RT_DEV uint32_t dropTopBits(uint32_t v, int n) { for(int k = 0; k < n; k++) v &= ~(1u << (31 - __clz(int(v)))); return v; }
+
+// Runs the live rays of this wave to completion.  Every lane of the wave calls it (uniform); on entry `live` marks the owner groups, T their state.
+// Stack space: a ray's column holds S.stackEntries = S.stackTotal + GANG_EXTRA entries in the latency build.  Several children are expanded per round only while
+// the column has more than S.stackTotal entries to spare; beyond that one child per round is taken — plain depth-first order, which from any state needs at most
+// the tree's depth (< S.stackTotal) more entries — so the column cannot overflow.
+RT_DEV void gangTail(const DevScene& S, float4* pool, uint2* waveStack, Trav& T, bool& live, int mySlot, TravCounters& tc)
+{
+  const int lane = int(threadIdx.x) & 63, j = lane & (WIDE_G - 1), g = lane >> 3;
+  float4* gbox = reinterpret_cast<float4*>(waveStack + size_t(S.stackEntries) * WIDE_RAYS);
+  const int wideRoom = S.stackEntries - S.stackTotal;   // parallel expansion while sp + taken <= wideRoom
+  bool working = false;          // this group works on a ray (its own or an adopted one)
+  int og = g;                    // owner group of that ray = its stack column
+  uint32_t wm = 0u;              // groups that work on the same ray
+  uint32_t lastOwners = 0u;
+  for(;;) {
+    const uint32_t owners = leaderBits(__ballot(live ? 1 : 0));
+    if(owners == 0u) break;
+    if(owners != lastOwners) {
+      // ---- (re)assignment: owners keep their ray; the groups without work are dealt round-robin to the live rays and adopt the ray's state; groups that are
+      //      still busy with a ray (its owner lives) keep everything they hold -------------------------------------------------------------------------------
+      lastOwners = owners;
+      const int n = __popc(owners);
+      const bool mine = (owners >> g) & 1u;
+      const uint32_t freeM = leaderBits(__ballot((!working && !mine) ? 1 : 0));
+      const bool adopt = !working && !mine;
+      if(mine && !working) {   // first round of an owner: what is pending moves to the stack column (the workers share it); pending triangles stay with their worker
+        if(T.ngroup.y > 0x00FFFFFFu) { stackPushW(T, waveStack + g, T.ngroup, j); T.ngroup.y = 0u; }
+        og = g;
+      }
+      if(adopt) {
+        uint32_t o = owners;
+        for(int k = __popc(freeM & ((1u << g) - 1u)) % n; k > 0; k--) o &= o - 1u;
+        og = __ffs(int(o)) - 1;
+      }
+      waveLdsSync();
+      const int src = og * WIDE_G;
+      const int slot = __shfl(mySlot, src);
+      const int sp = __shfl(T.sp, src);
+      const float bt = __shfl(T.hit.t, src), bu = __shfl(T.hit.u, src), bv = __shfl(T.hit.v, src);
+      const uint32_t bg = uint32_t(__shfl(int(T.hit.gid), src));
+      const int any = __shfl(T.isAny ? 1 : 0, src);
+      if(adopt) {
+        const float4 a = pool[slot * POOL_SLOT_F4], b = pool[slot * POOL_SLOT_F4 + 1];
+        T.isAny = any != 0;
+        (void)travInit<2>(T, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), b.z, rt_f2u(b.w));
+        T.ngroup.y = 0u; T.tgroup.y = 0u;
+        T.sp = sp; T.hit.t = bt; T.hit.gid = bg; T.hit.u = bu; T.hit.v = bv;
+      }
+      working = true;
+      wm = 0u;
+#pragma unroll
+      for(int k = 0; k < WIDE_RAYS; k++) if(__builtin_amdgcn_readlane(og, k * WIDE_G) == og) wm |= 1u << k;
+    }
+    uint2* stack = waveStack + og;
+    // ---- triangle phase: every worker tests (up to eight of) the leaf triangles of ITS node ----------------------------------------------------------------
+    const bool hasTri = working && T.tgroup.y != 0u;
+    if(__ballot(hasTri ? 1 : 0) != 0ull) {
+      if(hasTri) travTriW<2>(S, T, j, tc);
+      if(j == 0) gbox[g] = make_float4(T.hit.t, rt_u2f(T.hit.gid), T.hit.u, T.hit.v);
+      waveLdsSync();
+      uint32_t rest = wm & ~(1u << g);
+      while(rest != 0u) {   // merge: the workers of a ray end up with the same best hit
+        const int k = __ffs(int(rest)) - 1; rest &= rest - 1u;
+        const float4 c = gbox[k];
+        const uint32_t cg = rt_f2u(c.y);
+        if(cg != 0xffffffffu && (T.hit.gid == 0xffffffffu || (!T.isAny && (c.x < T.hit.t || (c.x == T.hit.t && cg < T.hit.gid))))) { T.hit.t = c.x; T.hit.gid = cg; T.hit.u = c.z; T.hit.v = c.w; }
+      }
+      if(T.isAny && T.hit.gid != 0xffffffffu) { T.sp = 0; T.tgroup.y = 0u; T.ngroup.y = 0u; }   // first accepted hit terminates the query, for every worker
+      waveLdsSync();
+    }
+    // ---- node phase: the workers without pending triangles take the nearest pending children of their ray, one each ---------------------------------------
+    const bool wantNode = working && T.tgroup.y == 0u && T.sp > 0;
+    const uint32_t wantM = leaderBits(__ballot(wantNode ? 1 : 0)) & wm;
+    bool took = false; uint32_t child = 0u;
+    if(wantNode) {
+      // The ray's pending children, nearest first: the hit bits of its top GANG_SCAN stack entries, top entry first, high bit first.  Worker i takes the i-th.
+      // Entries above the deepest one touched are used up and dropped; that one is written back with its remaining bits (or dropped as well).
+      const int iw = __popc(wantM & ((1u << g) - 1u)), nw = __popc(wantM);
+      uint2 e[GANG_SCAN]; int cnt[GANG_SCAN]; int avail = 0;
+#pragma unroll
+      for(int k = 0; k < GANG_SCAN; k++) {
+        e[k] = make_uint2(0u, 0u);
+        if(T.sp > k) e[k] = stack[(T.sp - 1 - k) * WIDE_RAYS];
+        cnt[k] = __popc(e[k].y >> 24); avail += cnt[k];
+      }
+      int nsel = min(nw, avail);
+      if(T.sp + nsel > wideRoom) nsel = 1;
+      int before = 0, nsp = T.sp; bool wrote = false; uint2 back = make_uint2(0u, 0u); int backAt = 0;
+#pragma unroll
+      for(int k = 0; k < GANG_SCAN; k++) {
+        const int takeHere = max(0, min(cnt[k], nsel - before));   // children of entry k that are taken this round
+        if(iw >= before && iw < before + takeHere) {
+          took = true;
+          const int bit = nthSetBitFromTop(e[k].y & 0xFF000000u, iw - before);
+          const uint32_t slotI = uint32_t(bit - 24) ^ T.octinv;
+          child = e[k].x + uint32_t(__popc(e[k].y & ~(0xFFFFFFFFu << slotI) & 0xFFu));
+        }
+        if(takeHere > 0) {
+          const uint32_t h = dropTopBits(e[k].y & 0xFF000000u, takeHere) | (e[k].y & 0x00FFFFFFu);
+          if(h > 0x00FFFFFFu) { nsp = T.sp - k; wrote = true; back = make_uint2(e[k].x, h); backAt = T.sp - 1 - k; }   // partially used: stays (it is the deepest one touched)
+          else nsp = T.sp - 1 - k;
+        }
+        before += takeHere;
+      }
+      if(wrote && iw == 0 && j == 0) stack[backAt * WIDE_RAYS] = back;
+      T.sp = nsp;
+    }
+    waveLdsSync();
+    // (workers of the ray that sat this phase out — pending triangles — follow the stack pointer)
+    { const int sp2 = __shfl(T.sp, wantM != 0u ? (__ffs(int(wantM)) - 1) * WIDE_G : lane); if(working && !wantNode && wantM != 0u) T.sp = sp2; }   // (every lane takes part in the shuffle)
+    if(took) { const NodeRegs N = nodeLoad(S, child); travNodeTestW(T, N, j); }
+    const bool push = took && T.ngroup.y > 0x00FFFFFFu;
+    const uint32_t pushM = leaderBits(__ballot(push ? 1 : 0)) & wm;
+    if(working) {
+      if(push && j == 0) stack[(T.sp + __popc(pushM & ~((2u << g) - 1u))) * WIDE_RAYS] = T.ngroup;   // farthest first: the nearest group ends on top
+      T.sp += __popc(pushM);
+      T.ngroup.y = 0u;
+    }
+    waveLdsSync();
+    // ---- finished rays: the owner publishes the result, its workers are free for the next assignment -------------------------------------------------------
+    const uint32_t busyM = leaderBits(__ballot((working && (T.tgroup.y != 0u || T.sp > 0)) ? 1 : 0)) & wm;
+    if(working && busyM == 0u) {
+      if(live) { if(j == 0) pool[mySlot * POOL_SLOT_F4] = make_float4(T.hit.t, rt_u2f(T.hit.gid), T.hit.u, T.hit.v); live = false; }
+      working = false;
+    }
+  }
+}
+
 // ---- workgroup-wide ray pool ------------------------------------------------------------------------------------------------------------------------
 // Rays wait in LDS slots (poolPut: ray in, hit out, 32 B), `list` holds the n occupied slot ids (kind of the ray in bit 7: any-hit), *next is the shared cursor.
 // EVERY wave of the workgroup calls this between two workgroup barriers; a wave serves up to eight rays at a time and refills group by group.
@@ -887,6 +1034,10 @@ RT_DEV void tracePoolWide(const DevScene& S, float4* pool, const unsigned char* 
     if(liveMask == 0ull) {
       if(exhausted) break;
       continue;
+    }
+    if(exhausted && S.gangMax > 0 && __popcll(liveMask & leaders) <= S.gangMax && __popcll(liveMask & leaders) < WIDE_RAYS) {   // the tail: idle slots become workers of the live rays
+      gangTail(S, pool, waveStack, T, live, mySlot, tc);
+      break;
     }
 #if RT_WAVEPROF
     const uint64_t pc0 = clock64();

@@ -99,7 +99,9 @@ def test_regression_sliver_triangle():
 
 KNOBS = ["RESTIR_IND_SUB=0", "RESTIR_IND_SUB=1", "RESTIR_IND_SUB=2 RESTIR_COOP=64", "RESTIR_OVERLAP=0 RESTIR_COOP=0", "RESTIR_OVERLAP=1",
          # two LDS stack entries: nearly every ray keeps part of its traversal stack in the HBM overflow area
-         "RESTIR_STACK_LDS=2", "RESTIR_STACK_LDS=64"]
+         "RESTIR_STACK_LDS=2", "RESTIR_STACK_LDS=64",
+         # latency build: gang mode off / as soon as one ray slot of a wave idles (the sweep draws either traversal build per case)
+         "RESTIR_GANG=0", "RESTIR_GANG=7"]
 
 
 @pytest.mark.gpu
