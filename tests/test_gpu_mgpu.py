@@ -152,3 +152,28 @@ def test_mgpu_recovers_after_a_failed_call():
     for b in (abi.BUF_GBUFFER0, abi.BUF_DIRECT_RESV0, abi.BUF_DIRECT_RESULT0, abi.BUF_INDIRECT_RESULT0):
         assert np.array_equal(m.readback(b), ref.readback(b)), abi.BUFFER_NAMES[b]
     m.destroy(); ref.destroy()
+
+
+def test_native_and_rccl_hosts_plan_the_same_bytes():
+    """The two multi-GPU hosts share one schedule and one set of halo rules: what a rank of the native context really pulls per steady-state frame
+    — history rows and filter halos, counted by csrc/mgpu.cpp — is what the RCCL host's transport-free plan (restir_amd/tiled.py CountingComm) prices for the same
+    partition.  A rule changed in one host only fails here."""
+    from restir_amd import tiled
+    from restir_amd.renderer import MultiGpuRenderer
+    W, H, world = 960, 544, 4
+    part = [0, 144, 272, 416, 544]
+    sc, env = make_scene(abi.PROC_SPONZA, 0.01, 1, (128, 64))
+    st = host.default_state(W, H, sc, env)
+    m = MultiGpuRenderer().setup(_devices(world)); m.load_scene(sc.desc(env)); m.update(W, H)
+    m.set_bands(part)
+    sc.updateCamera(W, H)
+    for f in range(8):                                   # static camera: no fallback, no rows change owner
+        st.time = 300 + f; sc.updateCamera(W, H); m.set_camera(sc.getCamera()); m.run(st, f)
+    s = m.stats()
+    assert s.historyFallbacks == 0
+    for r in range(world):
+        want = tiled.steady_halo_bytes(W, H, world, r, part=part, pipelined=True)
+        got = {k: int(s.haloBytesRankKind[r][i]) for i, k in enumerate(tiled.HALO_KINDS)}
+        assert got["history"] == want["history"] and got["filter"] == want["filter"], (r, got, want)
+        assert got["moved"] == 0 and got["fallback"] == 0
+    m.destroy()
