@@ -174,6 +174,9 @@ def test_native_and_rccl_hosts_plan_the_same_bytes():
     for r in range(world):
         want = tiled.steady_halo_bytes(W, H, world, r, part=part, pipelined=True)
         got = {k: int(s.haloBytesRankKind[r][i]) for i, k in enumerate(tiled.HALO_KINDS)}
-        assert got["history"] == want["history"] and got["filter"] == want["filter"], (r, got, want)
+        # the G-buffer history rows: found in last frame's filter halo (the plan), or — when the look-ahead issued this frame's direct stage before that pull, and in
+        # the first frame after a pipeline restart — fetched by the direct stage itself: 16 rows x W x 16 B per neighbour more under "history"
+        own_g = 16 * W * 16 * ((r > 0) + (r < world - 1))
+        assert got["history"] in (want["history"], want["history"] + own_g) and got["filter"] == want["filter"], (r, got, want)
         assert got["moved"] == 0 and got["fallback"] == 0
     m.destroy()
