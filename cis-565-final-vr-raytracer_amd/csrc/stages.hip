@@ -1124,8 +1124,16 @@ __global__ __launch_bounds__(64) void k_denoise_lds(DevFrame F, rt_state st, con
 #pragma unroll
       for(int i = -2; i <= 2; i++) {
         float w;
-        if(i == 0 && j == 0)
+        if(i == 0 && j == 0) {
+          // the pixel with itself: every distance is x - x = 0 for finite inputs (NaN otherwise), every exponential exp(-0) = 1, the weight a constant — evaluated
+          // with the general expression's own float operations, in its order.  A wave with a non-finite pixel takes the general path (scalar branch).
+          const float dl = IND ? dot(color - color, color - color) : rt_abs(cC.w - cC.w);
+#ifndef RT_NO_CENTRE_SHORTCUT
+          if(__ballot((dl == 0.0f && dot(norm - norm, norm - norm) == 0.0f && dot(pos - pos, pos - pos) == 0.0f) ? 0 : 1) == 0ull) w = (((1.0f + 1e-2f) * 1.0f) * (1.0f + 1e-2f)) * kGauss[2][2];
+          else
+#endif
           w = denoisePairWeight<IND, FAST>(color, cC.w, norm, pos, color, cC.w, norm, pos, kGauss[2][2], sigLumin, sigNormal, sigDepth, yL, yN, yD);
+        }
         else if(j > 0 || (j == 0 && i > 0)) w = wf[fwdIndex(i, j)];
         else {
           const int k = fwdIndex(-i, -j), qx = ux + i, qy = uy + j;
