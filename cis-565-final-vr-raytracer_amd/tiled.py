@@ -102,6 +102,9 @@ class Pending:
             return
         self.comm._wait_works(self.works)
         for dst, src in self.unpack:
+            if self.comm.nccl:
+                src.record_stream(self.comm.torch.cuda.current_stream())   # staged on the posting stream, read here on the consumer's: the allocator must not
+                                                                           # hand the block out again before this copy has run
             dst.copy_(src)
         if self.comm.nccl and (self.works or self.unpack):   # a later wait on another stream orders that stream after transfer + unpacking
             self.event = self.comm.torch.cuda.Event(); self.event.record(self.comm.torch.cuda.current_stream())
