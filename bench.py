@@ -325,6 +325,9 @@ def main():
                               "median over the frames of a separate pass; frame_latency_ms = first launch to last launch of one frame while frames are in flight")
         if sustained:
             out["sustained"] = sustained
+        if frame is not None:   # what rank 0 received for the last timed frame, by purpose (restir_amd/tiled.py accounting), and the exact fallbacks of the run
+            out["halo_bytes_rank0"] = dict(frame.halo_bytes)
+            out["history_fallbacks"] = int(frame.history_fallbacks)
     if world == 1 and di_only and not args.profile_run:
         out["roofline"], out["cpu_baseline"] = di_only_roofline(r, abi, st, W, H, first_timed, n_count, elapsed / args.steps * 1e3), None
         if not args.no_cpu_baseline:
