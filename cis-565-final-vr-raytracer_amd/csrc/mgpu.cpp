@@ -134,6 +134,9 @@ struct rt_mgpu {
   int W = 0, H = 0;
   std::vector<int> bands, prevBands;   // n + 1 row boundaries (multiples of 16, last = H)
   std::vector<float> stripeCost;       // smoothed cost per 16-row stripe
+  std::vector<float> rankMs;           // smoothed time per rank (diffusion phase of the balancer)
+  std::vector<int> boundaryCool;       // per rank: frames until its measured time belongs to its new band
+  int balanceFrames = 0;               // frames balanced since the partition was last reset
   bool haveHistory = false, balance = true, serialize = false, gatherResults = true, pipeline = true;
   int solo = -1;
   std::vector<uint8_t> peerOk;         // [puller rank * n + owner rank]: direct peer access from the puller's device to the owner's is enabled (rt_mgpu_create)
@@ -757,8 +760,32 @@ void rebalance(rt_mgpu* M)
     for(int s = a; s < b; s++) M->stripeCost[size_t(s)] = 0.5f * M->stripeCost[size_t(s)] + 0.5f * per;
   }
   if(!M->balance || n == 1) return;
+  // Two phases.  The first frames plan from the per-stripe cost model (a rank's time spread over its stripes): coarse, fast.  A rank's time is not the sum of its
+  // stripes' costs, though — a band that holds horizon rows takes what its slowest tile takes however few rows it has — so the model settles with the slowest rank
+  // 1.35x the fastest.  From then on the boundaries DIFFUSE: a boundary moves one stripe towards the slower of its two ranks when their smoothed times differ
+  // by more than 6 %; the two ranks it separates are then re-measured on their new bands before either of their boundaries moves again.
+  const int MODEL_FRAMES = 10, HOLD = 6;   // HOLD: frames until a rank's measured time belongs to its new band (the frames-in-flight schedule harvests timings 3 frames late)
+  if(int(M->rankMs.size()) != n) { M->rankMs.assign(size_t(n), 0.f); M->boundaryCool.assign(size_t(n), 0); M->balanceFrames = 0; }
+  std::vector<int>& hold = M->boundaryCool;   // per RANK: frames its band still has to be re-measured
+  for(int r = 0; r < n; r++) {
+    const float t = M->ranks[size_t(r)].tracedMs + M->ranks[size_t(r)].filterMs;
+    if(hold[size_t(r)] > 0) { if(--hold[size_t(r)] == 0) M->rankMs[size_t(r)] = t; }
+    else M->rankMs[size_t(r)] = M->rankMs[size_t(r)] > 0.f ? 0.5f * M->rankMs[size_t(r)] + 0.5f * t : t;
+  }
   std::vector<int> nb(size_t(n) + 1, 0);
-  rt_mgpu_plan_bands(M->H, n, M->stripeCost.data(), M->bands.data(), 2, nb.data());
+  if(M->balanceFrames++ < MODEL_FRAMES) {
+    rt_mgpu_plan_bands(M->H, n, M->stripeCost.data(), M->bands.data(), 2, nb.data());
+    if(nb != M->bands) for(int r = 0; r < n; r++) hold[size_t(r)] = HOLD;
+    M->bands = nb;
+    return;
+  }
+  nb = M->bands;
+  for(int k = 1; k < n; k++) {
+    if(hold[size_t(k) - 1] > 0 || hold[size_t(k)] > 0) continue;
+    const float a = M->rankMs[size_t(k) - 1], b = M->rankMs[size_t(k)];
+    if(a > b * 1.06f && nb[size_t(k)] - nb[size_t(k) - 1] > 16) { nb[size_t(k)] -= 16; hold[size_t(k) - 1] = hold[size_t(k)] = HOLD; }
+    else if(b > a * 1.06f && nb[size_t(k) + 1] - nb[size_t(k)] > 16) { nb[size_t(k)] += 16; hold[size_t(k) - 1] = hold[size_t(k)] = HOLD; }
+  }
   M->bands = nb;
 }
 
@@ -897,7 +924,7 @@ int rt_mgpu_resize(rt_mgpu* M, int w, int h)
   const int rc = dispatch(M, Cmd::RESIZE);
   equalBands(M);
   M->prevBands = M->bands;
-  M->stripeCost.clear();
+  M->stripeCost.clear(); M->rankMs.clear();
   M->haveHistory = false;
   for(Rank& R : M->ranks) for(auto& g : R.gptr) g = nullptr;
   return rc;
