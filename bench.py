@@ -703,6 +703,22 @@ def emulate_world(args, abi, host, scene, env, st, desc, single, W, H, device):
             m.set_solo(-1); m.set_bands(cur)
             for _ in range(3):
                 frame()      # the rows that moved travel with the history pulls
+        # ... then the boundaries diffuse (the rule of csrc/mgpu.cpp rebalance()): one stripe towards the slower of two neighbours whose periods differ by > 5 %
+        for rnd in range(0 if os.environ.get("RESTIR_EMULATE_RANKS") else 2 * args.period_rounds):
+            per = [solo_period(r, max(40, args.steps)) for r in range(n)]
+            history.append({"bands": cur, "period_ms": [round(float(x), 3) for x in per]})
+            nxt = list(cur)
+            for k in range(1, n):
+                if per[k - 1] > per[k] * 1.05 and nxt[k] - nxt[k - 1] > 16:
+                    nxt[k] -= 16
+                elif per[k] > per[k - 1] * 1.05 and nxt[k + 1] - nxt[k] > 16:
+                    nxt[k] += 16
+            if nxt == cur:
+                break
+            cur = nxt
+            m.set_solo(-1); m.set_bands(cur)
+            for _ in range(3):
+                frame()
         if history:
             # the re-planning is a noisy fixed-point iteration: measure the last plan as well and keep the best partition seen
             per = [solo_period(r, max(40, args.steps)) for r in range(n)]
