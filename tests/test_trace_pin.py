@@ -22,7 +22,7 @@ T_EPS = 2e-5        # two candidates closer than this (relative to t) may be res
 # triangle head on, unbounded for a ray that skims it.  BAND_K error bounds make the "uncertain" band; everything outside it must agree exactly.
 BAND_K = 16.0
 EPS32 = 2.0 ** -23
-RAYS = int(os.environ.get("RESTIR_PIN_RAYS", "100000"))
+RAYS = int(os.environ.get("RESTIR_PIN_RAYS", "50000"))   # per scene; RESTIR_PIN_RAYS=100000 was the default until round 4 (CPU suite time)
 
 
 def _arr(ptr, ctype, count):
