@@ -3,5 +3,5 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-fuzz}; mkdir -p $O
 cd $R
 C1=${2:-400}; C2=${3:-120}; SEED=${4:-31}
-RESTIR_FUZZ_CASES=$C1 RESTIR_FUZZ_SEED=$SEED timeout 2400 python -m pytest tests/test_gpu_fuzz.py -m gpu -x -q -k random_configurations > $O/gpu_fuzz.log 2>&1; echo "gpu fuzz ($C1 cases, seed $SEED) exit $?"; tail -2 $O/gpu_fuzz.log
-timeout 2400 python scripts/mgpu_fuzz.py $C2 $SEED > $O/mgpu_fuzz.log 2>&1; echo "mgpu fuzz exit $?"; grep -c MISMATCH $O/mgpu_fuzz.log; tail -1 $O/mgpu_fuzz.log
+RESTIR_FUZZ_CASES=$C1 RESTIR_FUZZ_SEED=$SEED timeout ${FUZZ_TIMEOUT:-2400} python -m pytest tests/test_gpu_fuzz.py -m gpu -x -q -k random_configurations > $O/gpu_fuzz.log 2>&1; echo "gpu fuzz ($C1 cases, seed $SEED) exit $?"; tail -2 $O/gpu_fuzz.log
+timeout ${FUZZ_TIMEOUT:-2400} python scripts/mgpu_fuzz.py $C2 $SEED > $O/mgpu_fuzz.log 2>&1; echo "mgpu fuzz exit $?"; grep -c MISMATCH $O/mgpu_fuzz.log; tail -1 $O/mgpu_fuzz.log
