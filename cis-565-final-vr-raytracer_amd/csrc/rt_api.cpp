@@ -112,7 +112,7 @@ typedef hipError_t (*StageLauncher)(hipStream_t, const DevScene&, const DevFrame
 // RT_TRAVERSAL_AUTO decides by the number of 8x8 tiles of the launch; the thresholds are where the two builds measured equal on the benchmark scene
 // (profiles/r03_band_chunk_ab.txt, profiles/r03_lat_wide_ab.txt):
 //   launches that run alone (rt_set_overlap 0/1; the barrier schedule of rt_mgpu): direct stage up to 2000 tiles (64 rows of 1080p), indirect stage up to
-//     2000 half-res tiles (256 rows of 1080p) — round 4, with gang mode in the latency build (round 3: 1440 / 1536; gpurun_out/r04_band_thresholds.txt);
+//     2000 half-res tiles (256 rows of 1080p) — round 4, with gang mode in the latency build (round 3: 1440 / 1536; profiles/r04_band_thresholds.txt, profiles/r04_gang_ab.txt);
 //   launches that share the CUs with the kernels of another frame (rt_set_overlap 2; frames in flight in rt_mgpu): 512 / 640 — eight lanes per ray buy a
 //     short chain with 2-4x the lane-cycles, which a co-running kernel would have used.
 // The counting build is a throughput build.  Bit-identical either way.  RESTIR_LAT_TILES / RESTIR_LAT_TILES_IND override both cases (experiments).
