@@ -140,6 +140,8 @@ def main():
     ap.add_argument("--emulate-world", type=int, default=0, help="(1 GPU) N ranks of the native row-tiled frame (rt_mgpu_*) on this device, taking turns: per-rank stage times of a chip to itself")
     ap.add_argument("--equal-bands", action="store_true", help="N > 1 (and --emulate-world): equal-height row bands instead of cost-weighted ones")
     ap.add_argument("--band-rounds", type=int, default=8, help="N > 1: planning rounds of the cost-weighted band heights before the warm-up")
+    ap.add_argument("--diffuse-rounds", type=int, default=10, help="N > 1: after the cost-model rounds the band boundaries diffuse one 16-row stripe per round towards the slower "
+                                                                  "neighbour (restir_amd/tiled.py diffuse_bands); the best partition seen is kept")
     ap.add_argument("--no-period", action="store_true", help="--emulate-world: skip the frames-in-flight period pass")
     ap.add_argument("--period-rounds", type=int, default=4, help="--emulate-world: re-planning rounds of the band heights on the measured per-rank periods")
     ap.add_argument("--native", action="store_true", help="N > 1: ONE process drives the N devices through the native context (rt_mgpu_*, csrc/mgpu.cpp: frames in flight per rank, "
@@ -244,7 +246,10 @@ def main():
         # frames, every rank times its band's two traced stages launched alone, the times are gathered, the boundaries move}.  The
         # partition is then fixed: nothing of this runs in the warm-up or in the timed region.
         tstream = torch.cuda.Stream()
-        for _ in range(args.band_rounds):
+
+        def band_ms():
+            """two real frames on the current partition, then this rank's two traced stages launched alone on its band (ms per pair)"""
+            nonlocal f
             for _k in range(2):
                 step(f); f += 1
             fence()
@@ -258,7 +263,29 @@ def main():
             e1.record(tstream); torch.cuda.synchronize()
             r.history_miss()                                   # the re-runs may have raised the flag again: clear it
             r.set_stream(stream.cuda_stream)
-            band_plan = frame.rebalance(e0.elapsed_time(e1) / 2.0, smoothing=0.6, max_move=6)
+            return e0.elapsed_time(e1) / 2.0
+
+        for _ in range(args.band_rounds):
+            band_plan = frame.rebalance(band_ms(), smoothing=0.6, max_move=6)
+        # A band's time is not the sum of its stripes' costs (a band with horizon rows takes what its slowest tile takes): the cost model settles with the
+        # slowest rank ~1.35x the fastest.  From there the boundaries diffuse, one stripe per round; the partition with the shortest slowest rank is kept.
+        seen = []
+        for _ in range(args.diffuse_rounds if args.band_rounds > 0 else 0):
+            ms = band_ms()
+            worst = max(a[0] for a in frame.comm.all_gather_floats([ms]))   # (the same gathered numbers on every rank)
+            seen.append((worst, list(frame.part)))
+            new, _spread = frame.diffuse(ms)
+            band_plan = new
+            if new == seen[-1][1]:
+                break
+        if seen:
+            ms = band_ms()
+            worst = max(a[0] for a in frame.comm.all_gather_floats([ms]))
+            seen.append((worst, list(frame.part)))
+            best = min(seen, key=lambda t: t[0])[1]
+            if best != list(frame.part):
+                frame.set_partition(best)
+            band_plan = best
         fence()
     for _ in range(args.warmup):
         step(f); f += 1
@@ -604,6 +631,7 @@ def emulate_world(args, abi, host, scene, env, st, desc, single, W, H, device):
     Exchanges run as device-to-device copies: their volume is reported per purpose and priced with the xGMI model above.  NOT a benchmark result — the
     driver measures real scaling; this is the load-balance / critical-path instrument DESIGN.md §7 quotes."""
     from restir_amd.renderer import MultiGpuRenderer
+    from restir_amd.tiled import diffuse_bands
     n = args.emulate_world
     single.update(W, H)
     scene.updateCamera(W, H)
@@ -703,16 +731,12 @@ def emulate_world(args, abi, host, scene, env, st, desc, single, W, H, device):
             m.set_solo(-1); m.set_bands(cur)
             for _ in range(3):
                 frame()      # the rows that moved travel with the history pulls
-        # ... then the boundaries diffuse (the rule of csrc/mgpu.cpp rebalance()): one stripe towards the slower of two neighbours whose periods differ by > 5 %
+        # ... then the boundaries diffuse (restir_amd/tiled.py diffuse_bands = the rule of csrc/mgpu.cpp rebalance()): one stripe towards the slower of two neighbours whose
+        # periods differ by > 6 %, the slowest rank's boundaries first
         for rnd in range(0 if os.environ.get("RESTIR_EMULATE_RANKS") else 2 * args.period_rounds):
             per = [solo_period(r, max(40, args.steps)) for r in range(n)]
             history.append({"bands": cur, "period_ms": [round(float(x), 3) for x in per]})
-            nxt = list(cur)
-            for k in range(1, n):
-                if per[k - 1] > per[k] * 1.05 and nxt[k] - nxt[k - 1] > 16:
-                    nxt[k] -= 16
-                elif per[k] > per[k - 1] * 1.05 and nxt[k + 1] - nxt[k] > 16:
-                    nxt[k] += 16
+            nxt = diffuse_bands(cur, per)
             if nxt == cur:
                 break
             cur = nxt

@@ -780,11 +780,19 @@ void rebalance(rt_mgpu* M)
     return;
   }
   nb = M->bands;
+  // the boundaries of the slowest ranks go first (then the larger imbalance): scanning top to bottom would let an upper boundary that keeps moving starve the one below it
+  std::vector<std::pair<std::pair<float, float>, int>> cand;
   for(int k = 1; k < n; k++) {
+    const float a = std::max(1e-9f, M->rankMs[size_t(k) - 1]), b = std::max(1e-9f, M->rankMs[size_t(k)]);
+    if(std::max(a, b) > std::min(a, b) * 1.06f) cand.push_back({{-std::max(a, b), -std::max(a, b) / std::min(a, b)}, k});
+  }
+  std::sort(cand.begin(), cand.end());
+  for(const auto& c : cand) {
+    const int k = c.second;
     if(hold[size_t(k) - 1] > 0 || hold[size_t(k)] > 0) continue;
     const float a = M->rankMs[size_t(k) - 1], b = M->rankMs[size_t(k)];
-    if(a > b * 1.06f && nb[size_t(k)] - nb[size_t(k) - 1] > 16) { nb[size_t(k)] -= 16; hold[size_t(k) - 1] = hold[size_t(k)] = HOLD; }
-    else if(b > a * 1.06f && nb[size_t(k) + 1] - nb[size_t(k)] > 16) { nb[size_t(k)] += 16; hold[size_t(k) - 1] = hold[size_t(k)] = HOLD; }
+    if(a > b && nb[size_t(k)] - nb[size_t(k) - 1] > 16) { nb[size_t(k)] -= 16; hold[size_t(k) - 1] = hold[size_t(k)] = HOLD; }
+    else if(b > a && nb[size_t(k) + 1] - nb[size_t(k)] > 16) { nb[size_t(k)] += 16; hold[size_t(k) - 1] = hold[size_t(k)] = HOLD; }
   }
   M->bands = nb;
 }

@@ -158,6 +158,29 @@ def plan_bands(H, world, stripe_cost, prev=None, max_move=None):
     return [min(H, b * 16) for b in nb[:-1]] + [H]
 
 
+def diffuse_bands(part, rank_ms, tol=0.06):
+    """One diffusion step of the band boundaries (the second phase of csrc/mgpu.cpp rebalance()): a boundary moves one 16-row stripe towards the slower of
+    the two ranks it separates when their times differ by more than `tol`; a band keeps at least one stripe; a rank whose band changed in this step is
+    measured again before another of its boundaries moves, and the boundaries of the slowest ranks go first (then the larger imbalance).  A rank's time is not
+    the sum of its stripes' costs (a band that holds horizon rows takes what its slowest tile takes), so the cost model of plan_bands settles with the slowest
+    rank well above the fastest; from there the boundaries diffuse."""
+    nb, n = list(part), len(part) - 1
+    cand = []
+    for k in range(1, n):
+        a, b = max(1e-9, float(rank_ms[k - 1])), max(1e-9, float(rank_ms[k]))
+        if max(a, b) > min(a, b) * (1.0 + tol):
+            cand.append((-max(a, b), -max(a, b) / min(a, b), k))
+    touched = [False] * n
+    for _, _, k in sorted(cand):
+        if touched[k - 1] or touched[k]:
+            continue
+        if rank_ms[k - 1] > rank_ms[k] and nb[k] - nb[k - 1] > 16:
+            nb[k] -= 16; touched[k - 1] = touched[k] = True
+        elif rank_ms[k] > rank_ms[k - 1] and nb[k + 1] - nb[k] > 16:
+            nb[k] += 16; touched[k - 1] = touched[k] = True
+    return nb
+
+
 class LocalComm:
     """world == 1: every exchange is a no-op."""
     rank, world = 0, 1
@@ -420,6 +443,15 @@ class TiledFrame:
         if new != self.part:
             self.set_partition(new)
         return new
+
+    def diffuse(self, my_ms, tol=0.06):
+        """One diffusion step (diffuse_bands) on the gathered per-rank times, after the cost-model rounds of rebalance(); every rank computes the same
+        partition.  Returns (new partition, slowest / fastest of the gathered times)."""
+        allms = [max(1e-6, a[0]) for a in self.comm.all_gather_floats([float(my_ms)])]
+        new = diffuse_bands(self.part, allms, tol)
+        if new != self.part:
+            self.set_partition(new)
+        return new, max(allms) / min(allms)
 
     def _t(self, buf):
         return self.b.tensor(buf)

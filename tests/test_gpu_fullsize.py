@@ -133,7 +133,7 @@ class ThreadComm:
     def barrier(self): self.s["barrier"].wait()
 
 
-@pytest.mark.parametrize("mode", ["serial", "serial-fallbacks", "frames-in-flight", "frames-in-flight-fallbacks", "frames-in-flight-uneven", "frames-in-flight-rebalance", "frames-in-flight-spatial", "serial-spatial"])
+@pytest.mark.parametrize("mode", ["serial", "serial-fallbacks", "frames-in-flight", "frames-in-flight-fallbacks", "frames-in-flight-uneven", "frames-in-flight-rebalance", "frames-in-flight-diffuse", "frames-in-flight-spatial", "serial-spatial"])
 def test_tiled_three_ranks_equals_untiled(bistro, mode, monkeypatch):
     import torch
     from restir_amd import tiled
@@ -169,6 +169,8 @@ def test_tiled_three_ranks_equals_untiled(bistro, mode, monkeypatch):
                 st_r.time = 500 + f; rs[rank].set_camera(cams[f]); fr.render_frame(st_r, f)
                 if mode.endswith("rebalance") and f == 1:      # cost feedback in the middle of the sequence: the street rows cost 5x the sky rows
                     fr.rebalance(sum(5.0 if y >= 500 else 1.0 for y in range(fr.y0, fr.y1)), smoothing=1.0, max_move=8)
+                if mode.endswith("diffuse") and f >= 1:        # the diffusion phase of the balancer: a stripe per frame towards the slower neighbour
+                    fr.diffuse(sum(5.0 if y >= 500 else 1.0 for y in range(fr.y0, fr.y1)))
             fr.finish(); rs[rank].sync()
             parts[rank] = list(fr.part)
             fallbacks[rank] = fr.history_fallbacks
@@ -189,7 +191,7 @@ def test_tiled_three_ranks_equals_untiled(bistro, mode, monkeypatch):
         assert bad.size == 0, (abi.BUFFER_NAMES[b], "rows", int(bad.min()), int(bad.max()), int(bad.size))
     part = parts[0]; parth = tiled.half_partition(part, H)
     assert all(p == part for p in parts)
-    if mode.endswith("rebalance"): assert part != tiled.equal_partition(H, world)
+    if mode.endswith("rebalance") or mode.endswith("diffuse"): assert part != tiled.equal_partition(H, world)
     for b, elem, half in [(abi.BUF_GBUFFER0 + cur, 16, False), (abi.BUF_DIRECT_RESV0 + cur, 36, False), (abi.BUF_LIGHT_ID0 + cur, 4, False),
                           (abi.BUF_INDIRECT_RESV0 + cur, 76, True)]:
         want = ref.readback(b)

@@ -66,6 +66,8 @@ def _worker(rank, world, port, outdir, fast, pipelined=False, part=None, replan=
             frame.set_partition(REPLAN[world])
         if replan == 2:                # cost feedback: a synthetic cost of 1 per row, 9 per row below row 128 => bands shrink at the bottom
             frame.rebalance(sum(9.0 if y >= 128 else 1.0 for y in range(frame.y0, frame.y1)), smoothing=1.0, max_move=3)
+        if replan == 3:                # the diffusion phase: the same synthetic cost, one 16-row stripe per frame towards the slower neighbour
+            frame.diffuse(sum(9.0 if y >= 128 else 1.0 for y in range(frame.y0, frame.y1)))
     frame.finish()
     cur = (FRAMES - 1) & 1
     if rank == 0:   # both parities: the last frame and the one before it (whose second half was issued one call later)
@@ -123,12 +125,12 @@ def test_tiled_equals_untiled(world, fast, pipelined, tmp_path):
 
 
 @pytest.mark.parametrize("pipelined", [False, True], ids=["serial", "frames-in-flight"])
-@pytest.mark.parametrize("mode", ["uneven", "replan", "feedback"])
+@pytest.mark.parametrize("mode", ["uneven", "replan", "feedback", "diffuse"])
 @pytest.mark.parametrize("world", [2, 3])
 def test_uneven_partitions_equal_untiled(world, mode, pipelined, tmp_path):
     """cost-weighted band heights: a fixed uneven partition, and a switch of partition in the middle of a temporal sequence"""
     part = UNEVEN[world] if mode == "uneven" else None
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), False, pipelined, part, {"uneven": 0, "replan": 1, "feedback": 2}[mode]), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), False, pipelined, part, {"uneven": 0, "replan": 1, "feedback": 2, "diffuse": 3}[mode]), nprocs=world, join=True)
     got = np.load(os.path.join(tmp_path, f"tiled_{world}.npz"))
     sc, env, st, o = _setup()
     sc.updateCamera(W, H)
@@ -151,6 +153,10 @@ def test_uneven_partitions_equal_untiled(world, mode, pipelined, tmp_path):
             w, a, e = (W // 2, h0, h1) if half else (W, y0, y1)
             elem = _ELEM[name[:-1]]
             assert np.array_equal(band[name].reshape(-1, w * elem)[a:e], o.readback(b).reshape(-1, w * elem)[a:e]), (name, rank)
+    if mode == "diffuse":    # the last boundary moved down a stripe per frame (the bottom band is the expensive one) until the two times were within 6 %
+        from restir_amd import tiled
+        eq = tiled.equal_partition(H, world)
+        assert ends[-1] == H and eq[-2] < ends[-2] <= min(H - 16, eq[-2] + 16 * FRAMES) and ends[-2] % 16 == 0
     if mode == "feedback":   # the expensive bottom rows ended up in a shorter band than the equal split's
         from restir_amd import tiled
         eq = tiled.equal_partition(H, world)
@@ -256,3 +262,23 @@ def test_steady_halo_bytes_budget():
     # N = 2: one neighbour each
     b = tiled.steady_halo_bytes(1920, 1080, 2, 0)
     assert b["history"] + b["filter"] <= 7.5e6 and b["gather"] == 32 * 1920 * (1080 - 544)   # rank 0 also receives the other band of the two result images (display)
+
+
+def test_diffuse_bands_rule():
+    """tiled.diffuse_bands: one stripe towards the slower neighbour, only beyond the tolerance, a band keeps one stripe, and a rank whose band changed in this
+    step keeps its other boundary (it is measured again first), the slowest rank's boundaries go first — the rule of csrc/mgpu.cpp rebalance()'s second phase."""
+    from restir_amd import tiled
+    assert tiled.diffuse_bands([0, 64, 128], [1.0, 1.05]) == [0, 64, 128]                 # inside the tolerance
+    assert tiled.diffuse_bands([0, 64, 128], [1.0, 1.2]) == [0, 80, 128]                  # rank 1 slower: its band shrinks
+    assert tiled.diffuse_bands([0, 64, 128], [1.2, 1.0]) == [0, 48, 128]
+    assert tiled.diffuse_bands([0, 112, 128], [1.0, 2.0]) == [0, 112, 128]                # ... but never below one stripe
+    assert tiled.diffuse_bands([0, 64, 128, 192], [1.0, 2.0, 1.0]) == [0, 80, 128, 192]   # rank 1 changed at its upper boundary: the lower one waits
+    assert tiled.diffuse_bands([0, 64, 128, 192, 256], [1.0, 2.0, 1.0, 2.0]) == [0, 80, 128, 208, 256]
+    assert tiled.diffuse_bands([0, 80, 160, 208], [80.0, 336.0, 432.0]) == [0, 80, 176, 208]                          # the slowest rank's boundary goes first
+    # times that are a function of the band: repeated steps end in a small limit cycle around the balance point, never worse than where they started
+    def ms(part): return [sum(5.0 if y >= 512 else 1.0 for y in range(part[r], part[r + 1])) + (300.0 if part[r] <= 520 < part[r + 1] else 0.0) for r in range(len(part) - 1)]
+    part = tiled.equal_partition(1080, 4); start = max(ms(part)); best = start
+    for _ in range(40):
+        part = tiled.diffuse_bands(part, ms(part)); best = min(best, max(ms(part)))
+        assert part[0] == 0 and part[-1] == 1080 and all(b - a >= 16 and a % 16 == 0 for a, b in zip(part[:-1], part[1:-1] + [1088]))
+    assert best < 0.8 * start
