@@ -32,6 +32,7 @@ SCREEN_BYTES = {0: 124.0, 1: 204.0, 2: 192.0, 3: 240.0, 4: 68.0}
 # because it also carries the opacity micro-map, csrc/bvh8.h; the algorithmic figure stays the survey's), hit gathers, RIS candidate gathers
 NODE_B, TRI_B, HIT_B, RIS_B = 80, 48, 12 + 96 + 80, 16 + 96
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E
+DEFAULT_FOOTPRINT = "lite"
 
 
 # SURVEY.md 8(d) configurations 2-5 (config 1 is the CPU-only plumbing case: tests/test_oracle.py).  The real assets are absent from the image: seeded procedural
@@ -55,8 +56,34 @@ def lib_sha256_16():
         return hashlib.sha256(fh.read()).hexdigest()[:16]
 
 
-def workload_key(config, orbit):
-    return f"config{config}" + ("_moving" if orbit and config != 5 else "")
+REAL_KINDS = {4: "PROC_BISTRO_EXT_REAL", 3: "PROC_SPONZA_1K"}   # host/scene.hpp: the same classes with the reference's texture upload rules (full size, BGRA8, no mips)
+
+
+def scene_kind(abi, config, footprint):
+    """ProcScene of a configuration.  `real` (configs 3 and 4): the memory footprint of the asset the scene stands in for (config 4: 128 materials with 2k^2 texture
+    sets = 3.3 GB of texels, 16 distinct 1k^2 foliage cards, long thin triangles; config 3: SURVEY 8(d)'s 1k^2 textures); `lite`: the rounds 1-4 scenes (60 MB of 512^2
+    textures, one 256^2 cut-out — a working set that fits the Infinity Cache)."""
+    if footprint == "real" and config in REAL_KINDS:
+        return getattr(abi, REAL_KINDS[config])
+    return getattr(abi, CONFIGS[config]["kind"])
+
+
+def footprint_of(args):
+    return args.scene_footprint if args.config in REAL_KINDS else "lite"
+
+
+def workload_key(config, orbit, footprint="lite"):
+    return f"config{config}" + ("_moving" if orbit and config != 5 else "") + ("_real" if footprint == "real" and config in REAL_KINDS else "")
+
+
+def texture_bytes(desc):
+    """BGRA8 bytes of every image of the upload payload (rt_texture: pointer, width, height, ... = 32 B, include/rt_abi.h)"""
+    import ctypes
+    n = int(desc.numTextures)
+    if not desc.textures or n == 0:
+        return 0
+    t = np.frombuffer((ctypes.c_char * (n * 32)).from_address(desc.textures), dtype=np.dtype([("ptr", "<u8"), ("w", "<i4"), ("h", "<i4"), ("rest", "<i4", 4)]))
+    return int((t["w"].astype(np.int64) * t["h"] * 4).sum())
 
 
 def pmc_entry(key, kname):
@@ -132,6 +159,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", type=int, default=4, choices=[2, 3, 4, 5], help="BASELINE.json / SURVEY.md 8(d) configuration (4 = the headline workload)")
     ap.add_argument("--moving-camera", action="store_true", help="the camera orbits its centre of interest by 0.5 degrees per frame (always on for --config 5)")
+    ap.add_argument("--scene-footprint", choices=["lite", "real"], default=os.environ.get("RESTIR_SCENE_FOOTPRINT", DEFAULT_FOOTPRINT),
+                    help="configs 3 / 4: `real` = the texture / material / triangle-shape footprint of the asset the procedural scene stands in for (see scene_kind); "
+                         "`lite` = the cache-resident scenes of rounds 1-4")
     ap.add_argument("--scale", type=float, default=1.0, help="scene tessellation scale (1.0 = the configuration's triangle count)")
     ap.add_argument("--width", type=int, default=0, help="default: the configuration's width")
     ap.add_argument("--height", type=int, default=0)
@@ -187,7 +217,8 @@ def main():
     cfg = CONFIGS[args.config]
     W, H = args.width or cfg["size"][0], args.height or cfg["size"][1]
     orbit = args.moving_camera or cfg.get("orbit", False)
-    scene = host.Scene().makeProcedural(getattr(abi, cfg["kind"]), args.scale, 1)
+    footprint = footprint_of(args)
+    scene = host.Scene().makeProcedural(scene_kind(abi, args.config, footprint), args.scale, 1)
     env = None
     if cfg["env"]:
         env = host.HdrSampling()
@@ -340,9 +371,10 @@ def main():
             "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"config {args.config}: {cfg['name']} procedural scene, {scene.getStat()['instancedTriangles']} triangles, {W}x{H}, {cfg['pipeline']}, "
+            "config": {"workload": f"config {args.config}: {cfg['name']} procedural scene ({footprint} footprint: {scene.getStat()['materials']} materials, {texture_bytes(desc) / 1e6:.0f} MB of BGRA8 texels), "
+                                   f"{scene.getStat()['instancedTriangles']} triangles, {W}x{H}, {cfg['pipeline']}, "
                                    + ("camera orbiting 0.5 deg / frame" if orbit else "static camera") + (f", {cfg['env'][0]}x{cfg['env'][1]} synthetic HDR sky" if cfg["env"] else ", no environment"),
-                       "baseline_config": args.config, "width": W, "height": H, "scene_scale": args.scale,
+                       "baseline_config": args.config, "scene_footprint": footprint, "texture_bytes": texture_bytes(desc), "width": W, "height": H, "scene_scale": args.scale,
                        "parallelism": ("single GPU" if frame is None else f"ONE rank of an emulated {args.emulate_world}-way row tiling, communication stubbed (not a benchmark result)") if world == 1 else f"row-tiled x{world}: frames in flight on 3 streams per rank, halo exchanges over RCCL (restir_amd/tiled.py PipelinedTiledFrame), " + ("equal-height bands" if band_plan is None else f"cost-weighted bands {band_plan}"),
                        "rays_per_frame": round(rays_per_frame), "fps": round(1e3 / ms_per_step, 2), "bvh8_build_s": round(build_s, 2),
                        "accel": r.accel_stats()},
@@ -411,7 +443,7 @@ def main():
         # HBM traffic and VALU instructions of the same kernel from the PMC passes of THIS workload (scripts/pmc.sh: separate rocprofv3 --pmc runs of this
         # command; FETCH_SIZE / WRITE_SIZE are in KiB; gfx950's FETCH_SIZE counts wide reads at half their size — MI355X_MICROARCH.md, HBM section — so it is
         # doubled; WRITE_SIZE is taken as reported).  Counters of another build or another workload are not used: the label is then null.
-        t, pmc = pmc_entry(workload_key(args.config, orbit), kname)
+        t, pmc = pmc_entry(workload_key(args.config, orbit, footprint), kname)
         out["roofline"]["traffic_lib"] = pmc.get("_lib_sha256_16") if pmc else None
         out["roofline"]["traffic_stale"] = bool(pmc) and pmc.get("_lib_sha256_16") != lib_sha256_16()
         sdur = None
@@ -438,7 +470,7 @@ def main():
                              "source": "profiles/pmc_traffic.json (SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU per launch)"})
                 if sdur:
                     valu["serial_frac"] = round(t["INSTS_VALU"] / (sdur * 1e-3) / peak_mix, 4)
-                w = (pmc.get("workloads", {}).get(workload_key(args.config, orbit)) or pmc) if pmc else None
+                w = (pmc.get("workloads", {}).get(workload_key(args.config, orbit, footprint)) or pmc) if pmc else None
                 fr = w.get("_frame") if w else None
                 if fr and args.emulate_world <= 1:
                     valu.update({"frame_wave_insts": round(fr["INSTS_VALU"]), "frame_frac": round(fr["INSTS_VALU"] / (out["ms_per_step"] * 1e-3) / peak_mix, 4)})
@@ -516,7 +548,8 @@ def native_world(args, abi, host, Renderer, torch):
     orbit = args.moving_camera or cfg.get("orbit", False)
     if cfg.get("di_only"):
         raise SystemExit("--native: config 2 is the direct stage alone (one launch per step); it has no row-tiled form")
-    scene = host.Scene().makeProcedural(getattr(abi, cfg["kind"]), args.scale, 1)
+    footprint = footprint_of(args)
+    scene = host.Scene().makeProcedural(scene_kind(abi, args.config, footprint), args.scale, 1)
     env = None
     if cfg["env"]:
         env = host.HdrSampling(); env.makeSyntheticSky(cfg["env"][0], cfg["env"][1], 5e4, 7)
@@ -571,9 +604,10 @@ def native_world(args, abi, host, Renderer, torch):
     out = {"metric": "Mrays/s (ClosestHit+AnyHit ray queries per second) of the " + ("1080p ReSTIR DI+GI+denoise frame" if args.config == 4 else f"config-{args.config} frame") + "; ms_per_step = ms/frame",
            "value": round(rays_per_frame * args.steps / elapsed / 1e6, 2), "unit": "Mrays/s", "n_gpus": distinct, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": f"config {args.config}: {cfg['name']} procedural scene, {scene.getStat()['instancedTriangles']} triangles, {W}x{H}, {cfg['pipeline']}, "
+           "config": {"workload": f"config {args.config}: {cfg['name']} procedural scene ({footprint} footprint: {scene.getStat()['materials']} materials, {texture_bytes(desc) / 1e6:.0f} MB of BGRA8 texels), "
+                                  f"{scene.getStat()['instancedTriangles']} triangles, {W}x{H}, {cfg['pipeline']}, "
                                   + ("camera orbiting 0.5 deg / frame" if orbit else "static camera"),
-                      "baseline_config": args.config, "width": W, "height": H, "scene_scale": args.scale,
+                      "baseline_config": args.config, "scene_footprint": footprint, "texture_bytes": texture_bytes(desc), "width": W, "height": H, "scene_scale": args.scale,
                       "parallelism": f"row-tiled x{n}: ONE process, native context (rt_mgpu_*): a worker thread, an rt_ctx and three streams per device, frames in flight per rank, "
                                      f"event-ordered hipMemcpyPeerAsync pulls; " + ("equal-height bands" if args.equal_bands else f"cost-weighted bands {bands}"),
                       "rays_per_frame": round(rays_per_frame), "fps": round(1e3 / ms_per_step, 2), "bvh8_build_s": round(build_s, 2)},
@@ -670,7 +704,7 @@ def emulate_world(args, abi, host, scene, env, st, desc, single, W, H, device):
     m = MultiGpuRenderer().setup([device] * n)
     m.load_scene(desc); m.update(W, H)
     m.set_serialize(True); m.set_balance(0 if args.equal_bands else 1)
-    scene2 = host.Scene().makeProcedural(getattr(abi, CONFIGS[args.config]["kind"]), args.scale, 1)   # (a second instance: its camera history is the tiled run's own)
+    scene2 = host.Scene().makeProcedural(scene_kind(abi, args.config, footprint_of(args)), args.scale, 1)   # (a second instance: its camera history is the tiled run's own)
     scene2.updateCamera(W, H)
     acc = np.zeros((n, 2)); halo = 0; kinds = np.zeros(6); bands = None
     f = 0

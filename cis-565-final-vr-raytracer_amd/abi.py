@@ -89,4 +89,4 @@ BUFFER_NAMES = ["gbuffer0", "gbuffer1", "motion", "direct_resv0", "direct_resv1"
 # rt_restir_state
 RESTIR_NONE, RESTIR_RIS, RESTIR_SPATIAL, RESTIR_TEMPORAL, RESTIR_SPATIOTEMPORAL = range(5)
 # ProcScene (host/scene.hpp)
-PROC_CORNELL, PROC_HELMET, PROC_SPONZA, PROC_BISTRO_EXT, PROC_BISTRO_INT = range(5)
+PROC_CORNELL, PROC_HELMET, PROC_SPONZA, PROC_BISTRO_EXT, PROC_BISTRO_INT, PROC_BISTRO_EXT_REAL, PROC_SPONZA_1K = range(7)

@@ -43,8 +43,8 @@ int rth_scene_save_gltf(void* s, const char* path)
 }
 int rth_scene_make_procedural(void* s, int kind, float scale, uint32_t seed)
 {
-  const char* names[] = {"cornell", "helmet-class", "sponza-class", "bistro-exterior-class", "bistro-interior-class"};
-  if(kind < 0 || kind > 4) return -1;
+  const char* names[] = {"cornell", "helmet-class", "sponza-class", "bistro-exterior-class", "bistro-interior-class", "bistro-exterior-class (real footprint)", "sponza-class (1k textures)"};
+  if(kind < 0 || kind > 6) return -1;
   return static_cast<Scene*>(s)->loadFromGltfScene(makeProceduralScene(ProcScene(kind), scale, seed), names[kind]) ? 0 : -1;
 }
 void rth_scene_set_camera(void* s, const float* eye, const float* center, const float* up, float fovDeg)

@@ -113,7 +113,10 @@ class Scene {
 };
 
 // ---- procedural stand-ins for the assets the reference downloads / the benchmark names (scene_gen.cpp) ----
-enum ProcScene { PROC_CORNELL = 0, PROC_HELMET = 1, PROC_SPONZA = 2, PROC_BISTRO_EXT = 3, PROC_BISTRO_INT = 4 };
+// 5 / 6 (round 5): the SAME classes with the memory footprint of the assets they stand in for — the reference uploads every image at full size, BGRA8, no mips
+// (src/scene.cpp:554-646): the exterior street with 128 materials of 2k^2 texture sets (3.3 GB), 16 distinct 1k^2 foliage cards and long thin triangles;
+// the atrium with SURVEY 8(d)'s 1k^2 textures.  0-4 are unchanged (`lite`): every fixture and digest of rounds 1-4 keeps its scene.
+enum ProcScene { PROC_CORNELL = 0, PROC_HELMET = 1, PROC_SPONZA = 2, PROC_BISTRO_EXT = 3, PROC_BISTRO_INT = 4, PROC_BISTRO_EXT_REAL = 5, PROC_SPONZA_1K = 6 };
 // scale in (0,1] shrinks tessellation (triangle count ~ scale) for quick tests; seed fixes every random choice
 GltfScene makeProceduralScene(ProcScene kind, float scale, uint32_t seed);
 

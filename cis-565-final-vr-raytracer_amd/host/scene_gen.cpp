@@ -7,6 +7,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <atomic>
+#include <thread>
 
 namespace rth {
 namespace {
@@ -110,6 +112,31 @@ struct Builder {
     quad(P(-1, 1, -1), P(1, 1, -1), P(1, 1, 1), P(-1, 1, 1), N(0, 1, 0), uvScale);
     quad(P(-1, -1, -1), P(1, -1, -1), P(1, -1, 1), P(-1, -1, 1), N(0, -1, 0), uvScale);
   }
+  // square-section beam from a to b (rails, balusters, cable segments, chair legs): 12 long thin triangles in any orientation
+  void beam(V3 a, V3 b, float half, float uvScale = 1.f)
+  {
+    V3 d = normalize(b - a);
+    V3 s = std::fabs(d.y) < 0.9f ? normalize(cross(d, V3{0, 1, 0})) : normalize(cross(d, V3{1, 0, 0}));
+    V3 t = cross(d, s);
+    s = s * half; t = t * half;
+    quad(a - s - t, b - s - t, b + s - t, a + s - t, t * (-1.f / half), uvScale);
+    quad(a - s + t, b - s + t, b + s + t, a + s + t, t * (1.f / half), uvScale);
+    quad(a - s - t, b - s - t, b - s + t, a - s + t, s * (-1.f / half), uvScale);
+    quad(a + s - t, b + s - t, b + s + t, a + s + t, s * (1.f / half), uvScale);
+    quad(a - s - t, a + s - t, a + s + t, a - s + t, d * -1.f, uvScale);
+    quad(b - s - t, b + s - t, b + s + t, b - s + t, d, uvScale);
+  }
+  // a parallelogram o + s*ax + t*ay as `n` strips along ax (awning fabric, shutters): 2n triangles |ay| long and |ax|/n wide, UVs over the whole sheet
+  void strips(V3 o, V3 ax, V3 ay, V3 nrm, int n)
+  {
+    if(dot(cross(ax, ay), nrm) < 0) { o = o + ax; ax = ax * -1.f; }
+    V3 t = normalize(ax);
+    for(int i = 0; i < n; i++) {
+      const float s0 = float(i) / n, s1 = float(i + 1) / n;
+      uint32_t a = vert(o + ax * s0, nrm, s0, 0, t), b = vert(o + ax * s1, nrm, s1, 0, t), c = vert(o + ax * s1 + ay, nrm, s1, 1, t), d = vert(o + ax * s0 + ay, nrm, s0, 1, t);
+      tri(a, b, c); tri(a, c, d);
+    }
+  }
   // UV sphere with optional noise displacement; nu x nv quads => 2*nu*nv triangles
   void sphere(V3 c, V3 radii, int nu, int nv, float disp = 0.f, uint32_t seed = 0)
   {
@@ -170,10 +197,12 @@ struct Builder {
   }
 };
 
-TextureImage makeTexture(int size, int kind, uint32_t seed, const float tint[3])
+// rows [y0, y1) of a procedural texture.  kind 0-5: the round-1 patterns (bit-identical: every generated scene of rounds 1-4 keeps its texels);
+// kind 6: cut-out with `tint[3]`-selected silhouette variants (the "real footprint" scenes: 16 distinct foliage cards)
+void fillTextureRows(TextureImage& t, int kind, uint32_t seed, const float tint[3], int y0, int y1, int variant = 0)
 {
-  TextureImage t; t.width = t.height = size; t.bgra.resize(size_t(size) * size * 4);
-  for(int y = 0; y < size; y++)
+  const int size = t.width;
+  for(int y = y0; y < y1; y++)
     for(int x = 0; x < size; x++) {
       float u = float(x) / size, v = float(y) / size;
       float r = 1, g = 1, b = 1, a = 1;
@@ -199,12 +228,85 @@ TextureImage makeTexture(int size, int kind, uint32_t seed, const float tint[3])
           r = nx / l * 0.5f + 0.5f; g = ny / l * 0.5f + 0.5f; b = nz / l * 0.5f + 0.5f; break;
         }
         case 5: { float n = fbm(u * 10, v * 10, seed); r = 1; g = 0.25f + 0.7f * n; b = n > 0.6f ? 1.f : 0.f; break; }  // occlusion/roughness/metallic
+        case 6: {  // foliage card: `variant` picks the silhouette — one lobed leaf (3..8 lobes), or a spray of 3..5 small leaves on a stem (coverage 18..40 %)
+          const int lobes = 3 + variant % 6;
+          float n = 0.6f + 0.4f * fbm(u * 20, v * 20, seed);
+          r = tint[0] * n; g = tint[1] * n; b = tint[2] * n;
+          if(variant < 8) {
+            float cx = u - 0.5f, cy = v - 0.5f, rad = std::sqrt(cx * cx + cy * cy), ang = std::atan2(cy, cx);
+            float lim = 0.27f + 0.02f * (variant & 3) + (0.08f + 0.01f * variant) * std::cos(ang * float(lobes)) + 0.06f * fbm(u * 9, v * 9, seed);
+            a = rad < lim ? 1.f : 0.f;
+          } else {
+            a = 0.f;
+            const int leaves = 3 + variant % 3;
+            for(int k = 0; k < leaves; k++) {
+              const float la = 6.2831853f * (float(k) + 0.3f * hashNoise(k, variant, seed)) / float(leaves);
+              const float lx = 0.5f + 0.24f * std::cos(la), ly = 0.5f + 0.24f * std::sin(la);
+              // an ellipse pointing away from the centre
+              const float dx = u - lx, dy = v - ly, al = dx * std::cos(la) + dy * std::sin(la), ac = -dx * std::sin(la) + dy * std::cos(la);
+              const float w = 0.075f + 0.02f * hashNoise(k, 7, seed);
+              if((al * al) / (0.2f * 0.2f) + (ac * ac) / (w * w) < 1.f + 0.25f * (fbm(u * 30, v * 30, seed + 5) - 0.5f)) a = 1.f;
+              // stem towards the centre
+              const float tt = ((u - 0.5f) * (lx - 0.5f) + (v - 0.5f) * (ly - 0.5f)) / (0.24f * 0.24f);
+              if(tt > 0.f && tt < 1.f) { const float px = (u - 0.5f) - tt * (lx - 0.5f), py = (v - 0.5f) - tt * (ly - 0.5f); if(px * px + py * py < 0.008f * 0.008f) { a = 1.f; r *= 0.5f; g *= 0.45f; } }
+            }
+          }
+          break;
+        }
+        case 7: {  // painted / weathered wall: large stains over fine grain, faint horizontal courses
+          float st = fbm(u * 3, v * 3, seed), gr = fbm(u * 64, v * 64, seed + 9), course = (v * 24 - std::floor(v * 24)) < 0.06f ? 0.85f : 1.f;
+          float n = (0.5f + 0.35f * st + 0.15f * gr) * course; r = tint[0] * n; g = tint[1] * n; b = tint[2] * n; break;
+        }
+        case 8: {  // cobbles / pavers: offset rows of rounded stones
+          float row = std::floor(v * 32), bu = u * 32 + (int(row) & 1) * 0.5f, fx = bu - std::floor(bu) - 0.5f, fy = v * 32 - row - 0.5f;
+          float d = std::sqrt(fx * fx + fy * fy), n = d > 0.46f ? 0.3f : (0.55f + 0.35f * hashNoise(int(std::floor(bu)), int(row), seed)) * (1.f - 0.5f * d);
+          n *= 0.8f + 0.2f * fbm(u * 48, v * 48, seed + 3); r = tint[0] * n; g = tint[1] * n; b = tint[2] * n; break;
+        }
+        case 9: {  // striped fabric (awnings)
+          bool c = (int(u * 24) & 1) != 0; float n = (c ? 0.95f : 0.6f) * (0.85f + 0.15f * fbm(u * 40, v * 40, seed));
+          r = c ? n : tint[0] * n; g = c ? n : tint[1] * n; b = c ? n : tint[2] * n; break;
+        }
       }
       uint8_t* p = &t.bgra[(size_t(y) * size + x) * 4];
       auto q = [](float f) { f = f < 0 ? 0 : (f > 1 ? 1 : f); return uint8_t(f * 255.f + 0.5f); };
       p[0] = q(b); p[1] = q(g); p[2] = q(r); p[3] = q(a);  // BGRA (scene.cpp:559)
     }
+}
+TextureImage makeTexture(int size, int kind, uint32_t seed, const float tint[3])
+{
+  TextureImage t; t.width = t.height = size; t.bgra.resize(size_t(size) * size * 4);
+  fillTextureRows(t, kind, seed, tint, 0, size);
   return t;
+}
+// The real-footprint scenes hold gigabytes of texels (below): their textures are declared first and filled by every host thread afterwards, 32 rows at a time.
+struct TexJob { int index, kind, variant; uint32_t seed; float tint[3]; };
+int declareTexture(Builder& B, std::vector<TexJob>& jobs, int size, int kind, uint32_t seed, const float tint[3], int variant = 0)
+{
+  TextureImage t; t.width = t.height = size; t.bgra.resize(size_t(size) * size * 4);
+  const int id = B.addTexture(std::move(t));
+  jobs.push_back(TexJob{id, kind, variant, seed, {tint[0], tint[1], tint[2]}});
+  return id;
+}
+void fillTextures(Builder& B, const std::vector<TexJob>& jobs)
+{
+  struct Chunk { int job, y0, y1; };
+  std::vector<Chunk> chunks;
+  for(size_t j = 0; j < jobs.size(); j++) {
+    const int h = B.g.textures[size_t(jobs[j].index)].height;
+    for(int y = 0; y < h; y += 32) chunks.push_back({int(j), y, std::min(h, y + 32)});
+  }
+  std::atomic<size_t> next{0};
+  auto work = [&]() {
+    for(size_t c; (c = next.fetch_add(1)) < chunks.size();) {
+      const TexJob& J = jobs[size_t(chunks[c].job)];
+      fillTextureRows(B.g.textures[size_t(J.index)], J.kind, J.seed, J.tint, chunks[c].y0, chunks[c].y1, J.variant);
+    }
+  };
+  const unsigned nt = std::max(1u, std::min(256u, std::thread::hardware_concurrency()));
+  std::vector<std::thread> pool;
+  for(unsigned i = 1; i < nt; i++) pool.emplace_back(work);
+  work();
+  for(auto& th : pool) th.join();
 }
 
 GltfMaterial diffuse(float r, float g, float b, float rough = 1.f, float metal = 0.f)
@@ -285,10 +387,10 @@ Palette makePalette(Builder& B, int numTextured, int texSize, uint32_t seed, flo
 }
 
 // ---- config 3: "Sponza-class" atrium, ~262k triangles at scale 1 ------------------------------------------------
-GltfScene makeSponza(float scale, uint32_t seed)
+GltfScene makeSponza(float scale, uint32_t seed, int texSize = 512)
 {
   Builder B(seed);
-  Palette P = makePalette(B, 25, 512, seed, 40.f, 34.f, 26.f);
+  Palette P = makePalette(B, 25, texSize, seed, 40.f, 34.f, 26.f);
   float s = std::sqrt(scale);
   auto mat = [&](int i) { return P.opaque[size_t(i) % P.opaque.size()]; };
   B.beginMesh(mat(0)); B.grid({-15, 0, -6}, {30, 0, 0}, {0, 0, 12}, {0, 1, 0}, std::max(2, int(200 * s)), std::max(2, int(100 * s)), 0.04f, 40.f, seed, 30.f); B.addNode(B.endMesh());
@@ -432,6 +534,215 @@ GltfScene makeBistro(bool interior, float scale, uint32_t seed)
   return std::move(B.g);
 }
 
+// ---- config 4, "real footprint": the exterior street with the memory behaviour of the asset it stands in for ------------------------------------------------
+// The round-1 scene above (kept as the `lite` variant) holds 60 MB of 512^2 textures and ONE 256^2 cut-out: its whole working set sits in the 256 MiB Infinity
+// Cache.  The reference uploads every glTF image at full size as BGRA8 without mips (src/scene.cpp:554-646); Bistro Exterior is ~130 materials with 2k
+// base-colour / normal / specular sets and dozens of foliage cards.  This variant follows those rules at scale 1:
+//   * 128 textured opaque materials, each a 2048^2 base colour; every second one a 2048^2 normal map, every third one a 1024^2 metallic-roughness map
+//     (3.3 GB of texels), mapped about once per object (no dense tiling: minified, incoherent fetches — the reference never generates mips)
+//   * 16 distinct 1024^2 cut-out textures (single lobed leaves and sprays of small leaves, 18-40 % coverage) spread over the tree crowns and the facade ivy
+//   * long thin triangles in every orientation: balcony rails and balusters, sagging cables across the street, striped awnings cut into strips, chairs
+//   * the same 2.8 M instanced triangles and the same camera
+// Texture sizes follow sqrt(scale) (128^2 at the 0.01 scale of the quick parity tests).
+int pow2Floor(int v) { int p = 1; while(p * 2 <= v) p *= 2; return p; }
+GltfScene makeBistroExteriorReal(float scale, uint32_t seed)
+{
+  Builder B(seed);
+  std::vector<TexJob> jobs;
+  const float s = std::sqrt(scale), one[3] = {1, 1, 1};
+  const int texSize = std::max(64, pow2Floor(int(2048.f * s + 0.5f)));
+  const float X = 60.f, Z = 40.f;
+  // ---- materials ----------------------------------------------------------------------------------------------------------------------------------
+  // pattern kinds by use: 0..15 ground (cobbles / mottled), 16..39 walls, 40..51 frames, 52..63 balconies, 64..71 awnings, 72..119 props, 120..123 bark, 124..127 furniture
+  const int NMAT = 128;
+  std::vector<int> M(NMAT);
+  for(int i = 0; i < NMAT; i++) {
+    float tint[3] = {B.rng.range(0.35f, 0.95f), B.rng.range(0.35f, 0.9f), B.rng.range(0.3f, 0.85f)};
+    const int kind = i < 16 ? ((i & 1) ? 8 : 0) : i < 40 ? ((i % 3 == 0) ? 2 : 7) : i < 64 ? 0 : i < 72 ? 9 : (i % 3);
+    GltfMaterial m = diffuse(1, 1, 1, B.rng.range(0.2f, 1.f), B.rng.uni() < 0.2f ? 1.f : 0.f);
+    m.baseColorTexture = declareTexture(B, jobs, texSize, kind, seed + 11u * i, tint);
+    if(i % 2 == 0) m.normalTexture = declareTexture(B, jobs, texSize, 4, seed + 101u * i, one);
+    if(i % 3 == 0) m.metallicRoughnessTexture = declareTexture(B, jobs, std::max(32, texSize / 2), 5, seed + 1001u * i, one);
+    M[size_t(i)] = B.addMaterial(m);
+  }
+  int leafMat[16];
+  for(int i = 0; i < 16; i++) {
+    float tint[3] = {B.rng.range(0.15f, 0.45f), B.rng.range(0.4f, 0.7f), B.rng.range(0.1f, 0.3f)};
+    GltfMaterial leaf = diffuse(1, 1, 1, 0.8f);
+    leaf.baseColorTexture = declareTexture(B, jobs, std::max(32, texSize / 2), 6, seed + 77u + 13u * i, tint, i);
+    leaf.alphaMode = RT_ALPHA_MASK; leaf.alphaCutoff = 0.5f; leaf.doubleSided = 1;
+    if(getenv("RESTIR_DEBUG_OPAQUE_LEAVES")) leaf.alphaMode = RT_ALPHA_OPAQUE;
+    leafMat[i] = B.addMaterial(leaf);
+  }
+  const int glass = B.addMaterial(diffuse(0.6f, 0.7f, 0.75f, 0.05f, 1.f));
+  const int metal = B.addMaterial(diffuse(0.9f, 0.85f, 0.7f, 0.25f, 1.f));
+  const int lamp = B.addMaterial(emissive(60.f, 48.f, 30.f));
+  // ---- ground: 4 x 4 patches, each its own material, mapped 3 x over a 30 x 20 m patch -----------------------------------------------------------------
+  {
+    const int n = std::max(2, int(125 * s));
+    for(int pz = 0; pz < 4; pz++)
+      for(int px = 0; px < 4; px++) {
+        B.beginMesh(M[size_t(pz * 4 + px)]);
+        // (one height field over the whole street: the patches meet without gaps because amp / freq / seed are global and the grid evaluates H(u, v) per patch —
+        // patches use their own seed and a small amplitude, the seams are below a centimetre and hidden under the kerb beams)
+        B.grid({-X + px * 2 * X / 4, 0, -Z + pz * 2 * Z / 4}, {2 * X / 4, 0, 0}, {0, 0, 2 * Z / 4}, {0, 1, 0}, n, n, 0.02f, 40.f, seed + 17u * (pz * 4 + px), 3.f);
+        B.addNode(B.endMesh());
+      }
+    B.beginMesh(metal);
+    for(int k = 1; k < 4; k++) { B.beam({-X, 0.01f, -Z + k * 2 * Z / 4}, {X, 0.01f, -Z + k * 2 * Z / 4}, 0.03f); B.beam({-X + k * 2 * X / 4, 0.01f, -Z}, {-X + k * 2 * X / 4, 0.01f, Z}, 0.03f); }
+    B.addNode(B.endMesh());
+  }
+  // ---- buildings: shell, window frames, glass, balconies with rails and balusters, awnings --------------------------------------------------------------
+  const int nb = std::max(2, int(24 * scale + 0.5f));
+  for(int b = 0; b < nb; b++) {
+    const float wbx = -X + 6.f + (b / 2) * (2 * X - 12.f) / std::max(1, nb / 2 - 1 + (nb / 2 == 1)), wbz = (b & 1) ? 14.f : -14.f;
+    const float hw = B.rng.range(3.5f, 4.8f), hh = B.rng.range(6.f, 11.f), hd = B.rng.range(4.f, 6.f);
+    // every second building is turned a little: its frames, rails and balusters are not axis aligned
+    const M4 bm = translate({wbx, 0, wbz}) * rotateY((b % 2 == 0) ? B.rng.range(-0.2f, 0.2f) : 0.f);
+    const int floors = std::max(1, int(10 * s)), cols = std::max(1, int(12 * s));
+    const float face = (b & 1) ? -hd : hd, dir = (b & 1) ? -1.f : 1.f;
+    B.beginMesh(M[size_t(16 + b % 24)]); B.box({0, hh, 0}, {hw, hh, hd}, 0.f, false, 2.f); B.addNode(B.endMesh(), bm);
+    B.beginMesh(M[size_t(40 + b % 12)]);
+    for(int f = 0; f < floors; f++)
+      for(int c = 0; c < cols; c++) {
+        const float wx = -hw + (c + 0.5f) * 2 * hw / cols, wy = (f + 0.6f) * 2 * hh / floors, ww = 0.7f * hw / cols, wh = 0.6f * hh / floors;
+        B.box({wx - ww, wy, face + dir * 0.06f}, {0.04f, wh, 0.06f});
+        B.box({wx + ww, wy, face + dir * 0.06f}, {0.04f, wh, 0.06f});
+        B.box({wx, wy - wh, face + dir * 0.06f}, {ww, 0.04f, 0.08f});
+        B.box({wx, wy + wh, face + dir * 0.06f}, {ww, 0.04f, 0.06f});
+      }
+    B.addNode(B.endMesh(), bm);
+    B.beginMesh(glass);
+    for(int f = 0; f < floors; f++)
+      for(int c = 0; c < cols; c++) {
+        const float wx = -hw + (c + 0.5f) * 2 * hw / cols, wy = (f + 0.6f) * 2 * hh / floors, ww = 0.7f * hw / cols, wh = 0.6f * hh / floors, z = face + dir * 0.02f;
+        B.quad({wx - ww, wy - wh, z}, {wx + ww, wy - wh, z}, {wx + ww, wy + wh, z}, {wx - ww, wy + wh, z}, {0, 0, dir});
+      }
+    B.addNode(B.endMesh(), bm);
+    // balconies: a slab, three full-width rails and a baluster every 12 cm, on every floor above the ground floor
+    B.beginMesh(M[size_t(52 + b % 12)]);
+    for(int f = 1; f < floors; f++) {
+      const float y = (f + 0.6f) * 2 * hh / floors - 0.6f * hh / floors - 0.05f, z0 = face + dir * 0.1f, z1 = face + dir * 0.75f;
+      B.box({0, y, 0.5f * (z0 + z1)}, {hw * 0.96f, 0.03f, 0.5f * std::fabs(z1 - z0)});
+      for(int k = 0; k < 3; k++) B.beam({-hw * 0.96f, y + 0.3f + 0.3f * k, z1}, {hw * 0.96f, y + 0.3f + 0.3f * k, z1}, 0.012f);
+      const int nbal = std::max(2, int(2 * hw * 0.96f / 0.12f * s));
+      for(int k = 0; k <= nbal; k++) { const float x = -hw * 0.96f + k * 2 * hw * 0.96f / nbal; B.beam({x, y, z1}, {x, y + 0.9f, z1}, 0.007f); }
+    }
+    B.addNode(B.endMesh(), bm);
+    // awnings over the ground floor: slanted sheets cut into strips along their width, on two thin struts each
+    B.beginMesh(M[size_t(64 + b % 8)]);
+    for(int a = 0; a < 3; a++) {
+      const float ax0 = -hw + (a + 0.1f) * 2 * hw / 3, aw = 0.8f * 2 * hw / 3, ay = 3.1f, out = 1.6f, drop = 0.7f;
+      B.strips({ax0, ay, face + dir * 0.05f}, {aw, 0, 0}, {0, -drop, dir * out}, normalize(V3{0, out, dir * drop}), std::max(2, int(60 * s)));
+    }
+    B.addNode(B.endMesh(), bm);
+    B.beginMesh(metal);
+    for(int a = 0; a < 3; a++) {
+      const float ax0 = -hw + (a + 0.1f) * 2 * hw / 3, aw = 0.8f * 2 * hw / 3;
+      for(int e = 0; e < 2; e++) B.beam({ax0 + e * aw, 3.1f - 0.7f, face + dir * 1.65f}, {ax0 + e * aw, 2.2f, face + dir * 0.05f}, 0.01f);
+    }
+    B.addNode(B.endMesh(), bm);
+    // ivy on every third facade: cut-out cards a few centimetres off the wall
+    if(b % 3 == 0) {
+      const int cards = std::max(4, int(1500 * scale));
+      for(int part = 0; part < 2; part++) {
+        B.beginMesh(leafMat[(b + 8 * part + 3) % 16]);
+        for(int q = 0; q < cards / 2; q++) {
+          const float x = B.rng.range(-hw, hw), y = B.rng.range(0.2f, hh * 1.2f) * std::sqrt(B.rng.uni()), z = face + dir * B.rng.range(0.1f, 0.3f);
+          V3 n = normalize(V3{B.rng.range(-0.5f, 0.5f), B.rng.range(-0.2f, 0.6f), dir});
+          V3 t1 = normalize(cross(n, V3{0.3f, 1, 0.2f})), t2 = cross(n, t1);
+          const float sz = B.rng.range(0.1f, 0.2f);
+          V3 c{x, y, z};
+          B.quad(c - t1 * sz - t2 * sz, c + t1 * sz - t2 * sz, c + t1 * sz + t2 * sz, c - t1 * sz + t2 * sz, n);
+        }
+        B.addNode(B.endMesh(), bm);
+      }
+    }
+  }
+  // ---- trees: 4 crown shapes x 4 card textures each (16 cut-out materials), instanced along the street ------------------------------------------------
+  {
+    const int leafQuads = std::max(8, int(3000 * scale));
+    int trunkMesh[4], crownMesh[4][4];
+    for(int t = 0; t < 4; t++) {
+      B.beginMesh(M[size_t(120 + t)]); B.cylinder({0, 0, 0}, 0.22f, 3.2f, std::max(5, int(24 * s)), std::max(2, int(20 * s))); trunkMesh[t] = B.endMesh();
+      for(int k = 0; k < 4; k++) {
+        B.beginMesh(leafMat[t * 4 + k]);
+        for(int q = k; q < leafQuads; q += 4) {
+          float th = B.rng.range(0, 3.14159f), ph = B.rng.range(0, 6.28318f), r = 1.7f * std::cbrt(B.rng.uni());
+          V3 c{r * std::sin(th) * std::cos(ph), 4.2f + r * std::cos(th) * 0.8f, r * std::sin(th) * std::sin(ph)};
+          V3 n = normalize(V3{B.rng.range(-1, 1), B.rng.range(-0.3f, 1), B.rng.range(-1, 1)});
+          V3 t1 = normalize(cross(n, V3{0.3f, 1, 0.2f})), t2 = cross(n, t1);
+          float sz = B.rng.range(0.12f, 0.22f);
+          B.quad(c - t1 * sz - t2 * sz, c + t1 * sz - t2 * sz, c + t1 * sz + t2 * sz, c - t1 * sz + t2 * sz, n);
+        }
+        crownMesh[t][k] = B.endMesh();
+      }
+    }
+    const int nt = std::max(4, int(40 * scale + 0.5f));   // (at least one tree of every crown shape: all 16 card textures are referenced at any scale)
+    for(int t = 0; t < nt; t++) {
+      M4 m = translate({-X + 5.f + t * (2 * X - 10.f) / nt, 0, (t & 1) ? 7.5f : -7.5f}) * rotateY(B.rng.range(0, 6.28f)) * scaleM({1, B.rng.range(0.85f, 1.2f), 1});
+      B.addNode(trunkMesh[t & 3], m);
+      for(int k = 0; k < 4; k++) B.addNode(crownMesh[t & 3][k], m);
+    }
+  }
+  // ---- lamps, posts, and cables sagging from post to post across the street ------------------------------------------------------------------------------
+  {
+    const int nl = std::max(2, int(40 * std::min(1.f, scale * 4)));
+    for(int l = 0; l < nl; l++) {
+      const float lx = -X + 3.f + (l + 0.5f) * (2 * X - 6.f) / nl, lz = (l & 1) ? 5.2f : -5.2f, ly = 4.4f;
+      B.beginMesh(lamp); B.sphere({lx, ly, lz}, {0.16f, 0.12f, 0.16f}, 6, 4); B.addNode(B.endMesh());
+      B.beginMesh(metal); B.cylinder({lx, 0, lz}, 0.05f, 4.3f, 8, 2); B.addNode(B.endMesh());
+      if(l + 1 < nl) {
+        const float nx2 = -X + 3.f + (l + 1.5f) * (2 * X - 6.f) / nl, nz2 = -lz;
+        B.beginMesh(metal);
+        const int seg = std::max(2, int(16 * s));
+        for(int c = 0; c < 3; c++) {           // three strands with different sag
+          const float sag = 0.25f + 0.2f * c, y0 = 4.25f - 0.1f * c;
+          for(int k = 0; k < seg; k++) {
+            const float a0 = float(k) / seg, a1 = float(k + 1) / seg;
+            auto P = [&](float a) { return V3{lx + (nx2 - lx) * a, y0 - sag * 4.f * a * (1.f - a), lz + (nz2 - lz) * a}; };
+            B.beam(P(a0), P(a1), 0.006f);
+          }
+        }
+        B.addNode(B.endMesh());
+      }
+    }
+  }
+  // ---- furniture: chairs (thin legs, back slats) and tables on the pavement, instanced ---------------------------------------------------------------------
+  {
+    int chairMesh[4];
+    for(int k = 0; k < 4; k++) {
+      B.beginMesh(M[size_t(124 + k)]);
+      B.box({0, 0.45f, 0}, {0.2f, 0.015f, 0.2f});
+      for(int lx = -1; lx <= 1; lx += 2) for(int lz = -1; lz <= 1; lz += 2) B.beam({0.18f * lx, 0, 0.18f * lz}, {0.17f * lx, 0.45f, 0.17f * lz}, 0.01f);
+      for(int lx = -1; lx <= 1; lx += 2) B.beam({0.18f * lx, 0.45f, -0.19f}, {0.19f * lx, 0.95f, -0.24f}, 0.01f);
+      for(int sl = 0; sl < 4 + k; sl++) { const float y = 0.55f + 0.4f * sl / (4 + k); B.beam({-0.19f, y, -0.19f - 0.05f * (y - 0.45f) / 0.5f}, {0.19f, y, -0.19f - 0.05f * (y - 0.45f) / 0.5f}, 0.008f); }
+      chairMesh[k] = B.endMesh();
+    }
+    const int nc = std::max(2, int(600 * scale));
+    for(int c = 0; c < nc; c++) {
+      V3 pos{B.rng.range(-X + 2.f, X - 2.f), 0.f, (c & 1) ? B.rng.range(8.3f, 9.4f) : B.rng.range(-9.4f, -8.3f)};
+      B.addNode(chairMesh[c & 3], translate(pos) * rotateY(B.rng.range(0, 6.28f)));
+    }
+  }
+  // ---- props: 48 distinct meshes, one material each -------------------------------------------------------------------------------------------------------
+  {
+    const int np = std::max(2, int(425 * s)), nu = std::max(6, int(48 * s)), nv = std::max(4, int(38 * s));
+    int meshes[48];
+    for(int k = 0; k < 48; k++) { B.beginMesh(M[size_t(72 + k)]); B.sphere({0, 0, 0}, {1.f, 0.6f + 0.02f * k, 1.f}, nu, nv, 0.35f, seed + 31u * k); meshes[k] = B.endMesh(); }
+    for(int p = 0; p < np; p++) {
+      float r = B.rng.range(0.15f, 0.7f);
+      V3 pos{B.rng.range(-X + 1.f, X - 1.f), r * 0.8f, B.rng.range(-6.5f, 6.5f)};
+      float sgn = (p % 11 == 0) ? -1.f : 1.f;  // a few mirrored instances (negative determinant)
+      B.addNode(meshes[p % 48], translate(pos) * rotateY(B.rng.range(0, 6.28f)) * scaleM({r * sgn, r, r}));
+    }
+  }
+  fillTextures(B, jobs);
+  GltfCamera cam; cam.eye = {-52.f, 2.4f, 1.5f}; cam.center = {10.f, 4.5f, -1.f}; cam.yfovDeg = 60.f;
+  B.g.cameras.push_back(cam);
+  return std::move(B.g);
+}
+
 }  // namespace
 
 GltfScene makeProceduralScene(ProcScene kind, float scale, uint32_t seed)
@@ -443,6 +754,8 @@ GltfScene makeProceduralScene(ProcScene kind, float scale, uint32_t seed)
     case PROC_SPONZA: return makeSponza(scale, seed);
     case PROC_BISTRO_EXT: return makeBistro(false, scale, seed);
     case PROC_BISTRO_INT: return makeBistro(true, scale, seed);
+    case PROC_BISTRO_EXT_REAL: return makeBistroExteriorReal(scale, seed);
+    case PROC_SPONZA_1K: return makeSponza(scale, seed, std::max(64, pow2Floor(int(1024.f * std::sqrt(scale) + 0.5f))));
   }
   return makeCornell();
 }

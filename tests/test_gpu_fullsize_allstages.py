@@ -142,3 +142,9 @@ def test_config5_bistro_interior_class_4k_all_stages_orbiting_camera():
     """BASELINE config 5 (single-GPU leg): Bistro-Interior-class ~1.0 M triangles with ~2 k emissive triangles, 3840x2160, DI + GI with
     temporal reuse under a camera orbiting 0.5 degrees per frame; frame 3, three bands, all 12 dispatches."""
     run_config(abi.PROC_BISTRO_INT, 1.0, (512, 256), lambda st: None, nframes=4, moving=False, bands_seed=5, tri_range=(0.8e6, 1.3e6), W=3840, H=2160, orbit_deg=0.5)
+
+
+def test_config4_real_footprint_1080p_all_stages_moving_camera():
+    """BASELINE config 4 on the `real` footprint variant of the exterior scene (round 5: 147 materials, 251 textures = 3.3 GB of BGRA8 texels uploaded at full size like
+    src/scene.cpp:554-646, 16 distinct cut-out cards, rails / cables / awning strips): 1920x1080, defaults, frame 3 under a moving camera, three bands, all 12 dispatches."""
+    run_config(abi.PROC_BISTRO_EXT_REAL, 1.0, (2048, 1024), lambda st: None, nframes=4, moving=True, bands_seed=6, tri_range=(2.6e6, 3.0e6))

@@ -51,6 +51,7 @@ CASES = [
     ("sponza-moving", abi.PROC_SPONZA, 0.02, 320, 180, 4, (512, 256), True), # instancing, emissive mesh, env, reprojection
     ("bistro-ext", abi.PROC_BISTRO_EXT, 0.01, 320, 180, 3, (512, 256), True),  # alpha-masked foliage, mirrored instances
     ("bistro-int", abi.PROC_BISTRO_INT, 0.01, 256, 144, 3, (128, 64), False),
+    ("bistro-ext-real", abi.PROC_BISTRO_EXT_REAL, 0.01, 320, 180, 3, (512, 256), True),  # 16 cut-out cards, 128 texture sets, beams / strips (round 5)
 ]
 
 

@@ -15,6 +15,31 @@ def test_procedural_scene_sizes_match_baseline_configs():
     assert 1500 <= st["trigLights"] <= 2500          # "~30 emissive meshes (~2 k emissive tris)", SURVEY §8d config 5
 
 
+def test_real_footprint_scene_follows_the_reference_upload_rules():
+    """round 5: the `real` variant of the exterior scene — material / texture counts and sizes scale as documented (2048^2 * scale base colour; the full-scale scene is
+    generated on the GPU box: 3.3 GB), 16 DISTINCT cut-out textures each referenced by geometry, thin triangles present."""
+    from test_gltf import dump
+    sc = host.Scene().makeProcedural(abi.PROC_BISTRO_EXT_REAL, 0.0625, 1)
+    st = sc.getStat()
+    assert st["materials"] >= 120 + 16 and st["textures"] >= 128 + 64 + 16
+    d = dump(sc)
+    sizes = [(int(t["width"]), int(t["height"])) for t in d["textures"]]
+    assert max(sizes) == (512, 512) and sizes.count((512, 512)) == 128 + 64        # 2048 * sqrt(1/16): base colour for all, a normal map for every second material
+    total = sum(w * h * 4 for w, h in sizes)
+    assert total * 16 > 3.0e9                                                       # => 3.3 GB at scale 1 (>= 1.5 GB asked for by the round-4 verdict)
+    masked = [i for i, m in enumerate(d["materials"]) if m["alphaMode"] == 1]       # RT_ALPHA_MASK
+    assert len(masked) == 16
+    cards = {d["texels"][int(d["materials"][i]["baseColorTexture"])][:, 3].tobytes() for i in masked}
+    assert len(cards) == 16                                                         # distinct silhouettes
+    cover = [float((d["texels"][int(d["materials"][i]["baseColorTexture"])][:, 3] > 127).mean()) for i in masked]
+    assert 0.1 < min(cover) and max(cover) < 0.5
+    used = {int(d["prims"][int(i["primMesh"])]["materialIndex"]) for i in d["instances"]}
+    assert set(masked) <= used
+    assert 4e4 <= st["instancedTriangles"] <= 2.4e5                                 # (mesh resolution AND instance counts shrink with scale; 2.81 M at scale 1: GPU test)
+    sp = dump(host.Scene().makeProcedural(abi.PROC_SPONZA_1K, 0.25, 1))
+    assert max(int(t["width"]) for t in sp["textures"]) == 512                      # 1024 * sqrt(1/4)
+
+
 def test_cornell_light_table():
     sc = host.Scene().makeProcedural(abi.PROC_CORNELL)
     p, t = sc.lightWeights

@@ -17,7 +17,7 @@ def _rays(n, bbox_lo, bbox_hi, seed):
     return r
 
 
-@pytest.mark.parametrize("kind,scale", [(abi.PROC_SPONZA, 0.02), (abi.PROC_BISTRO_EXT, 0.004)])
+@pytest.mark.parametrize("kind,scale", [(abi.PROC_SPONZA, 0.02), (abi.PROC_BISTRO_EXT, 0.004), (abi.PROC_BISTRO_EXT_REAL, 0.004)])
 def test_bvh_equals_brute_force(kind, scale):
     sc, _ = make_scene(kind, scale)
     o = Oracle(1)
