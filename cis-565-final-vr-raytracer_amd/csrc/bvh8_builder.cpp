@@ -6,9 +6,16 @@
 #include "dev_math.h"
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <thread>
+
+#ifndef RT_BVH_SPLIT_DEFAULT
+#define RT_BVH_SPLIT_DEFAULT 0
+#endif
 
 namespace rt {
 namespace {
@@ -104,6 +111,208 @@ struct Builder2 {
   }
 };
 
+// ---- BVH2 with spatial splits (Stich, Friedrich, Dietrich, "Spatial Splits in Bounding Volume Hierarchies", HPG 2009) -----------------------------------
+// The reference asks its driver for PREFER_FAST_TRACE trees (src/accelstruct.cpp:125-126, 161).  An object-split SAH tree cannot separate a long thin
+// triangle (a rail, a cable, an awning strip, a facade quad) from the small geometry next to it: the boxes of its children overlap and every ray through
+// the overlap walks both.  Here a node may instead be cut by a PLANE: a triangle that straddles it is referenced from both sides, each reference bounded
+// by the box of the part of the triangle inside its cell (the triangle is clipped, not its box).  References are bounded (RESTIR_BVH_SPLIT_BUDGET x the
+// triangle count); a reference is a copy of the 64 B triangle record in leaf order, `triRef` and ids stay per TRIANGLE.
+// Results do not depend on it: the verdict of a candidate is a function of (ray, triangle), the closest hit the minimum over (t, id) — testing
+// a triangle twice changes neither; every point of a triangle lies in the (padded) box of at least one of its references.
+struct Ref { Box b; uint32_t tri; };   // b: UNPADDED bounds of the part of triangle `tri` this reference stands for
+
+struct BuilderS {
+  const std::vector<Tri48>& flat;
+  const float pad;
+  std::vector<N2> nodes;
+  std::vector<uint32_t> leafTris;
+  std::atomic<uint32_t> nodeCount{1}, leafCount{0};
+  std::atomic<int64_t> budget;           // references that may still be added
+  std::atomic<int> liveThreads{0};
+  std::atomic<uint64_t> spatialSplits{0};
+  int maxThreads;
+  float rootArea = 1.f, alpha = 1e-5f;
+  int NB = 16;
+  float leafSlotCost = 0.25f;
+  BuilderS(const std::vector<Tri48>& f, float pad_, size_t n, double budgetFrac, int threads)
+    : flat(f), pad(pad_), nodes(2 * (n + size_t(double(n) * budgetFrac)) + 16), leafTris(n + size_t(double(n) * budgetFrac) + 16), budget(int64_t(double(n) * budgetFrac)), maxThreads(threads) {}
+
+  // bounds of (triangle t) AND box `cell` (closed), by clipping the polygon in double; false: empty
+  bool clipBounds(uint32_t t, const Box& cell, Box& out) const
+  {
+    const Tri48& T = flat[t];
+    double poly[2][12][3]; int np = 3, cur = 0;
+    poly[0][0][0] = T.v0x; poly[0][0][1] = T.v0y; poly[0][0][2] = T.v0z;
+    poly[0][1][0] = double(T.v0x) + double(T.e1x); poly[0][1][1] = double(T.v0y) + double(T.e1y); poly[0][1][2] = double(T.v0z) + double(T.e1z);
+    poly[0][2][0] = double(T.v0x) + double(T.e2x); poly[0][2][1] = double(T.v0y) + double(T.e2y); poly[0][2][2] = double(T.v0z) + double(T.e2z);
+    for(int ax = 0; ax < 3 && np > 0; ax++)
+      for(int side = 0; side < 2 && np > 0; side++) {
+        const double plane = side ? double(cell.hi[ax]) : double(cell.lo[ax]);
+        const double sg = side ? -1.0 : 1.0;           // inside: sg * (x - plane) >= 0
+        int nq = 0;
+        for(int i = 0; i < np; i++) {
+          const double* a = poly[cur][i]; const double* b = poly[cur][(i + 1) % np];
+          const double da = sg * (a[ax] - plane), db = sg * (b[ax] - plane);
+          if(da >= 0) { for(int k = 0; k < 3; k++) poly[cur ^ 1][nq][k] = a[k]; nq++; }
+          if((da >= 0) != (db >= 0)) {
+            const double tt = da / (da - db);
+            for(int k = 0; k < 3; k++) poly[cur ^ 1][nq][k] = a[k] + (b[k] - a[k]) * tt;
+            poly[cur ^ 1][nq][ax] = plane;
+            nq++;
+          }
+        }
+        cur ^= 1; np = nq;
+      }
+    if(np == 0) return false;
+    out.reset();
+    for(int i = 0; i < np; i++) {
+      float q[3];
+      for(int k = 0; k < 3; k++) q[k] = float(poly[cur][i][k]);
+      // (double -> float rounds to nearest: may fall short of the true bound by half an ulp; the pad — >= 300 ulp of the largest coordinate — covers it)
+      out.grow(q);
+    }
+    for(int k = 0; k < 3; k++) { out.lo[k] = std::max(out.lo[k], cell.lo[k]); out.hi[k] = std::min(out.hi[k], cell.hi[k]); if(out.lo[k] > out.hi[k]) return false; }
+    return true;
+  }
+
+  void makeLeaf(N2& N, const std::vector<Ref>& refs)
+  {
+    const uint32_t off = leafCount.fetch_add(uint32_t(refs.size()));
+    for(size_t k = 0; k < refs.size(); k++) leafTris[off + k] = refs[k].tri;
+    N.leaf = true; N.a = off; N.n = uint32_t(refs.size());
+  }
+
+  void build(uint32_t node, std::vector<Ref> refs)
+  {
+    for(;;) {
+      N2& N = nodes[node];
+      Box nb, cb; nb.reset(); cb.reset();
+      for(const Ref& r : refs) { nb.grow(r.b); const float c[3] = {0.5f * (r.b.lo[0] + r.b.hi[0]), 0.5f * (r.b.lo[1] + r.b.hi[1]), 0.5f * (r.b.lo[2] + r.b.hi[2])}; cb.grow(c); }
+      N.b = nb;
+      for(int a = 0; a < 3; a++) { N.b.lo[a] -= pad; N.b.hi[a] += pad; }
+      const uint32_t cnt = uint32_t(refs.size());
+      if(cnt <= 1) { makeLeaf(N, refs); return; }
+      constexpr int NBMAX = 64;
+      // ---- object split: binned SAH on the reference centroids (the rule of Builder2) ----
+      float best = 3e38f; int bestAxis = -1, bestBin = 0; Box bestL, bestR;
+      for(int ax = 0; ax < 3; ax++) {
+        const float ext = cb.hi[ax] - cb.lo[ax];
+        if(!(ext > 0)) continue;
+        Box bb[NBMAX]; uint32_t bc[NBMAX];
+        for(int i = 0; i < NB; i++) { bb[i].reset(); bc[i] = 0; }
+        const float k1 = NB * (1.f - 1e-6f) / ext;
+        for(const Ref& r : refs) {
+          const int bi = std::min(NB - 1, std::max(0, int((0.5f * (r.b.lo[ax] + r.b.hi[ax]) - cb.lo[ax]) * k1)));
+          bb[bi].grow(r.b); bc[bi]++;
+        }
+        Box rb[NBMAX]; uint32_t rc[NBMAX];
+        Box acc; acc.reset(); uint32_t c = 0;
+        for(int i = NB - 1; i > 0; i--) { acc.grow(bb[i]); c += bc[i]; rb[i] = acc; rc[i] = c; }
+        acc.reset(); c = 0;
+        for(int i = 0; i < NB - 1; i++) {
+          acc.grow(bb[i]); c += bc[i];
+          if(c == 0 || rc[i + 1] == 0) continue;
+          const float cost = acc.area() * c + rb[i + 1].area() * rc[i + 1];
+          if(cost < best) { best = cost; bestAxis = ax; bestBin = i; bestL = acc; bestR = rb[i + 1]; }
+        }
+      }
+      const float pa = std::max(nb.area(), 1e-30f);
+      // ---- spatial split: only where the object split leaves its children overlapping (Stich et al., 4.5), and while references may be added ----
+      float sBest = 3e38f; int sAxis = -1; float sPlane = 0.f; uint32_t sNL = 0, sNR = 0; Box sL, sR;
+      bool trySpatial = cnt >= 2 && budget.load(std::memory_order_relaxed) > 0;
+      if(trySpatial && bestAxis >= 0) {
+        Box ov;
+        for(int a = 0; a < 3; a++) { ov.lo[a] = std::max(bestL.lo[a], bestR.lo[a]); ov.hi[a] = std::min(bestL.hi[a], bestR.hi[a]); }
+        trySpatial = ov.area() > alpha * rootArea;   // (area() is 0 for an empty intersection)
+      }
+      if(trySpatial) {
+        for(int ax = 0; ax < 3; ax++) {
+          const float lo = nb.lo[ax], ext = nb.hi[ax] - nb.lo[ax];
+          if(!(ext > 0)) continue;
+          Box bb[NBMAX]; uint32_t en[NBMAX], exx[NBMAX];
+          for(int i = 0; i < NB; i++) { bb[i].reset(); en[i] = exx[i] = 0; }
+          const float k1 = NB * (1.f - 1e-6f) / ext, w = ext / NB;
+          for(const Ref& r : refs) {
+            const int b0 = std::min(NB - 1, std::max(0, int((r.b.lo[ax] - lo) * k1))), b1 = std::min(NB - 1, std::max(b0, int((r.b.hi[ax] - lo) * k1)));
+            en[b0]++; exx[b1]++;
+            if(b0 == b1) { bb[b0].grow(r.b); continue; }
+            for(int bi = b0; bi <= b1; bi++) {
+              Box cell = r.b, part;
+              cell.lo[ax] = std::max(cell.lo[ax], lo + w * float(bi)); cell.hi[ax] = std::min(cell.hi[ax], bi == NB - 1 ? nb.hi[ax] : lo + w * float(bi + 1));
+              if(cell.lo[ax] <= cell.hi[ax] && clipBounds(r.tri, cell, part)) bb[bi].grow(part);
+            }
+          }
+          Box rb[NBMAX]; uint32_t rc[NBMAX];
+          Box acc; acc.reset(); uint32_t c = 0;
+          for(int i = NB - 1; i > 0; i--) { acc.grow(bb[i]); c += exx[i]; rb[i] = acc; rc[i] = c; }
+          acc.reset(); c = 0;
+          for(int i = 0; i < NB - 1; i++) {
+            acc.grow(bb[i]); c += en[i];
+            if(c == 0 || rc[i + 1] == 0 || c >= cnt || rc[i + 1] >= cnt) continue;   // a cut that leaves every reference on one side makes no progress
+            const float cost = acc.area() * c + rb[i + 1].area() * rc[i + 1];
+            if(cost < sBest) { sBest = cost; sAxis = ax; sPlane = lo + w * float(i + 1); sNL = c; sNR = rc[i + 1]; sL = acc; sR = rb[i + 1]; }
+          }
+        }
+      }
+      const bool spatial = sAxis >= 0 && sBest < best && int64_t(sNL + sNR) - int64_t(cnt) <= budget.load(std::memory_order_relaxed);
+      const float chosen = spatial ? sBest : best;
+      if(cnt <= 3) {
+        if((bestAxis < 0 && !spatial) || leafSlotCost * pa + chosen >= float(cnt) * pa) { makeLeaf(N, refs); return; }
+      }
+      std::vector<Ref> left, right;
+      if(spatial) {
+        left.reserve(sNL); right.reserve(sNR);
+        Box L = sL, R = sR; uint32_t nl = sNL, nr = sNR;   // running estimates for the unsplitting rule (Stich et al., 4.4)
+        for(const Ref& r : refs) {
+          if(r.b.hi[sAxis] <= sPlane) { left.push_back(r); continue; }
+          if(r.b.lo[sAxis] >= sPlane) { right.push_back(r); continue; }
+          Box cl = r.b, cr = r.b, pl, pr;
+          cl.hi[sAxis] = sPlane; cr.lo[sAxis] = sPlane;
+          const bool okL = clipBounds(r.tri, cl, pl), okR = clipBounds(r.tri, cr, pr);
+          if(!okL && !okR) { left.push_back(r); continue; }      // (cannot happen for a non-empty reference; keep it whole)
+          if(!okR) { Ref q = r; q.b = pl; left.push_back(q); nr--; continue; }
+          if(!okL) { Ref q = r; q.b = pr; right.push_back(q); nl--; continue; }
+          // split it, or keep it whole on one side when that is cheaper
+          Box Lw = L, Rw = R; Lw.grow(r.b); Rw.grow(r.b);
+          const float cSplit = L.area() * nl + R.area() * nr, cLeft = Lw.area() * nl + R.area() * (nr - 1), cRight = L.area() * (nl - 1) + Rw.area() * nr;
+          if(cLeft < cSplit && cLeft <= cRight && nr > 1) { left.push_back(r); L = Lw; nr--; }
+          else if(cRight < cSplit && nl > 1) { right.push_back(r); R = Rw; nl--; }
+          else { Ref a = r, b = r; a.b = pl; b.b = pr; left.push_back(a); right.push_back(b); }
+        }
+        if(left.empty() || right.empty() || left.size() >= cnt || right.size() >= cnt) { left.clear(); right.clear(); }   // no progress: the object split below
+        else {
+          budget.fetch_sub(int64_t(left.size() + right.size()) - int64_t(cnt));
+          spatialSplits++;
+        }
+      }
+      if(left.empty()) {
+        if(bestAxis >= 0) {
+          const float ext = cb.hi[bestAxis] - cb.lo[bestAxis], k1 = NB * (1.f - 1e-6f) / ext, lo = cb.lo[bestAxis];
+          for(const Ref& r : refs) {
+            const int bi = std::min(NB - 1, std::max(0, int((0.5f * (r.b.lo[bestAxis] + r.b.hi[bestAxis]) - lo) * k1)));
+            (bi <= bestBin ? left : right).push_back(r);
+          }
+        }
+        if(left.empty() || right.empty()) {   // identical centroids: split by index
+          left.assign(refs.begin(), refs.begin() + cnt / 2); right.assign(refs.begin() + cnt / 2, refs.end());
+        }
+      }
+      std::vector<Ref>().swap(refs);
+      const uint32_t child = nodeCount.fetch_add(2);
+      N.leaf = false; N.a = child; N.n = 0;
+      if(left.size() + right.size() > 100000 && liveThreads.load() < maxThreads) {
+        liveThreads++;
+        std::thread th([this, child, l = std::move(left)]() mutable { build(child, std::move(l)); liveThreads--; });
+        build(child + 1, std::move(right));
+        th.join();
+        return;
+      }
+      build(child, std::move(left));
+      node = child + 1; refs = std::move(right);
+    }
+  }
+};
+
 inline int slotSign(int slot, int axis) { return (slot >> axis) & 1 ? 1 : -1; }
 
 }  // namespace
@@ -164,7 +373,7 @@ bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads)
     }
   }
   const size_t n = total;
-  out.nodes.clear(); out.tris.clear(); out.maxDepth = 0;
+  out.nodes.clear(); out.tris.clear(); out.maxDepth = 0; out.sahNodeSteps = out.sahTriSteps = 0; out.references = 0; out.spatialSplits = 0;
   if(n == 0) {  // a single empty node keeps the kernels branch-free
     Node8 e{}; e.ex = e.ey = e.ez = 127;
     out.nodes.push_back(e);
@@ -186,9 +395,37 @@ bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads)
   }
   std::vector<uint32_t> idx(n);
   for(size_t i = 0; i < n; i++) idx[i] = uint32_t(i);
+  // RESTIR_BVH_SPLIT: 0 = object splits only (the tree of rounds 1-4), 1 = spatial splits (BuilderS); RESTIR_BVH_SPLIT_BUDGET: added references / triangles
+  const int splitMode = getenv("RESTIR_BVH_SPLIT") ? atoi(getenv("RESTIR_BVH_SPLIT")) : RT_BVH_SPLIT_DEFAULT;
+  const double splitBudget = getenv("RESTIR_BVH_SPLIT_BUDGET") ? std::max(0.0, std::min(2.0, atof(getenv("RESTIR_BVH_SPLIT_BUDGET")))) : 0.3;
+  const float splitAlpha = getenv("RESTIR_BVH_SPLIT_ALPHA") ? float(atof(getenv("RESTIR_BVH_SPLIT_ALPHA"))) : 1e-5f;
   Builder2 B2(prims, idx, std::max(1, threads));
-  B2.build(0, 0, uint32_t(n));
-  const std::vector<N2>& N = B2.nodes;
+  std::unique_ptr<BuilderS> BS;
+  uint32_t n2count = 0;
+  if(splitMode > 0 && n > 1) {
+    BS.reset(new BuilderS(flat, pad, n, splitBudget, std::max(1, threads)));
+    std::vector<Ref> refs(n);
+    Box root; root.reset();
+    for(size_t i = 0; i < n; i++) {
+      const Tri48& T = flat[i];
+      const float v[3][3] = {{T.v0x, T.v0y, T.v0z}, {T.v0x + T.e1x, T.v0y + T.e1y, T.v0z + T.e1z}, {T.v0x + T.e2x, T.v0y + T.e2y, T.v0z + T.e2z}};
+      refs[i].tri = uint32_t(i); refs[i].b.reset();
+      for(int k = 0; k < 3; k++) refs[i].b.grow(v[k]);   // the UNPADDED bounds (the same expressions as the padded boxes above)
+      root.grow(refs[i].b);
+    }
+    BS->rootArea = std::max(root.area(), 1e-30f); BS->alpha = splitAlpha;
+    BS->NB = getenv("RESTIR_BVH_BINS") ? std::min(64, std::max(4, atoi(getenv("RESTIR_BVH_BINS")))) : 16;
+    BS->leafSlotCost = getenv("RESTIR_BVH_SLOTCOST") ? float(atof(getenv("RESTIR_BVH_SLOTCOST"))) : 0.25f;
+    BS->build(0, std::move(refs));
+    n2count = BS->nodeCount.load();
+    out.references = BS->leafCount.load(); out.spatialSplits = BS->spatialSplits.load();
+  } else {
+    B2.build(0, 0, uint32_t(n));
+    n2count = B2.nodeCount.load();
+    out.references = n; out.spatialSplits = 0;
+  }
+  const std::vector<N2>& N = BS ? BS->nodes : B2.nodes;
+  const std::vector<uint32_t>& leafTris = BS ? BS->leafTris : idx;
 
   // ---- 3a. which BVH2 nodes become wide nodes: SAH-optimal collapse (Ylitie, Karras, Laine 2017, §3.1) -------------------------
   // cost[n][i] = cheapest way to hang BVH2 subtree n under a parent using at most i of the parent's 8 slots, where a slot holds
@@ -203,7 +440,6 @@ bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads)
   static const bool useDp = getenv("RESTIR_BVH_COLLAPSE") && strcmp(getenv("RESTIR_BVH_COLLAPSE"), "dp") == 0;
   static const float cNode = 2.3f;   // a node step is ~230 instructions,
   static const float cTri = 1.0f;                                                                            // a triangle step ~100
-  const uint32_t n2count = B2.nodeCount.load();
   std::vector<float> cost;        // [n][i], i = 1..7 at [n * 8 + i]
   std::vector<uint8_t> choice;    // [n][i]: 0 = single slot (leaf / wide node), 0xff = same as i - 1, else k = slots of the left child
   std::vector<uint8_t> k8;        // [n]: left child's share of the 8 slots when n becomes a wide node
@@ -241,7 +477,7 @@ bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads)
   struct Work { uint32_t n2; uint32_t wide; int depth; };
   std::vector<Work> queue;
   out.nodes.reserve(n / 2 + 16);
-  out.tris.reserve(n);
+  out.tris.reserve(size_t(out.references));
   out.nodes.push_back(Node8{});
   // a root that is itself a leaf gets wrapped by a one-child wide node (handled by the generic path below)
   queue.push_back({0, 0, 1});
@@ -334,7 +570,7 @@ bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads)
         // c.n <= 3 by construction, except the degenerate "root is one big leaf" case which cannot happen for n > 3
         uint32_t cntT = std::min<uint32_t>(c.n, 3u);
         W.meta[s] = uint8_t((((1u << cntT) - 1u) << 5) | triOff);
-        for(uint32_t k = 0; k < cntT; k++) out.tris.push_back(flat[idx[c.a + k]]);
+        for(uint32_t k = 0; k < cntT; k++) out.tris.push_back(flat[leafTris[c.a + k]]);
         triOff += cntT;
       } else {
         W.imask |= uint8_t(1u << s);
@@ -345,8 +581,88 @@ bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads)
       }
     }
     out.nodes[w.wide] = W;
+    // SAH statistics of the WIDE tree (expected steps of a random ray that hits the root box): a node step per wide node whose box is hit, a triangle step
+    // per triangle of a leaf slot whose box is hit
+    const double ra = std::max(1e-30, double(N[0].b.area()));
+    out.sahNodeSteps += double(nb.area()) / ra;
+    for(int i = 0; i < nc; i++) if(N[ch[i]].leaf) out.sahTriSteps += double(N[ch[i]].b.area()) / ra * double(std::min<uint32_t>(N[ch[i]].n, 3u));
   }
   return true;
 }
 
 }  // namespace rt
+
+// ---- host-side self check of a built tree (tests/test_bvh_quality.py; no GPU) ----------------------------------------------------------------------------
+// The property every parity claim rests on: the answer of a query is a function of the triangle set, never of the tree.  For that every point of
+// every triangle must be reachable: walking down from the root through the child boxes that contain the point has to arrive at a leaf slot that holds the
+// triangle.  With spatial splits a triangle has several references, each bounded by the part inside its cell: the check samples points on every triangle
+// (vertices, edge and interior points) and counts the points that no reference covers.  Decodes the nodes the way csrc/traverse.h does.
+extern "C" int rt_bvh8_selfcheck(const rt_scene_desc* scene, int samplesPerTri, uint64_t* out /* [8]: triangles, references, nodes, depth, spatial splits, uncovered points, points, 0 */,
+                                 double* outF /* [3]: SAH node steps, SAH triangle steps, build seconds */)
+{
+  if(!scene || !out || !outF) return -1;
+  rt::BuildOutput bo;
+  const auto t0 = std::chrono::steady_clock::now();
+  const int threads = std::max(1, int(std::thread::hardware_concurrency()));
+  if(!rt::buildBvh8(*scene, bo, threads)) return -2;
+  outF[2] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  outF[0] = bo.sahNodeSteps; outF[1] = bo.sahTriSteps;
+  const size_t n = bo.triRef.size();
+  // geometry by globalId (any reference of a triangle carries its full record)
+  std::vector<const rt::Tri48*> byId(n, nullptr);
+  for(const rt::Tri48& T : bo.tris) if(T.globalId < n) byId[T.globalId] = &T;
+  std::atomic<uint64_t> uncovered{0}, points{0};
+  std::atomic<size_t> next{0};
+  const int S = std::max(3, samplesPerTri);
+  auto worker = [&] {
+    std::vector<uint32_t> stack;
+    for(;;) {
+      const size_t g0 = next.fetch_add(1024);
+      if(g0 >= n) return;
+      for(size_t g = g0; g < std::min(n, g0 + 1024); g++) {
+        const rt::Tri48* T = byId[g];
+        if(!T) { uncovered += uint64_t(S); points += uint64_t(S); continue; }   // a triangle without any reference
+        uint32_t rng = uint32_t(g) * 2654435761u + 12345u;
+        for(int k = 0; k < S; k++) {
+          float u, v;
+          if(k == 0) { u = 0; v = 0; } else if(k == 1) { u = 1; v = 0; } else if(k == 2) { u = 0; v = 1; }
+          else {
+            rng = rng * 747796405u + 2891336453u; u = float(rng >> 8) * (1.0f / 16777216.0f);
+            rng = rng * 747796405u + 2891336453u; v = float(rng >> 8) * (1.0f / 16777216.0f);
+            if(u + v > 1.0f) { u = 1.0f - u; v = 1.0f - v; }
+            if(k % 3 == 0) v = 0.0f; else if(k % 3 == 1) u = 1.0f - v;   // two thirds of the random points on edges
+          }
+          const double p[3] = {double(T->v0x) + double(u) * T->e1x + double(v) * T->e2x, double(T->v0y) + double(u) * T->e1y + double(v) * T->e2y,
+                               double(T->v0z) + double(u) * T->e1z + double(v) * T->e2z};
+          bool found = false;
+          stack.clear(); stack.push_back(0u);
+          while(!stack.empty() && !found) {
+            const rt::Node8& N = bo.nodes[stack.back()]; stack.pop_back();
+            const double sx = std::ldexp(1.0, int(N.ex) - 127), sy = std::ldexp(1.0, int(N.ey) - 127), sz = std::ldexp(1.0, int(N.ez) - 127);
+            uint32_t rel = 0;
+            for(int s = 0; s < 8 && !found; s++) {
+              const bool inner = (N.imask >> s) & 1u;
+              const uint32_t myRel = rel; if(inner) rel++;
+              if(N.meta[s] == 0) continue;
+              const bool in = p[0] >= double(N.px) + N.qlox[s] * sx && p[0] <= double(N.px) + N.qhix[s] * sx && p[1] >= double(N.py) + N.qloy[s] * sy &&
+                              p[1] <= double(N.py) + N.qhiy[s] * sy && p[2] >= double(N.pz) + N.qloz[s] * sz && p[2] <= double(N.pz) + N.qhiz[s] * sz;
+              if(!in) continue;
+              if(inner) stack.push_back(N.childBase + myRel);
+              else {
+                const uint32_t cnt = uint32_t(__builtin_popcount(N.meta[s] >> 5)), off = N.meta[s] & 31u;
+                for(uint32_t q = 0; q < cnt; q++) if(bo.tris[N.triBase + off + q].globalId == uint32_t(g)) found = true;
+              }
+            }
+          }
+          points++;
+          if(!found) uncovered++;
+        }
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  for(int i = 0; i < threads; i++) pool.emplace_back(worker);
+  for(auto& t : pool) t.join();
+  out[0] = n; out[1] = bo.tris.size(); out[2] = bo.nodes.size(); out[3] = uint64_t(bo.maxDepth); out[4] = bo.spatialSplits; out[5] = uncovered.load(); out[6] = points.load(); out[7] = 0;
+  return 0;
+}

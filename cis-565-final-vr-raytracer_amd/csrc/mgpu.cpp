@@ -38,6 +38,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -139,6 +140,8 @@ struct rt_mgpu {
   int balanceFrames = 0;               // frames balanced since the partition was last reset
   bool haveHistory = false, balance = true, serialize = false, gatherResults = true, pipeline = true;
   int solo = -1;
+  bool corruptHalo = false;            // test hook (RESTIR_TEST_CORRUPT_HALO=1): the first bytes of every pulled noisy-direct-colour halo are overwritten, so the
+                                       // bench's tiled == untiled gate must report a mismatch (tests/test_gpu_bench_cli.py).  Never set outside tests.
   std::vector<uint8_t> peerOk;         // [puller rank * n + owner rank]: direct peer access from the puller's device to the owner's is enabled (rt_mgpu_create)
   int64_t seq = 0; int lastFrames = -2; bool pipeActive = false;
   int histHalo = HIST_HALO_MIN; uint32_t fallbacksSeen = 0; int calmFrames = 0; bool lastDenoise = false;
@@ -228,6 +231,8 @@ void pullRowsOn(rt_mgpu& M, Rank& R, hipStream_t strm, int buf, int a, int b, co
     else MG_HIP(hipMemcpyPeerAsync(static_cast<char*>(dst) + off, R.dev, static_cast<char*>(src) + off, Q.dev, len, strm), "hipMemcpyPeerAsync");
     (R.accSlot >= 0 ? R.pulledBy[R.accSlot] : R.pulled)[kind] += len;
     if(R.grp >= 0) R.grpBytes[R.grpSlot][R.grp] += len;
+    if(M.corruptHalo && kind == HK_FILTER && (buf == RT_BUF_DIRECT_RESULT0 || buf == RT_BUF_DIRECT_RESULT1))
+      MG_HIP(hipMemsetAsync(static_cast<char*>(dst) + off, 0x3f, std::min<size_t>(len, 1024), strm), "hipMemsetAsync (test hook)");
   }
 }
 void pullRows(rt_mgpu& M, Rank& R, int buf, int a, int b, const std::vector<int>& part, int kind) { pullRowsOn(M, R, R.stream, buf, a, b, part.data(), kind); }
@@ -403,8 +408,10 @@ void harvestTiming(Rank& R, int64_t seq)
   if(hipEventElapsedTime(&c, t[4], t[5]) == hipSuccess && hipEventElapsedTime(&d, t[6], t[7]) == hipSuccess) R.filterMs = c + d;
   for(int g = 0; g < Rank::LG_COUNT; g++) {
     float ms = 0.f;
-    R.linkBytes[g] = R.grpBytes[seq % RING][g];
-    R.linkMs[g] = (R.linkBytes[g] && hipEventElapsedTime(&ms, R.tl[seq % RING][2 * g], R.tl[seq % RING][2 * g + 1]) == hipSuccess) ? ms : 0.f;
+    const uint64_t bytes = R.grpBytes[seq % RING][g];
+    if(!bytes) { R.linkBytes[g] = 0; R.linkMs[g] = 0.f; continue; }
+    // bytes and milliseconds are reported as a PAIR of one frame: when the events of this frame are not ready (or unreadable) the previous pair stands
+    if(hipEventElapsedTime(&ms, R.tl[seq % RING][2 * g], R.tl[seq % RING][2 * g + 1]) == hipSuccess) { R.linkBytes[g] = bytes; R.linkMs[g] = ms; }
   }
 }
 // bracket a group of pulls on `strm` for the link statistics
@@ -740,8 +747,12 @@ void beginCall(rt_mgpu* M)
   M->err.clear();
 }
 
+// the balancer starts over: the smoothed per-rank times were measured on bands that no longer exist (a stale rankMs would steer the first diffusion steps)
+void resetBalancer(rt_mgpu* M) { M->balanceFrames = 0; M->rankMs.clear(); M->boundaryCool.clear(); }
+
 void equalBands(rt_mgpu* M)
 {
+  resetBalancer(M);
   const int stripes = (M->H + 15) / 16;
   M->bands.assign(size_t(M->n) + 1, 0);
   for(int r = 0; r <= M->n; r++) M->bands[size_t(r)] = std::min(M->H, 16 * int((int64_t(stripes) * r + M->n - 1) / M->n));
@@ -847,6 +858,7 @@ int rt_mgpu_create(rt_mgpu** out, int numRanks, const int* devices)
   rt_mgpu* M = new(std::nothrow) rt_mgpu();
   if(!M) return RT_ERR_OOM;
   M->n = numRanks;
+  if(const char* e = getenv("RESTIR_TEST_CORRUPT_HALO")) M->corruptHalo = e[0] == '1';
   M->ranks = std::vector<Rank>(size_t(numRanks));
   auto bail = [&](int rc) { for(Rank& R : M->ranks) destroyRank(R); delete M; return rc; };
   for(int r = 0; r < numRanks; r++) {
@@ -918,6 +930,7 @@ int rt_mgpu_upload_scene(rt_mgpu* M, const rt_scene_desc* d)
   M->desc = d;
   const int rc = dispatch(M, Cmd::UPLOAD);
   M->desc = nullptr; M->haveHistory = false;
+  resetBalancer(M); M->stripeCost.clear();   // another scene: another cost per stripe
   return rc;
 }
 
@@ -975,6 +988,8 @@ int rt_mgpu_render_frame(rt_mgpu* M, const rt_state* st, int frames)
     rc = firstError(M);
   } else {
     rc = dispatch(M, Cmd::FRAME, &c);
+    // the barrier schedule does not bracket its pulls: rt_mgpu_get_link_stats reports zeros rather than the pair of some earlier pipelined frame
+    for(Rank& R : M->ranks) for(int g = 0; g < Rank::LG_COUNT; g++) { R.linkMs[g] = 0.f; R.linkBytes[g] = 0; }
   }
   M->lastFrames = frames;
   // statistics of the latest finished frame, then the partition of the next one
@@ -1009,6 +1024,7 @@ int rt_mgpu_sync(rt_mgpu* M)
 int rt_mgpu_set_balance(rt_mgpu* M, int mode)
 {
   if(!M || mode < 0 || mode > 2) return RT_ERR_INVALID_ARG;
+  if(mode == 1 && !M->balance) resetBalancer(M);   // (re-enabled after a freeze: the times of the frozen partition are kept only if the balancer never stopped)
   M->balance = mode == 1;
   if(mode == 0 && M->H) { equalBands(M); /* the next frame pulls what moved through the history exchange */ }
   return RT_OK;   // mode 2: keep the partition as it is now
@@ -1022,6 +1038,7 @@ int rt_mgpu_set_bands(rt_mgpu* M, const int* bands)
   for(int r = 0; r < M->n; r++) if(bands[r + 1] <= bands[r] || (bands[r] & 15)) return RT_ERR_INVALID_ARG;
   M->bands.assign(bands, bands + M->n + 1);
   M->balance = false;
+  resetBalancer(M);
   return RT_OK;
 }
 int rt_mgpu_set_serialize(rt_mgpu* M, int on) { if(!M) return RT_ERR_INVALID_ARG; M->serialize = on != 0; return RT_OK; }

@@ -48,7 +48,8 @@ struct rt_ctx {
   std::vector<void*> sceneAllocs, accelAllocs, ovfAllocs;
   DevScene ds{};
   bool haveScene = false, haveAccel = false;
-  int maxDepth = 0; size_t numNodes = 0, numTris = 0;
+  int maxDepth = 0; size_t numNodes = 0, numTris = 0, numRefs = 0, spatialSplits = 0;
+  double sahNodeSteps = 0, sahTriSteps = 0;
   // screen-space buffers
   int W = 0, H = 0;
   void* bufs[RT_BUF_COUNT] = {};
@@ -500,8 +501,12 @@ static int buildHostAccel(rt_ctx* c, HostAccel& out)
   std::vector<AlphaRec>& alpha = out.alpha; alpha.assign(1, AlphaRec{});
   std::vector<int32_t>& alphaTex = out.alphaTex; alphaTex.assign(1, -1);
   std::map<std::array<uint32_t, 12>, std::array<uint32_t, 4>> ommCache;
+  std::vector<uint32_t> alphaOf;   // by globalId: the record of a triangle that has several references (spatial splits) is made once
+  if(bo.tris.size() > bo.triRef.size()) alphaOf.assign(bo.triRef.size(), 0u);
+  std::vector<std::array<uint32_t, 4>> ommOf;
   for(Tri48& T : bo.tris) {
     if(T.flags & TRI_OPAQUE) continue;
+    if(!alphaOf.empty() && alphaOf[T.globalId]) { T.alphaIdx = alphaOf[T.globalId]; memcpy(T.omm, ommOf[T.alphaIdx].data(), sizeof(T.omm)); continue; }
     const TriRef ref = bo.triRef[T.globalId];
     const rt_prim_mesh& pm = c->primMeshes[c->instances[ref.inst].primMesh];
     const rt_material& m = c->materials[size_t(pm.materialIndex > 0 ? pm.materialIndex : 0)];
@@ -529,6 +534,7 @@ static int buildHostAccel(rt_ctx* c, HostAccel& out)
       it = ommCache.emplace(key, o).first;
     }
     memcpy(T.omm, it->second.data(), sizeof(T.omm));
+    if(!alphaOf.empty()) { alphaOf[T.globalId] = T.alphaIdx; ommOf.resize(alpha.size()); ommOf[T.alphaIdx] = it->second; }
   }
   return RT_OK;
 }
@@ -581,7 +587,8 @@ int rt_build_accel(rt_ctx* c)
   c->ds.triPad = bo.pad;
   { const char* e = getenv("RESTIR_COOP"); c->ds.coopLive = e ? std::max(0, std::min(64, atoi(e))) : 4; }
   { const char* e = getenv("RESTIR_GANG"); c->ds.gangMax = e ? std::max(0, std::min(7, atoi(e))) : 4; }   // latency build: gang mode for the last rays of a wave (traverse.h)
-  c->numNodes = bo.nodes.size(); c->numTris = bo.tris.size(); c->maxDepth = bo.maxDepth;
+  c->numNodes = bo.nodes.size(); c->numTris = bo.triRef.size(); c->maxDepth = bo.maxDepth;
+  c->numRefs = bo.tris.size(); c->spatialSplits = size_t(bo.spatialSplits); c->sahNodeSteps = bo.sahNodeSteps; c->sahTriSteps = bo.sahTriSteps;
   RT_HIP(c, hipDeviceSynchronize());
   c->haveAccel = true;
   return ensureStackOverflow(c);
@@ -1057,6 +1064,18 @@ int rt_accel_stats(rt_ctx* c, uint64_t* numNodes, uint64_t* numTris, int* maxDep
   if(numNodes) *numNodes = c->numNodes;
   if(numTris) *numTris = c->numTris;
   if(maxDepth) *maxDepth = c->maxDepth;
+  return RT_OK;
+}
+
+/* tree quality: leaf records (references: > triangles when spatial splits duplicated some), spatial splits taken, and the SAH expectation of node / triangle
+ * steps of a ray that hits the root box */
+int rt_accel_quality(rt_ctx* c, uint64_t* references, uint64_t* spatialSplits, double* sahNodeSteps, double* sahTriSteps)
+{
+  if(!c || !c->haveAccel) return RT_ERR_NO_ACCEL;
+  if(references) *references = c->numRefs;
+  if(spatialSplits) *spatialSplits = c->spatialSplits;
+  if(sahNodeSteps) *sahNodeSteps = c->sahNodeSteps;
+  if(sahTriSteps) *sahTriSteps = c->sahTriSteps;
   return RT_OK;
 }
 

@@ -1129,7 +1129,9 @@ __global__ __launch_bounds__(64) void k_denoise_lds(DevFrame F, rt_state st, con
           // with the general expression's own float operations, in its order.  A wave with a non-finite pixel takes the general path (scalar branch).
           const float dl = IND ? dot(color - color, color - color) : rt_abs(cC.w - cC.w);
 #ifndef RT_NO_CENTRE_SHORTCUT
-          if(__ballot((dl == 0.0f && dot(norm - norm, norm - norm) == 0.0f && dot(pos - pos, pos - pos) == 0.0f) ? 0 : 1) == 0ull) w = (((1.0f + 1e-2f) * 1.0f) * (1.0f + 1e-2f)) * kGauss[2][2];
+          // Only in the FAST instantiation: there every sigma has been checked to lie in [1e-6, 1e6] (uniformDivOk), so 0 / sigma = 0.  With sigma = 0 or NaN the
+          // general expression is 0 / 0 = NaN and the reference clears the pixel — that case must take the general path.
+          if(FAST && __ballot((dl == 0.0f && dot(norm - norm, norm - norm) == 0.0f && dot(pos - pos, pos - pos) == 0.0f) ? 0 : 1) == 0ull) w = (((1.0f + 1e-2f) * 1.0f) * (1.0f + 1e-2f)) * kGauss[2][2];
           else
 #endif
           w = denoisePairWeight<IND, FAST>(color, cC.w, norm, pos, color, cC.w, norm, pos, kGauss[2][2], sigLumin, sigNormal, sigDepth, yL, yN, yD);

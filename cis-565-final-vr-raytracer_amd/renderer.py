@@ -83,6 +83,7 @@ def hip_lib():
         L.rt_mgpu_last_error.argtypes = [C.c_void_p]; L.rt_mgpu_last_error.restype = C.c_char_p
         L.rt_mgpu_plan_bands.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.rt_accel_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+        L.rt_accel_quality.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _lib = L
     return _lib
 
@@ -251,7 +252,10 @@ class Renderer:
     def accel_stats(self):
         n, t, d = C.c_uint64(), C.c_uint64(), C.c_int()
         self._chk(hip_lib().rt_accel_stats(self._h, C.byref(n), C.byref(t), C.byref(d)), "rt_accel_stats")
-        return {"nodes": n.value, "triangles": t.value, "max_depth": d.value}
+        refs, sp, sn, stt = C.c_uint64(), C.c_uint64(), C.c_double(), C.c_double()
+        self._chk(hip_lib().rt_accel_quality(self._h, C.byref(refs), C.byref(sp), C.byref(sn), C.byref(stt)), "rt_accel_quality")
+        return {"nodes": n.value, "triangles": t.value, "max_depth": d.value, "references": refs.value, "spatial_splits": sp.value,
+                "sah_node_steps": round(sn.value, 3), "sah_tri_steps": round(stt.value, 3)}
 
 
 class MgpuStats(C.Structure):  # rt_mgpu_stats

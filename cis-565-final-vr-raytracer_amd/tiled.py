@@ -28,6 +28,7 @@ frame per neighbour; nothing is all-gathered in the steady state.  When a halo i
 images, many ranks) the exchange falls back to an in-place all-gather (allocations carry slack rows for that).
 """
 import math
+import os
 
 from . import abi
 
@@ -92,8 +93,9 @@ def halo_view(item, a, b, tensor=None):
 class Pending:
     """Works of one batched exchange plus the unpacking of its staged (strided / partial-width) receives.  wait() may be called once per consuming stream:
     the first call waits for the transfers and unpacks on the current stream, later calls (other streams) wait for that unpacking."""
-    def __init__(self, comm, works, unpack, keep=()):
+    def __init__(self, comm, works, unpack, keep=(), corrupt=()):
         self.comm, self.works, self.unpack, self.keep, self.event, self.done = comm, works, unpack, list(keep), None, False
+        self.corrupt = list(corrupt)   # test hook (RESTIR_TEST_CORRUPT_HALO): received views to damage once they have arrived
 
     def wait(self):
         if self.done:
@@ -106,6 +108,9 @@ class Pending:
                 src.record_stream(self.comm.torch.cuda.current_stream())   # staged on the posting stream, read here on the consumer's: the allocator must not
                                                                            # hand the block out again before this copy has run
             dst.copy_(src)
+        for v in self.corrupt:
+            v[:1, :64] = 0x3f
+        self.corrupt = []
         if self.comm.nccl and (self.works or self.unpack):   # a later wait on another stream orders that stream after transfer + unpacking
             self.event = self.comm.torch.cuda.Event(); self.event.record(self.comm.torch.cuda.current_stream())
         self.done, self.works, self.unpack, self.keep = True, [], [], []
@@ -206,6 +211,10 @@ class TorchComm:
         self._flag = torch.zeros(1, dtype=torch.int32, device="cuda" if self.nccl else "cpu")
         self._done = {}
         self.rx_bytes = dict.fromkeys(HALO_KINDS, 0)   # bytes this rank has received, by purpose (TiledFrame snapshots it per frame)
+        # Test hook for the bench's tiled == untiled gate (bench.py verify_*, tests/test_tiled_gloo.py): the first row of every received filter-halo segment is
+        # overwritten after it has arrived, so the gate must report a mismatch.  Never set outside tests.
+        self._corrupt = os.environ.get("RESTIR_TEST_CORRUPT_HALO") == "1"
+        self._rx_log = []
 
     # Every exchange is expressed on an arbitrary row partition `part` (world + 1 boundaries): rank q owns rows [part[q], part[q+1]).
     # A rank receives the rows it needs from whoever owns them and sends the rows others need from its own band — one batched
@@ -213,7 +222,8 @@ class TorchComm:
     # in-order matching of a group requires.  Bands may be narrower than a halo (a halo then spans several ranks).
     def _batch(self, ops, unpack, async_op):
         works = self.dist.batch_isend_irecv(ops) if ops else []
-        p = Pending(self, [w for w in works if w is not None], unpack, keep=[op.tensor for op in ops])   # packed send buffers live until the exchange is waited for
+        p = Pending(self, [w for w in works if w is not None], unpack, keep=[op.tensor for op in ops], corrupt=self._rx_log)   # packed send buffers live until the exchange is waited for
+        self._rx_log = []
         if not async_op:
             p.wait()
             return None
@@ -237,6 +247,8 @@ class TorchComm:
                 self.rx_bytes[item.kind or kind] += item.nbytes(a, b)
                 if P2P is None:
                     continue                                 # CountingComm: the accounting is all there is
+                if self._corrupt and (item.kind or kind) == "filter":
+                    self._rx_log.append(v)
                 if packed:
                     stage = self.torch.empty(v.shape, dtype=v.dtype, device=v.device)
                     unpack.append((v, stage))
@@ -308,7 +320,7 @@ class CountingComm(TorchComm):
     def __init__(self, rank, world):
         import torch
         self.torch, self.dist, self.group, self.rank, self.world, self.nccl = torch, None, None, rank, world, False
-        self._done = {}
+        self._done, self._corrupt, self._rx_log = {}, False, []
         self.rx_bytes = dict.fromkeys(HALO_KINDS, 0)
     def _batch(self, ops, unpack, async_op): return None
     def all_gather_floats(self, values): return [list(values) for _ in range(self.world)]

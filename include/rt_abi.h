@@ -466,7 +466,9 @@ int rt_mgpu_get_stats(rt_mgpu* m, rt_mgpu_stats* out);
 /* Link statistics of the latest complete frame of the frames-in-flight schedule (ABI 2.1): every rank's four pull groups — 0 history rows (main stream),
  * 1 indirect-reservoir history (indirect stream), 2 direct filter halo, 3 indirect filter halo (filter stream) — timed with HIP events on the stream that
  * carried them, and their bytes; the device of every rank; peerAccess[puller][owner] = 1 when the puller's device has direct peer access to the owner's
- * (xGMI on an MI355X node; 0 = staged by the runtime).  This is the measured point bench.py's xgmi_model stands in for on a one-GPU box. */
+ * (xGMI on an MI355X node; 0 = staged by the runtime).  This is the measured point bench.py's xgmi_model stands in for on a one-GPU box.
+ * pullBytes / pullMs of a group are a pair of ONE frame (a frame whose events cannot be read yet leaves the previous pair standing); the barrier schedule
+ * (rt_mgpu_set_pipeline(0), serialize, spatial modes) does not bracket its pulls: zeros. */
 typedef struct {
   int32_t numRanks;
   int32_t devices[RT_MGPU_MAX_RANKS];

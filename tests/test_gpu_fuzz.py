@@ -17,7 +17,7 @@ def _skip_case(rng):
     rng.choice([1.0, 0.5, 3.0]); rng.choice([0, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
     if env_kind != 1:
         rng.choice([5.0, 50.0, 1e4])
-    rng.choice([0.4, 0.05, 3.0, 1e-7]); rng.choice([1.0, 0.2, 2e6])
+    rng.choice([0.4, 0.05, 3.0, 1e-7, 0.0]); rng.choice([1.0, 0.2, 2e6])
     rng.integers(0, 2)
     if env_kind == 2:
         rng.uniform(0, 5); rng.normal(size=3); rng.uniform(-0.5, 0.5)
@@ -44,7 +44,7 @@ def run_sweep(cases, seed, first=0):
         st.hdrMultiplier = float(rng.choice([1.0, 0.5, 3.0])); st.debugging_mode = int(rng.choice([0, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9]))
         if env_kind != 1:
             st.environmentProb = 0.0 if env_kind == 0 else 0.5; st.fireflyClampThreshold = float(rng.choice([5.0, 50.0, 1e4])); st.envMapLuminIntegInv = 0.0
-        st.sigLuminDirect = float(rng.choice([0.4, 0.05, 3.0, 1e-7])); st.sigDepthIndirect = float(rng.choice([1.0, 0.2, 2e6]))
+        st.sigLuminDirect = float(rng.choice([0.4, 0.05, 3.0, 1e-7, 0.0])); st.sigDepthIndirect = float(rng.choice([1.0, 0.2, 2e6]))
         latency = bool(rng.integers(0, 2))
         desc = sc.desc(env)
         o = Oracle(0); o.upload_scene(desc); o.resize(W, H)
