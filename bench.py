@@ -178,6 +178,9 @@ def main():
                                                          "event-ordered peer pulls) instead of one process per GPU over RCCL; same JSON line plus the measured link time of every pull group")
     ap.add_argument("--devices", type=str, default="", help="--native: explicit device list, e.g. 0,1,2,3; a list with repeats (0,0) runs several ranks on one device — a functional check "
                                                             "of the host (tests/test_gpu_bench_cli.py), reported with n_gpus = the number of DISTINCT devices")
+    ap.add_argument("--verify-frames", type=int, default=3, help="N > 1: frames of the tiled == untiled gate after the timed region (0 = skip the gate; the line then says so)")
+    ap.add_argument("--single-host", action="store_true", help="N > 1 without --native: time the RCCL host only (default: rank 0 then also runs the native host in a child process and "
+                                                                "reports both, the faster as `value`)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -212,7 +215,24 @@ def main():
         import datetime
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this host driver
         # a stuck exchange should end the run with an error instead of hanging it
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"), timeout=datetime.timedelta(seconds=300))
+        try:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"), timeout=datetime.timedelta(seconds=300))
+            probe = torch.ones(1, device="cuda")
+            dist.all_reduce(probe)                       # the first collective builds the communicator: a broken fabric / IPC setup fails HERE, not in the timed region
+            if int(probe.item()) != world:
+                raise RuntimeError(f"all_reduce over {world} ranks returned {probe.item()}")
+        except Exception as e:   # noqa: BLE001 — whatever RCCL raises: the run must still produce a line
+            # RCCL could not be brought up: say so with what a maintainer needs (devices, peer access) and fall through to the native host, which needs no
+            # process group (one process, hipMemcpyPeerAsync).  Ranks other than 0 leave: the native host is rank 0's process.
+            devs = [torch.cuda.get_device_name(i) for i in range(torch.cuda.device_count())]
+            print(f"[bench rank {rank}] RCCL init failed: {e!r}; visible devices: {devs}; peer access: {peer_matrix(torch, args.gpus)}", file=sys.stderr, flush=True)
+            try:
+                dist.destroy_process_group()
+            except Exception:   # noqa: BLE001
+                pass
+            if rank != 0:
+                return None
+            return native_world(args, abi, host, Renderer, torch, extra={"rccl": f"failed: {e!r}"[:300]})
 
     cfg = CONFIGS[args.config]
     W, H = args.width or cfg["size"][0], args.height or cfg["size"][1]
@@ -272,6 +292,7 @@ def main():
 
     f = 0
     band_plan = None
+    last_band_ms = -1.0
     if world > 1 and not args.equal_bands and os.environ.get("RESTIR_EQUAL_BANDS", "0") != "1":
         # Cost-weighted band heights (SURVEY 8(e) "expected scaling limit"), planned before the warm-up: a few rounds of {two real
         # frames, every rank times its band's two traced stages launched alone, the times are gathered, the boundaries move}.  The
@@ -297,12 +318,13 @@ def main():
             return e0.elapsed_time(e1) / 2.0
 
         for _ in range(args.band_rounds):
-            band_plan = frame.rebalance(band_ms(), smoothing=0.6, max_move=6)
+            last_band_ms = band_ms()
+            band_plan = frame.rebalance(last_band_ms, smoothing=0.6, max_move=6)
         # A band's time is not the sum of its stripes' costs (a band with horizon rows takes what its slowest tile takes): the cost model settles with the
         # slowest rank ~1.35x the fastest.  From there the boundaries diffuse, one stripe per round; the partition with the shortest slowest rank is kept.
         seen = []
         for _ in range(args.diffuse_rounds if args.band_rounds > 0 else 0):
-            ms = band_ms()
+            ms = last_band_ms = band_ms()
             worst = max(a[0] for a in frame.comm.all_gather_floats([ms]))   # (the same gathered numbers on every rank)
             seen.append((worst, list(frame.part)))
             new, _spread = frame.diffuse(ms)
@@ -310,7 +332,7 @@ def main():
             if new == seen[-1][1]:
                 break
         if seen:
-            ms = band_ms()
+            ms = last_band_ms = band_ms()
             worst = max(a[0] for a in frame.comm.all_gather_floats([ms]))
             seen.append((worst, list(frame.part)))
             best = min(seen, key=lambda t: t[0])[1]
@@ -328,6 +350,7 @@ def main():
         step(f); f += 1
     fence()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -515,11 +538,135 @@ def main():
                                "screen_bytes": round(b_screen), "traversal_bytes": round(b_trav), "launch_ms": round(dur_ms, 4)}
         except Exception as e:  # the headline number must not depend on this extra pass
             out["roofline"] = {"bound": None, "error": repr(e)}
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+    if world > 1 and frame is not None:
+        # ---- what the first real multi-device run should tell (it runs once, on a node nobody sees): per-rank bands and times, the peer-access matrix, and the
+        #      tiled == untiled gate (restir_amd/verify.py): a short sequence rendered twice from a cold history, tiled on the timed partition and untiled on rank 0
+        per_rank = comm.all_gather_floats([float(frame.y0), float(frame.y1), float(last_band_ms), elapsed_local / args.steps * 1e3, float(frame.history_fallbacks)])
+        ver = None
+        if args.verify_frames > 0 and not args.profile_run:
+            ver = verify_rccl(args, abi, tiled, torch, Renderer, comm, Frame, r, list(frame.part), scene, (eye0, center0, up0, fov0), st, desc, W, H, orbit, rank, local_rank)
+        if rank == 0 and out is not None:
+            out["rccl_ranks"] = world
+            out["rccl"] = "ok"
+            out["peer_access"] = peer_matrix(torch, world)
+            out["rank_report"] = [{"rank": q, "rows": [int(v[0]), int(v[1])], "traced_stages_alone_ms": (round(v[2], 4) if v[2] >= 0 else None),
+                                   "ms_per_step_local": round(v[3], 4), "history_fallbacks": int(v[4])} for q, v in enumerate(per_rank)]
+            attach_verdict(out, ver)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        if world > 1 and not args.single_host and not args.profile_run and os.environ.get("RESTIR_BENCH_BOTH", "1") != "0":
+            out = both_hosts(args, out)     # the driver never passes --native: time that host too (child process) and report the faster verified one
+        print(json.dumps(out), flush=True)
+        if world > 1 and out.get("tiled_equals_untiled") is False:
+            raise SystemExit(3)             # a number for a wrong image is not a result
+
+
+def peer_matrix(torch, n):
+    """torch.cuda.can_device_access_peer for the first n devices (1 on the diagonal)"""
+    k = min(n, torch.cuda.device_count())
+    return [[1 if a == b else int(torch.cuda.can_device_access_peer(a, b)) for b in range(k)] for a in range(k)]
+
+
+def attach_verdict(out, ver):
+    """top-level verdict fields of the tiled == untiled gate"""
+    if not ver:
+        out["tiled_equals_untiled"] = None
+        out["verify"] = {"skipped": "--verify-frames 0 or --profile-run"}
+        return
+    out["verify"] = ver
+    out["tiled_equals_untiled"] = bool(ver["workload"]["equal"])
+    if "moving_camera" in ver:     # informational: the history halos / the exact fallback under camera motion (the timed workload is the static camera)
+        out["tiled_equals_untiled_moving_camera"] = bool(ver["moving_camera"]["equal"])
+
+
+def verify_rccl(args, abi, tiled, torch, Renderer, comm, Frame, r, part, scene, pose, st, desc, W, H, orbit, rank, local_rank):
+    """COLLECTIVE (every rank calls it, outside the timed region).  For the workload's camera path — and, when that is static, also for the orbiting camera, which
+    exercises the history halos — render --verify-frames frames from a cold history row-tiled on the timed partition, gather every distributed buffer to rank 0,
+    render the same frames untiled on rank 0's device (a second context) and compare digests of all six buffers of the last frame."""
+    from restir_amd import verify as V
+    res = {}
+    modes = [("workload", orbit)] + ([] if orbit else [("moving_camera", True)])
+    for name, orb in modes:
+        cams = V.verify_cameras(scene, W, H, pose, orb, args.verify_frames)
+        torch.cuda.synchronize(); comm.barrier()
+        r.update(W, H)                                   # re-allocates and clears every screen buffer: cold history on every rank
+        be = tiled.RendererTensors(r)
+        fr, cur = V.render_tiled(Frame, be, comm, W, H, part, cams, st, r.set_camera)
+        torch.cuda.synchronize()
+        if rank == 0:
+            td = V.digests(r.readback, cur)
+            ref = Renderer().setup(local_rank); ref.load_scene(desc); ref.update(W, H)
+            V.render_untiled(ref.run, ref.set_camera, cams, st); ref.sync()
+            ud = V.digests(ref.readback, cur); ref.destroy()
+            res[name] = dict(V.compare(td, ud), frames=len(cams), partition=list(part), history_fallbacks=int(fr.history_fallbacks),
+                             camera="orbiting 0.5 deg / frame" if orb else "static")
+        comm.barrier()
+    return res
+
+
+def verify_native(args, abi, m, r, bands, scene, pose, st, W, H, orbit):
+    """the same gate for the native context: m = MultiGpuRenderer (its readback assembles a buffer from the ranks that own its rows), r = a single-device Renderer"""
+    from restir_amd import verify as V
+    res = {}
+    part = [b[0] for b in bands] + [bands[-1][1]]
+    modes = [("workload", orbit)] + ([] if orbit else [("moving_camera", True)])
+    for name, orb in modes:
+        cams = V.verify_cameras(scene, W, H, pose, orb, args.verify_frames)
+        m.sync(); m.update(W, H); m.set_bands(part)     # cold history; rt_mgpu_resize falls back to equal bands: the timed partition again (frozen)
+        fb0 = int(m.stats().historyFallbacks)
+        cur = V.render_untiled(m.run, m.set_camera, cams, st); m.sync()
+        td = V.digests(m.readback, cur)
+        r.set_stream(0)                                  # (the roofline pass above bound the context to a torch stream: back to its own)
+        r.sync(); r.update(W, H)
+        V.render_untiled(r.run, r.set_camera, cams, st); r.sync()
+        ud = V.digests(r.readback, cur)
+        res[name] = dict(V.compare(td, ud), frames=len(cams), partition=part, history_fallbacks=int(m.stats().historyFallbacks) - fb0,
+                         camera="orbiting 0.5 deg / frame" if orb else "static")
+    return res
+
+
+def both_hosts(args, rccl_line):
+    """rank 0, after the RCCL host's run and the end of its process group: the native host (one process, hipMemcpyPeerAsync pulls, no host sync per stage) on the
+    same devices in a CHILD process (this one has RCCL and N idle peers' contexts around), both results in one line — `value` is the faster host whose tiled ==
+    untiled gate passed."""
+    import subprocess
+    keep = ["--gpus", str(args.gpus), "--native", "--steps", str(args.steps), "--warmup", str(args.warmup), "--config", str(args.config), "--scene-footprint", args.scene_footprint,
+            "--scale", str(args.scale), "--verify-frames", str(args.verify_frames)]
+    keep += (["--moving-camera"] if args.moving_camera else []) + (["--equal-bands"] if args.equal_bands else [])
+    keep += (["--width", str(args.width)] if args.width else []) + (["--height", str(args.height)] if args.height else [])
+    env = {k: v for k, v in os.environ.items() if not (k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE",
+                                                               "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS") or k.startswith(("TORCHELASTIC_", "NCCL_ASYNC", "TORCH_NCCL")))}
+    nat, err = None, None
+    try:
+        time.sleep(2.0)     # the other ranks are leaving: let their contexts go before the native host times anything
+        p = subprocess.run([sys.executable, os.path.abspath(__file__)] + keep, env=env, capture_output=True, text=True, timeout=1500)
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        if lines:
+            nat = json.loads(lines[-1])
+        if p.returncode != 0 or nat is None:
+            err = f"exit {p.returncode}: {(p.stderr or '').strip()[-400:]}"
+    except Exception as e:   # noqa: BLE001 — the RCCL line must survive whatever the child does
+        err = repr(e)
+
+    def summary(d):
+        return None if d is None else {"value": d.get("value"), "ms_per_step": d.get("ms_per_step"), "tiled_equals_untiled": d.get("tiled_equals_untiled"),
+                                       "tiled_equals_untiled_moving_camera": d.get("tiled_equals_untiled_moving_camera"), "history_fallbacks": d.get("history_fallbacks")}
+    hosts = {"rccl": summary(rccl_line), "native": summary(nat)}
+    if err:
+        hosts["native_error"] = err
+    ok = {k: d for k, d in (("rccl", rccl_line), ("native", nat)) if d is not None and d.get("value") and d.get("tiled_equals_untiled") is not False}
+    if not ok:
+        out = dict(rccl_line); out["host"] = "rccl"
+    else:
+        name = max(ok, key=lambda k: ok[k]["value"])
+        out = dict(ok[name]); out["host"] = name
+    out["hosts"] = hosts
+    out["rccl_ranks"] = rccl_line.get("rccl_ranks"); out["rccl"] = rccl_line.get("rccl", "ok")
+    out.setdefault("peer_access", rccl_line.get("peer_access"))
+    out["hosts_all_verified"] = all(h is not None and h.get("tiled_equals_untiled") is True for h in (hosts["rccl"], hosts["native"]))
+    return out
 
 
 def self_launch(args):
@@ -534,7 +681,7 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
-def native_world(args, abi, host, Renderer, torch):
+def native_world(args, abi, host, Renderer, torch, extra=None):
     """N > 1 through the native context: ONE process, one worker thread + rt_ctx + three streams per device, frames in flight per rank, every exchange a
     hipMemcpyPeerAsync pull ordered by events (csrc/mgpu.cpp) — the host round 3 optimised, on N REAL devices.  Same metric and JSON as the RCCL host."""
     from restir_amd.renderer import MultiGpuRenderer, LINK_GROUPS
@@ -622,6 +769,10 @@ def native_world(args, abi, host, Renderer, torch):
     out["links"] = lk
     if distinct < n:
         out["note"] = f"{n} ranks on {distinct} device(s): a functional check of the native host, NOT a benchmark result"
+    out["host"] = "native"
+    out["peer_access_runtime"] = peer_matrix(torch, torch.cuda.device_count())
+    if extra:
+        out.update(extra)
     # roofline of the dominant kernel of rank 0's band, launched alone on device 0 (same per-unit figures as the N = 1 line)
     try:
         y0, y1 = bands[0]
@@ -646,8 +797,18 @@ def native_world(args, abi, host, Renderer, torch):
                            "screen_bytes": round(b_screen), "traversal_bytes": round(b_trav), "launch_ms": round(dur_ms, 4)}
     except Exception as e:  # the headline number must not depend on this extra pass
         out["roofline"] = {"bound": None, "error": repr(e)}
+    # the tiled == untiled gate (restir_amd/verify.py), outside the timed region, on the partition that was timed
+    ver = None
+    if args.verify_frames > 0:
+        try:
+            ver = verify_native(args, abi, m, r, bands, scene, (eye0, center0, up0, fov0), st, W, H, orbit)
+        except Exception as e:   # noqa: BLE001
+            ver = {"workload": {"equal": False, "error": repr(e)}}
+    attach_verdict(out, ver)
     print(json.dumps(out), flush=True)
     m.destroy(); r.destroy()
+    if out.get("tiled_equals_untiled") is False:
+        raise SystemExit(3)                 # a number for a wrong image is not a result
     return None
 
 

@@ -239,8 +239,25 @@ static bool cuSplitRange(int which, int& lo, int& hi)
   lo = std::max(0, std::min(32, r[which][0])); hi = std::max(lo + 1, std::min(32, r[which][1]));
   return !(lo == 0 && hi == 32);
 }
-static hipError_t createStream(hipStream_t* s, int which, bool high)
+// Stream priorities of the frames-in-flight schedule.  RESTIR_PRIO = 0..3 (rounds 2-4: 0 none, 1 indirect + filter streams high, 2 indirect stream high — the
+// default —, 3 filter stream high) or three characters over {-, 0, +} for the main (direct stage) / indirect / filter stream: "+00" = main stream high, "0+-" =
+// indirect high and filters low.  level: -1 low, 0 normal, +1 high.
+static void prioSpec(int level[3])
 {
+  static int cached[3] = {0, 1, 0}; static bool have = false;
+  if(!have) {
+    have = true;
+    const char* e = getenv("RESTIR_PRIO");
+    if(e && strlen(e) == 3 && strspn(e, "-0+") == 3) { for(int i = 0; i < 3; i++) cached[i] = e[i] == '+' ? 1 : (e[i] == '-' ? -1 : 0); }
+    else if(e) { const int m = atoi(e); cached[0] = 0; cached[1] = (m == 1 || m == 2) ? 1 : 0; cached[2] = (m == 1 || m == 3) ? 1 : 0; }
+  }
+  for(int i = 0; i < 3; i++) level[i] = cached[i];
+}
+static hipError_t createStreamLevel(hipStream_t* s, int which, int level);
+static hipError_t createStream(hipStream_t* s, int which, bool high) { return createStreamLevel(s, which, high ? 1 : 0); }
+static hipError_t createStreamLevel(hipStream_t* s, int which, int level)
+{
+  const bool high = level > 0;
   int lo, hi;
   if(cuSplitRange(which, lo, hi)) {
     uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -249,6 +266,7 @@ static hipError_t createStream(hipStream_t* s, int which, bool high)
   }
   int plo = 0, phi = 0;
   (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
+  if(level < 0 && phi < plo) return hipStreamCreateWithPriority(s, hipStreamNonBlocking, plo);   // (numerically larger = lower priority)
   return (high && phi < plo) ? hipStreamCreateWithPriority(s, hipStreamNonBlocking, phi) : hipStreamCreateWithFlags(s, hipStreamNonBlocking);
 }
 
@@ -305,7 +323,8 @@ int rt_create(rt_ctx** out, int device)
   g_liveCtx.fetch_add(1);   // counted from here on: every exit below goes through rt_destroy, which un-counts it
   c->device = device;
   {
-    bool ok = createStream(&c->ownStream, 0, false) == hipSuccess;
+    int lvl[3]; prioSpec(lvl);
+    bool ok = createStreamLevel(&c->ownStream, 0, lvl[0]) == hipSuccess;
     if(!ok) { g_createErr = "rt_create: hipStreamCreate failed"; rt_destroy(c); return RT_ERR_HIP; }
     c->stream = c->ownStream;
     for(int i = 0; i < 4; i++) {
@@ -680,18 +699,15 @@ static void selectFrame(rt_ctx* c, int frames) { if(c->indA[0]) c->bufs[RT_BUF_D
 
 // The two extra streams of rt_render_frame's overlapped schedules, created on first use: a host that drives the stages itself (rt_run_stage on its own streams:
 // rt_mgpu, tiled.py) never needs them, and every stream of a process takes one of the device's few hardware queues (4 by default) out of the rotation.
-// Stream priorities of the frames-in-flight schedule (RESTIR_PRIO): 0 none, 1 ind + side high, 2 ind high (default: measured 2 % faster than 1, round 2),
-// 3 side high.  (Modes 4-7 of round 2 — main stream high — measured slower and needed the main stream created with a priority: removed.)
+// Stream priorities of the frames-in-flight schedule: prioSpec() above (RESTIR_PRIO).  Default: indirect stream high (measured 2 % faster than indirect + filter
+// streams high on the lite config 4, round 2).
 static hipError_t ensureOverlapStreams(rt_ctx* c)
 {
   if(c->sideStream && c->indStream) return hipSuccess;
-  int lo = 0, hi = 0;
-  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-  static const int mode = getenv("RESTIR_PRIO") ? atoi(getenv("RESTIR_PRIO")) : 2;
-  const bool can = hi < lo;
+  int lvl[3]; prioSpec(lvl);
   hipError_t e = hipSuccess;
-  if(!c->sideStream) e = createStream(&c->sideStream, 2, can && (mode == 1 || mode == 3));
-  if(e == hipSuccess && !c->indStream) e = createStream(&c->indStream, 1, can && (mode == 1 || mode == 2));
+  if(!c->sideStream) e = createStreamLevel(&c->sideStream, 2, lvl[2]);
+  if(e == hipSuccess && !c->indStream) e = createStreamLevel(&c->indStream, 1, lvl[1]);
   return e;
 }
 

@@ -282,3 +282,51 @@ def test_diffuse_bands_rule():
         part = tiled.diffuse_bands(part, ms(part)); best = min(best, max(ms(part)))
         assert part[0] == 0 and part[-1] == 1080 and all(b - a >= 16 and a % 16 == 0 for a, b in zip(part[:-1], part[1:-1] + [1088]))
     assert best < 0.8 * start
+
+
+# ---- the tiled == untiled gate of bench.py --gpus N (restir_amd/verify.py) over gloo, oracle as the backend ---------------------------------------------------
+def _verify_worker(rank, world, port, outdir, pipelined, corrupt):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if corrupt:
+        os.environ["RESTIR_TEST_CORRUPT_HALO"] = "1"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import json
+    from restir_amd import tiled, verify as V
+    sc, env, st, o = _setup()
+    comm = tiled.TorchComm()
+    res = {}
+    for name, orbit in (("workload", False), ("moving_camera", True)):
+        cams = V.verify_cameras(sc, W, H, sc.cameraPose(), orbit, 3)
+        o.resize(W, H)                                                    # cold history, like Renderer.update in the bench
+        fr, cur = V.render_tiled(tiled.PipelinedTiledFrame if pipelined else tiled.TiledFrame, OracleTensors(o), comm, W, H, UNEVEN[world], cams, st, o.set_camera)
+        if rank == 0:
+            td = V.digests(o.readback, cur)
+            from oracle.binding import Oracle
+            ref = Oracle(1); ref.upload_scene(sc.desc(env)); ref.resize(W, H)
+            V.render_untiled(ref.render_frame, ref.set_camera, cams, st)
+            res[name] = V.compare(td, V.digests(ref.readback, cur))
+        dist.barrier()
+    if rank == 0:
+        with open(os.path.join(outdir, "verdict.json"), "w") as fh:
+            json.dump(res, fh)
+    dist.barrier(); dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pipelined", [False, True], ids=["serial", "frames-in-flight"])
+def test_verify_gate(pipelined, tmp_path):
+    """bench.py's gate: digests of all six frame buffers of a tiled sequence equal the untiled ones (world 2, uneven bands, static and orbiting camera) ..."""
+    import json
+    mp.spawn(_verify_worker, args=(2, _free_port(), str(tmp_path), pipelined, False), nprocs=2, join=True)
+    res = json.load(open(os.path.join(tmp_path, "verdict.json")))
+    for name in ("workload", "moving_camera"):
+        assert res[name]["equal"] and len(res[name]["buffers"]) == 6, res[name]
+
+
+def test_verify_gate_catches_a_corrupted_halo(tmp_path):
+    """... and a damaged filter halo (the RESTIR_TEST_CORRUPT_HALO hook of tiled.TorchComm) is reported as a mismatch of the filtered images"""
+    import json
+    mp.spawn(_verify_worker, args=(2, _free_port(), str(tmp_path), False, True), nprocs=2, join=True)
+    res = json.load(open(os.path.join(tmp_path, "verdict.json")))
+    assert not res["workload"]["equal"]
+    assert not res["workload"]["buffers"]["direct_result0"]["equal"]
