@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """bench.py — BASELINE.json's metric on MI355X: Mrays/s and ms/frame of the ReSTIR DI+GI+denoise frame at 1920x1080 on the
 Bistro-Exterior-class scene (BASELINE.json configs[3]; the real asset is absent => seeded procedural stand-in, 2.8 M
-triangles, alpha-masked foliage, emissive lamps, synthetic HDR sky: `data: synthetic`).
+triangles, alpha-masked foliage, emissive lamps, synthetic HDR sky: `data: synthetic`; since round 5 with the asset's memory
+footprint — 147 materials, 3.4 GB of full-size BGRA8 textures, 16 distinct cut-out cards, long thin triangles; `--scene-footprint
+lite` is the cache-resident scene of rounds 1-4).
 
     python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
 
@@ -32,7 +34,9 @@ SCREEN_BYTES = {0: 124.0, 1: 204.0, 2: 192.0, 3: 240.0, 4: 68.0}
 # because it also carries the opacity micro-map, csrc/bvh8.h; the algorithmic figure stays the survey's), hit gathers, RIS candidate gathers
 NODE_B, TRI_B, HIT_B, RIS_B = 80, 48, 12 + 96 + 80, 16 + 96
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E
-DEFAULT_FOOTPRINT = "lite"
+# Round 5: the `real` footprint scenes are the default.  The headline moved by 52 % when the exterior stand-in got the memory footprint and triangle shapes of the
+# asset it stands in for (2.88 -> 4.39 ms per frame on one box, profiles/r05_real_vs_lite.txt): the number that describes a Bistro-class workload is the latter.
+DEFAULT_FOOTPRINT = "real"
 
 
 # SURVEY.md 8(d) configurations 2-5 (config 1 is the CPU-only plumbing case: tests/test_oracle.py).  The real assets are absent from the image: seeded procedural
@@ -178,6 +182,9 @@ def main():
                                                          "event-ordered peer pulls) instead of one process per GPU over RCCL; same JSON line plus the measured link time of every pull group")
     ap.add_argument("--devices", type=str, default="", help="--native: explicit device list, e.g. 0,1,2,3; a list with repeats (0,0) runs several ranks on one device — a functional check "
                                                             "of the host (tests/test_gpu_bench_cli.py), reported with n_gpus = the number of DISTINCT devices")
+    ap.add_argument("--stream-priorities", type=str, default="tune", help="N = 1: `tune` (default) = load-time tuning of the indirect / filter stream priorities "
+                    "(rt_tune_stream_priorities, outside the timed region, reported in the line), `default` = the library default (+1, 0), or `i,f` with levels -1 / 0 / +1; "
+                    "--profile-run uses the library default unless levels are given")
     ap.add_argument("--verify-frames", type=int, default=3, help="N > 1: frames of the tiled == untiled gate after the timed region (0 = skip the gate; the line then says so)")
     ap.add_argument("--single-host", action="store_true", help="N > 1 without --native: time the RCCL host only (default: rank 0 then also runs the native host in a child process and "
                                                                 "reports both, the faster as `value`)")
@@ -266,6 +273,19 @@ def main():
 
     eye0, center0, up0, fov0 = scene.cameraPose()
     scene.updateCamera(W, H)  # prime the camera history (static camera unless --moving-camera / config 5: SURVEY.md §8d)
+    prio_tuning = None
+    if world == 1 and not di_only:
+        # load-time choice of the stream priorities (round 5): which of the indirect / filter streams should be high or low depends on the workload
+        # (profiles/r05_prio_by_config_ab.txt); the tuner renders a few throw-away frames per setting and leaves the history cold — setup, like the BVH build
+        r.set_camera(scene.getCamera()); st.time = 999
+        if args.stream_priorities == "tune" and not args.profile_run:
+            t_tune = time.time()
+            prio_tuning = r.tune_stream_priorities(st, 8)
+            prio_tuning["seconds"] = round(time.time() - t_tune, 3)
+        elif "," in args.stream_priorities:
+            lv = [int(x) for x in args.stream_priorities.split(",")]
+            r.set_stream_priorities(lv[0], lv[1])
+            prio_tuning = {"chosen": lv, "ms_per_frame": None}
 
     def step(f):
         st.time = 1000 + f
@@ -407,6 +427,8 @@ def main():
                               "median over the frames of a separate pass; frame_latency_ms = first launch to last launch of one frame while frames are in flight")
         if sustained:
             out["sustained"] = sustained
+        if prio_tuning:
+            out["stream_priorities"] = prio_tuning
         if frame is not None:   # what rank 0 received for the last timed frame, by purpose (restir_amd/tiled.py accounting), and the exact fallbacks of the run
             out["halo_bytes_rank0"] = dict(frame.halo_bytes)
             out["history_fallbacks"] = int(frame.history_fallbacks)
@@ -467,6 +489,14 @@ def main():
         # command; FETCH_SIZE / WRITE_SIZE are in KiB; gfx950's FETCH_SIZE counts wide reads at half their size — MI355X_MICROARCH.md, HBM section — so it is
         # doubled; WRITE_SIZE is taken as reported).  Counters of another build or another workload are not used: the label is then null.
         t, pmc = pmc_entry(workload_key(args.config, orbit, footprint), kname)
+        frames_note = None
+        if t and orbit:
+            # a moving camera renders other work every frame: counters describe this line only if they were collected over the same frame indices
+            # (scripts/pmc.sh records them: `_frames`; entries of round 4 have none)
+            wf = ((pmc.get("workloads", {}).get(workload_key(args.config, orbit, footprint)) or {}).get("_frames") or {})
+            if wf.get("warmup") != args.warmup or wf.get("steps") != args.steps:
+                frames_note = f"the counter pass of this workload covers frames {wf.get('warmup')}..+{wf.get('steps')}, this line times frames {args.warmup}..+{args.steps} of a moving camera: counters withheld"
+                t = None
         out["roofline"]["traffic_lib"] = pmc.get("_lib_sha256_16") if pmc else None
         out["roofline"]["traffic_stale"] = bool(pmc) and pmc.get("_lib_sha256_16") != lib_sha256_16()
         sdur = None
@@ -501,6 +531,13 @@ def main():
         except Exception as e:  # the headline number must not depend on this extra pass
             out["roofline"]["valu"] = {"error": repr(e)}
         label_bound(out["roofline"], t, dur_ms, peak_mix, b_screen + b_trav)
+        if frames_note:
+            out["roofline"]["bound_evidence"] = frames_note
+        ff = (out["roofline"].get("valu") or {}).get("frame_frac")
+        if ff is not None and ff > 1.0:
+            # more instructions per second than the chip can issue: the counted instructions are not the timed work (round-4 verdict, weak 6) — no label
+            out["roofline"]["bound"] = None
+            out["roofline"]["bound_evidence"] = f"valu.frame_frac = {ff} > 1: the counter pass does not describe the timed frames; label withheld"
         if t and sdur:
             out["roofline"]["hbm_counter"]["serial_frac"] = round(out["roofline"]["traffic"] / (sdur * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
             if t.get("WRITE_SIZE_KB_full_lds_stack"):
@@ -980,18 +1017,21 @@ def emulate_world(args, abi, host, scene, env, st, desc, single, W, H, device):
 
 
 def cpu_baseline(abi, host, scene, env, st, desc, W, H, frame0, di_only=False):
-    """The CPU oracle (naive binary BVH + scalar C++, std::thread over all host cores) on a bounded sample that is THE SAME in every round: the full
-    12-dispatch frame (config 2: its direct stage) restricted to the 256 full-res rows around the image centre, cold temporal history, timed once after a
-    64-row warm-up band (threads, page cache, BVH in the host caches)."""
+    """The CPU oracle (naive binary BVH + scalar C++, std::thread workers) on bounded samples of the SAME frame, built to repeat (round-4 verdict, weak 7: four
+    driver runs gave 0.36 .. 1.12 Mrays/s): workers are pinned to the CPUs of the process's affinity mask, every point is the BEST of its passes (a pass can
+    only be slowed by whatever else the host runs, never sped up), and the rate is reported at three thread counts — 1, 32 and all — each on a band sized to
+    ~2-6 s of work (rows around the image centre, cold temporal history, the full 12-dispatch frame; config 2: its direct stage), with the per-thread rate and
+    the host's load average beside it.  `value` is the all-threads point."""
     from oracle.binding import Oracle
     o = Oracle(0)
     o.upload_scene(desc)
-    o.resize(W, H)
-    o.set_camera(scene.getCamera())
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    load0 = os.getloadavg()
     st.time = 1000 + frame0
 
     def band(y0, y1):
         h0, h1 = y0 // 2, y1 // 2
+        o.resize(W, H); o.set_camera(scene.getCamera())          # (re-allocates the screen buffers: cold history every pass)
         o.reset_counters()
         t0 = time.perf_counter()
         o.run_stage(st, frame0, abi.STAGE_DIRECT, 0, y0, y1)
@@ -1007,21 +1047,33 @@ def cpu_baseline(abi, host, scene, env, st, desc, W, H, frame0, di_only=False):
         return c.closestHitRays + c.anyHitRays, dt
 
     mid = (H // 2 // 16) * 16
-    band(max(0, mid - 32), min(H, mid + 32))                     # warm-up, 64 rows, not reported
-    y0, y1 = max(0, mid - 128), min(H, mid + 128)
-    # the same band, cold history each time, until >= 10 s of CPU work or 6 passes: a 256-thread pass of a few seconds moves by 2-3x with whatever else the
-    # host runs, so the MEDIAN pass is reported
-    passes, spent = [], 0.0
-    while len(passes) < 6 and (spent < 10.0 or len(passes) < 3):
-        o.resize(W, H); o.set_camera(scene.getCamera())          # (re-allocates the screen buffers: cold history again)
-        rays, dt = band(y0, y1)
-        passes.append((rays / dt, rays, dt)); spent += dt
-    passes.sort()
-    rate, rays, dt = passes[len(passes) // 2]
-    return {"value": round(rate / 1e6, 3), "unit": "Mrays/s", "cores": o.threads, "kind": "port",
-            "sample": f"rows {y0}..{y1} of one {W}x{H} frame ({'direct stage' if di_only else 'all 12 dispatches'}, cold temporal history), after a 64-row warm-up band; "
-                      f"median of {len(passes)} passes ({spent:.1f} s of CPU work, {passes[0][0] / 1e6:.3f}..{passes[-1][0] / 1e6:.3f} Mrays/s): "
-                      f"{rays} rays in {dt:.2f} s => {dt * H / max(1, y1 - y0) * 1e3:.0f} ms/frame extrapolated (fixed sample since round 3; rounds 1-2 used other bands)"}
+
+    def point(threads, rows, passes, budget_s):
+        """best of up to `passes` passes (at least 2, until budget_s is spent) over `rows` rows around the image centre"""
+        o.set_threads(threads, pin=True)
+        y0, y1 = max(0, mid - rows // 2), min(H, mid + rows // 2)
+        got, spent = [], 0.0
+        while len(got) < passes and (len(got) < 2 or spent < budget_s):
+            rays, dt = band(y0, y1)
+            got.append((rays / dt, rays, dt)); spent += dt
+        best = max(got)
+        return {"threads": threads, "rows": [y0, y1], "mrays_s": round(best[0] / 1e6, 4), "per_thread_mrays_s": round(best[0] / 1e6 / threads, 5), "passes": len(got),
+                "spread": [round(min(g[0] for g in got) / 1e6, 4), round(best[0] / 1e6, 4)], "rays": int(best[1]), "seconds_best": round(best[2], 3), "cpu_seconds": round(spent, 1)}
+
+    o.set_threads(min(ncpu, 32), pin=True)
+    band(max(0, mid - 16), min(H, mid + 16))                      # warm-up (page cache, BVH in the host caches), not reported
+    # rows per point: whole multiples of the thread count keep the dynamic row scheduler balanced (one thread per row leaves the slowest row as the pass time)
+    pts = [point(1, 8, 2 if not di_only else 3, 0.0), point(min(ncpu, 32), 64 if ncpu >= 32 else 32, 3, 5.0), point(ncpu, 256, 6, 10.0)]
+    allp = pts[-1]
+    load1 = os.getloadavg()
+    y0, y1 = allp["rows"]
+    return {"value": allp["mrays_s"], "unit": "Mrays/s", "cores": ncpu, "threads_used": allp["threads"], "per_thread": allp["per_thread_mrays_s"], "kind": "port",
+            "pinned": True, "statistic": "best pass of each point", "scaling": pts,
+            "parallel_efficiency_all_vs_1": round(allp["per_thread_mrays_s"] / max(1e-12, pts[0]["per_thread_mrays_s"]), 3),
+            "host_loadavg_before_after": [round(load0[0], 2), round(load1[0], 2)],
+            "sample": f"rows {y0}..{y1} of one {W}x{H} frame ({'direct stage' if di_only else 'all 12 dispatches'}, cold temporal history) on {allp['threads']} pinned threads: best of "
+                      f"{allp['passes']} passes ({allp['spread'][0]}..{allp['spread'][1]} Mrays/s), {allp['rays']} rays in {allp['seconds_best']:.2f} s => "
+                      f"{allp['seconds_best'] * H / max(1, y1 - y0) * 1e3:.0f} ms/frame extrapolated; 1-thread and 32-thread points on 8 / 64 centre rows in `scaling`"}
 
 
 if __name__ == "__main__":

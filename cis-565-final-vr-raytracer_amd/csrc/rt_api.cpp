@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <map>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -30,6 +31,8 @@ struct rt_ctx {
   hipEvent_t evD[4] = {}, evI[4] = {}, evDone[4] = {};
   uint64_t seq = 0;          // frames submitted through the pipelined path since the last join
   bool inFlight = false;     // work may be pending on indStream / sideStream
+  int prio[3] = {0, 1, 0};   // priority level of the main / indirect / filter stream (-1 low, 0 normal, +1 high): prioSpec() at rt_create, rt_set_stream_priorities, rt_tune_stream_priorities
+  bool prioFromEnv = false;  // RESTIR_PRIO was set: the tuner leaves the streams alone (A/B scripts stay in control)
   void* dSky = nullptr;      // SkyPre (csrc/sky.h), valid while sunAndSky.in_use == 1
   void* dPick = nullptr;     // rt_pick_result written by k_pick
   rt_sun_and_sky sunAndSky{};
@@ -323,8 +326,8 @@ int rt_create(rt_ctx** out, int device)
   g_liveCtx.fetch_add(1);   // counted from here on: every exit below goes through rt_destroy, which un-counts it
   c->device = device;
   {
-    int lvl[3]; prioSpec(lvl);
-    bool ok = createStreamLevel(&c->ownStream, 0, lvl[0]) == hipSuccess;
+    prioSpec(c->prio); c->prioFromEnv = getenv("RESTIR_PRIO") != nullptr;
+    bool ok = createStreamLevel(&c->ownStream, 0, c->prio[0]) == hipSuccess;
     if(!ok) { g_createErr = "rt_create: hipStreamCreate failed"; rt_destroy(c); return RT_ERR_HIP; }
     c->stream = c->ownStream;
     for(int i = 0; i < 4; i++) {
@@ -704,10 +707,9 @@ static void selectFrame(rt_ctx* c, int frames) { if(c->indA[0]) c->bufs[RT_BUF_D
 static hipError_t ensureOverlapStreams(rt_ctx* c)
 {
   if(c->sideStream && c->indStream) return hipSuccess;
-  int lvl[3]; prioSpec(lvl);
   hipError_t e = hipSuccess;
-  if(!c->sideStream) e = createStreamLevel(&c->sideStream, 2, lvl[2]);
-  if(e == hipSuccess && !c->indStream) e = createStreamLevel(&c->indStream, 1, lvl[1]);
+  if(!c->sideStream) e = createStreamLevel(&c->sideStream, 2, c->prio[2]);
+  if(e == hipSuccess && !c->indStream) e = createStreamLevel(&c->indStream, 1, c->prio[1]);
   return e;
 }
 
@@ -1071,6 +1073,54 @@ int rt_set_overlap(rt_ctx* c, int mode)
   c->overlap = mode;
   if((mode == 2) != hadShort) return ensureStackOverflow(c);   // the short LDS stacks of frames in flight spill into an HBM area that serial schedules do not hold
   return RT_OK;
+}
+
+/* Priorities of the indirect and the filter stream of the frames-in-flight schedule (levels -1 low, 0 normal, +1 high; the main stream keeps the level it was
+ * created with).  Which setting is fastest depends on the workload — where the filter chain is the critical path (cheap traced stages: configs 3 and 5) the
+ * filter stream wants to be high, where traversal dominates (the real-footprint exterior scene) it wants to be LOW, profiles/r05_prio_by_config_ab.txt — so the
+ * library offers the knob and a tuner instead of one compiled-in answer.  Results are identical under every setting. */
+int rt_set_stream_priorities(rt_ctx* c, int indirectLevel, int filterLevel)
+{
+  if(!c || indirectLevel < -1 || indirectLevel > 1 || filterLevel < -1 || filterLevel > 1) return RT_ERR_INVALID_ARG;
+  RT_HIP(c, hipSetDevice(c->device));
+  RT_HIP(c, syncAll(c));
+  if(c->prio[1] == indirectLevel && c->prio[2] == filterLevel) return RT_OK;
+  if(c->indStream) { (void)hipStreamDestroy(c->indStream); c->indStream = nullptr; }
+  if(c->sideStream) { (void)hipStreamDestroy(c->sideStream); c->sideStream = nullptr; }
+  c->prio[1] = indirectLevel; c->prio[2] = filterLevel;
+  return RT_OK;   // (the streams are created on first use: ensureOverlapStreams)
+}
+
+/* One-time tuning at load time (like the BVH build: before the first frame, outside any timed region): renders `framesPerCandidate` frames in flight under each
+ * candidate setting with the CURRENT camera and `state`, keeps the fastest, and leaves every screen-space buffer as rt_resize left it (cold history), so the frames
+ * that follow are the frames of a context that was never tuned.  chosen[0..1] = the levels kept, msPerFrame[0..4] = the measured period of each candidate
+ * (order: {+1,0}, {+1,+1}, {0,+1}, {0,-1}, {+1,-1}; 0 = not measured).  With RESTIR_PRIO set in the environment the call measures nothing and reports that setting. */
+int rt_tune_stream_priorities(rt_ctx* c, const rt_state* st, int framesPerCandidate, int* chosen, float* msPerFrame)
+{
+  int rc = checkReady(c, st);
+  if(rc) return rc;
+  static const int cand[5][2] = {{1, 0}, {1, 1}, {0, 1}, {0, -1}, {1, -1}};
+  if(msPerFrame) for(int i = 0; i < 5; i++) msPerFrame[i] = 0.f;
+  if(c->prioFromEnv || c->overlap != 2 || framesPerCandidate < 2) { if(chosen) { chosen[0] = c->prio[1]; chosen[1] = c->prio[2]; } return RT_OK; }
+  RT_HIP(c, hipSetDevice(c->device));
+  const int W = c->W, H = c->H;
+  rt_state s = *st;
+  int best = 0; double bestMs = 1e30;
+  int f = 0;
+  for(int i = 0; i < 5; i++) {
+    if((rc = rt_set_stream_priorities(c, cand[i][0], cand[i][1]))) return rc;
+    for(int k = 0; k < 3; k++) { s.time = 7000 + f; if((rc = rt_render_frame(c, &s, f))) return rc; f++; }   // fill the pipeline (and, first candidate, warm the caches)
+    RT_HIP(c, syncAll(c));
+    const auto t0 = std::chrono::steady_clock::now();
+    for(int k = 0; k < framesPerCandidate; k++) { s.time = 7000 + f; if((rc = rt_render_frame(c, &s, f))) return rc; f++; }
+    RT_HIP(c, syncAll(c));
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / framesPerCandidate;
+    if(msPerFrame) msPerFrame[i] = float(ms);
+    if(ms < bestMs * 0.99) { bestMs = ms; best = i; }      // (a later candidate must win by 1 %: the default stays on a tie)
+  }
+  if((rc = rt_set_stream_priorities(c, cand[best][0], cand[best][1]))) return rc;
+  if(chosen) { chosen[0] = cand[best][0]; chosen[1] = cand[best][1]; }
+  return rt_resize(c, W, H);   // cold history again: the tuning frames leave no trace
 }
 
 /* extra introspection used by bench.py / DESIGN.md numbers (not part of the reference-facing surface) */

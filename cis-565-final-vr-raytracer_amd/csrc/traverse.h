@@ -574,6 +574,9 @@ RT_DEV bool traceRay(const DevScene& S, f3 o, f3 d, float tmax, uint32_t raySeed
 // slots are compacted into a work list, and every lane — dead or alive — pulls the next ray whenever its current one
 // finishes.  Results come back through the same slots.  A ray's result does not depend on the lane that traced it (the
 // HitTest RNG is keyed by ray seed and triangle id), so the frame is unchanged bit for bit.
+#ifndef RT_POOL_ORDER
+#define RT_POOL_ORDER 0
+#endif
 constexpr int POOL_SLOT_F4 = 2;                 // 32 B per slot: ray (o.xyz, d.x | d.yz, tmax, seed) then result (t, gid, u, v)
 constexpr int POOL_BYTES = 128 * 32 + 128;      // 128 slots + the work list (u8 slot ids)
 
@@ -599,8 +602,15 @@ RT_DEV void tracePool(const DevScene& S, float4* pool, bool hasC, bool hasS, uin
   const unsigned long long mC = __ballot(hasC ? 1 : 0), mS = __ballot(hasS ? 1 : 0);
   const int nC = __popcll(mC), n = nC + __popcll(mS);
   if(n == 0) return;
+#if RT_POOL_ORDER & 2
+  // experiment (round 5, profiles/r05_pool_order_ab.txt): the shadow rays first — they end at their first accepted hit — then the bounce rays
+  const int nS = n - nC;
+  if(hasS) list[__popcll(mS & lt)] = (unsigned char)(lane * 2 + 1);
+  if(hasC) list[nS + __popcll(mC & lt)] = (unsigned char)(lane * 2);
+#else
   if(hasC) list[__popcll(mC & lt)] = (unsigned char)(lane * 2);
   if(hasS) list[nC + __popcll(mS & lt)] = (unsigned char)(lane * 2 + 1);
+#endif
   waveLdsSync();
   int next = 0, mySlot = 0;
   bool live = false;
@@ -641,6 +651,25 @@ RT_DEV void tracePoolTiles(const DevScene& S, float4* pool, uint32_t have /* bit
   const int lane = int(threadIdx.x) & 63;
   const unsigned long long lt = (1ull << lane) - 1ull;
   int n = 0;
+#if RT_POOL_ORDER & 1
+  // experiment (round 5, profiles/r05_pool_order_ab.txt): the work list ordered by direction octant, so that the rays a wave traces at the same time head the
+  // same way through the tree (the pool of a K-tile wave holds up to K x 64 rays of incoherent directions)
+  uint32_t oct = 0;
+#pragma unroll
+  for(int k = 0; k < K; k++) if((have >> k) & 1u) {
+    const float4 a = pool[(k * 64 + lane) * POOL_SLOT_F4], b = pool[(k * 64 + lane) * POOL_SLOT_F4 + 1];
+    oct |= ((a.w < 0.0f ? 1u : 0u) | (b.x < 0.0f ? 2u : 0u) | (b.y < 0.0f ? 4u : 0u)) << (4 * k);
+  }
+  for(uint32_t oc = 0; oc < 8u; oc++) {
+#pragma unroll
+    for(int k = 0; k < K; k++) {
+      const bool h = ((have >> k) & 1u) && ((oct >> (4 * k)) & 7u) == oc;
+      const unsigned long long m = __ballot(h ? 1 : 0);
+      if(h) list[n + __popcll(m & lt)] = (unsigned char)(k * 64 + lane);
+      n += __popcll(m);
+    }
+  }
+#else
 #pragma unroll
   for(int k = 0; k < K; k++) {
     const bool h = (have >> k) & 1u;
@@ -648,6 +677,7 @@ RT_DEV void tracePoolTiles(const DevScene& S, float4* pool, uint32_t have /* bit
     if(h) list[n + __popcll(m & lt)] = (unsigned char)(k * 64 + lane);
     n += __popcll(m);
   }
+#endif
   if(n == 0) return;
   waveLdsSync();
   int next = 0, mySlot = 0;

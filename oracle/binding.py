@@ -43,6 +43,7 @@ def lib():
         L.orc_decompress_unit_vec.argtypes = [C.c_uint32, C.c_void_p]
         for n in ["orc_destroy", "orc_reset_counters", "orc_num_triangles", "orc_threads"]:
             getattr(L, n).argtypes = [C.c_void_p]
+        L.orc_set_threads.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orc_upload_scene.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_resize.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orc_set_camera.argtypes = [C.c_void_p, C.c_void_p]
@@ -89,6 +90,7 @@ class Oracle:
             lib().orc_destroy(self._h); self._h = None
     @property
     def threads(self): return lib().orc_threads(self._h)
+    def set_threads(self, threads, pin=False): lib().orc_set_threads(self._h, int(threads), 1 if pin else 0)
     def _chk(self, rc, what):
         if rc != 0: raise RuntimeError(f"oracle {what} failed: {rc}")
     def upload_scene(self, desc): self._chk(lib().orc_upload_scene(self._h, C.byref(desc)), "upload_scene")

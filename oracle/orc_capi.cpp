@@ -66,6 +66,13 @@ void* orc_create(int threads)
 }
 void orc_destroy(void* p) { delete static_cast<Ctx*>(p); }
 int orc_threads(void* p) { return static_cast<Ctx*>(p)->frame.threads; }
+// bench.py's cpu_baseline leg: another thread count for the same context (scaling points), workers pinned to the CPUs of the process's affinity mask
+void orc_set_threads(void* p, int threads, int pin)
+{
+  Ctx* c = static_cast<Ctx*>(p);
+  if(threads <= 0) threads = int(std::thread::hardware_concurrency());
+  c->frame.threads = threads > 0 ? threads : 1; c->frame.pin = pin != 0;
+}
 int orc_upload_scene(void* p, const rt_scene_desc* d)
 {
   Ctx* c = static_cast<Ctx*>(p);

@@ -6,6 +6,8 @@
 #include <algorithm>
 #include <atomic>
 #include <vector>
+#include <sched.h>
+#include <pthread.h>
 #include "orc_shading.h"
 
 namespace orc {
@@ -15,6 +17,7 @@ struct Frame {
   rt_scene_camera cam{};
   int W = 0, H = 0;
   int threads = 1;
+  bool pin = false;   // bench.py's cpu_baseline leg: worker t runs on the t-th CPU of the process's affinity mask (orc_set_threads), so that a pass measures cores, not the scheduler
   // row-tiled runs: rows of the last-frame buffers valid on this rank; lookups outside raise histMiss (rt_abi.h rt_set_history_rows)
   int histRow0 = 0, histRow1 = 1 << 30;
   mutable std::atomic<uint32_t> histMiss{0}, histMissInd{0};  // raised by the direct stages / by the indirect stage (rt_history_miss_stage)
@@ -79,8 +82,15 @@ void Frame::parallelRows(int rows, int rowBegin, int rowEnd, F&& fn) const
   if(nt == 1) { for(int y = rowBegin; y < rowEnd; y++) fn(y); return; }
   std::vector<std::thread> pool;
   std::atomic<int> next{rowBegin};
-  for(int t = 0; t < nt; t++)
+  std::vector<int> cpus;
+  if(pin) {
+    cpu_set_t set; CPU_ZERO(&set);
+    if(sched_getaffinity(0, sizeof(set), &set) == 0) for(int c = 0; c < CPU_SETSIZE; c++) if(CPU_ISSET(c, &set)) cpus.push_back(c);
+  }
+  for(int t = 0; t < nt; t++) {
     pool.emplace_back([&] { for(;;) { int y = next.fetch_add(1); if(y >= rowEnd) break; fn(y); } });
+    if(!cpus.empty()) { cpu_set_t one; CPU_ZERO(&one); CPU_SET(cpus[size_t(t) % cpus.size()], &one); (void)pthread_setaffinity_np(pool.back().native_handle(), sizeof(one), &one); }
+  }
   for(auto& th : pool) th.join();
 }
 

@@ -5,12 +5,18 @@
 # Counters are collected in their own runs (no trace domains besides kernel dispatch), one group per pass, every pass under `timeout`.
 # The per-kernel figures go to <out>/summary.txt and are MERGED into profiles/pmc_traffic.json under workloads[<key>] (the file is stamped with the hash of the
 # library the counters were collected on; entries of another build are dropped).  bench.py reads the entry of the workload it runs.
+# Frames (round 5, verdict item 6): the counters must describe the frames the bench line times.  Static camera: every frame is the same work, 4 timed frames after
+# 2 warm-up frames.  Moving camera (--moving-camera, --config 5): the bench's own --steps / --warmup (100 / 20 unless PMC_STEPS / PMC_WARMUP say otherwise), i.e.
+# the same frame indices and camera poses, and the per-launch averages are taken over the launches of the TIMED frames only (the warm-up launches are dropped
+# by dispatch order).  bench.py uses an entry of a moving workload only when its frames match the run's.
 TAG=${1:-pmc}; KEY=${2:-config4}; shift; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-run() { local name=$1 ctrs=$2; shift; shift; env "$@" timeout 300 rocprofv3 --pmc $ctrs --output-format csv -d $OUT -o $name -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --profile-run $BENCH_ARGS > /dev/null 2>&1; }
 BENCH_ARGS="$*"
+STEPS=${PMC_STEPS:-4}; WARMUP=${PMC_WARMUP:-2}
+case " $BENCH_ARGS " in *" --moving-camera "*|*" --config 5 "*) STEPS=${PMC_STEPS:-100}; WARMUP=${PMC_WARMUP:-20};; esac
+run() { local name=$1 ctrs=$2; shift; shift; env "$@" timeout 600 rocprofv3 --pmc $ctrs --output-format csv -d $OUT -o $name -- python $GRAFT_REPO_ROOT/bench.py --steps $STEPS --warmup $WARMUP --no-cpu-baseline --profile-run $BENCH_ARGS > /dev/null 2>&1; }
 run sq1 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM" X_=1
 run sq2 "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_INST_LEVEL_VMEM SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" X_=1
 run sq3 "SQ_LEVEL_WAVES SQ_CYCLES SQ_INSTS_BRANCH SQ_IFETCH SQ_INST_CYCLES_VMEM_RD SQ_LDS_IDX_ACTIVE" X_=1
@@ -20,18 +26,29 @@ run tcc2 "FETCH_SIZE" X_=1
 run tcc3 "WRITE_SIZE" X_=1
 # the same write counter with the WHOLE traversal stack in LDS (no HBM overflow area): the difference is what the short stacks of the frames in flight write
 run tcc3full "WRITE_SIZE" RESTIR_STACK_LDS=64
-python - "$KEY" "$BENCH_ARGS" <<PY
+python - "$KEY" "$BENCH_ARGS" "$STEPS" "$WARMUP" <<PY
 import csv, glob, collections, os, sys, json, hashlib
 out = "$OUT"
-key, bench_args = sys.argv[1], sys.argv[2]
+key, bench_args, steps, warmup = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.Counter()
 for f in glob.glob(out + "/*counter_collection.csv"):
     full = "tcc3full" in os.path.basename(f)
+    rows = collections.defaultdict(list)     # (kernel, counter) -> [(dispatch id, value)]: one pass = one process, dispatch ids are its launch order
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"].split("(")[0]
         c = row["Counter_Name"] + ("_FULL_LDS_STACK" if full else "")
-        agg[k][c] += float(row["Counter_Value"])
-        calls[(k, c)] += 1
+        rows[(k, c)].append((int(row.get("Dispatch_Id", 0) or 0), float(row["Counter_Value"])))
+    for (k, c), lst in rows.items():
+        lst.sort()
+        # a counter may be reported once per dispatch or once per dispatch and dimension (XCD / SE instances): group by dispatch id first
+        per = collections.OrderedDict()
+        for d, v in lst: per[d] = per.get(d, 0.0) + v
+        vals = list(per.values())
+        per_frame = len(vals) / float(steps + warmup)
+        if "_cnt::" not in k and per_frame >= 1 and abs(per_frame - round(per_frame)) < 1e-9:
+            vals = vals[int(round(per_frame)) * warmup:]      # the launches of the timed frames only
+        agg[k][c] += sum(vals)
+        calls[(k, c)] += len(vals)
 with open(out + "/summary.txt", "w") as fo:
     fo.write("workload: %s (bench.py %s)\n" % (key, bench_args))
     for k, d in sorted(agg.items()):
@@ -53,7 +70,8 @@ traffic = {kname(k): {"FETCH_SIZE_KB": per(k, d, "FETCH_SIZE"), "WRITE_SIZE_KB":
 frames = max(1, calls[("rt::base::k_direct_stage", "SQ_INSTS_VALU")])
 traffic["_frame"] = {"INSTS_VALU": sum(d.get("SQ_INSTS_VALU", 0) for k, d in agg.items() if k.startswith(("rt::base::", "void rt::base::"))) / frames,
                      "note": "sum over the kernels of one frame (count-free variants), SQ_INSTS_VALU per launch x launches per frame"}
-traffic["_bench_args"] = bench_args
+traffic["_bench_args"] = bench_args + " --steps %d --warmup %d" % (steps, warmup)
+traffic["_frames"] = {"warmup": warmup, "steps": steps, "averaged_over": "the launches of the timed frames (warm-up launches dropped by dispatch order)"}
 root = os.environ["GRAFT_REPO_ROOT"]
 lib = os.path.join(root, "cis-565-final-vr-raytracer_amd", "csrc", "librestir_hip.so")
 sha = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]   # bench.py marks these numbers stale for any other build

@@ -2,7 +2,8 @@
 # Same-box A/B of measurement builds and environment settings on the bench scene (round 4).  usage (gpurun):
 #   bash scripts/variants_bench.sh <tag> "<label>|<extra hipcc flags or ->|<env assignments or ->" ...
 # A variant with flags is built ON THE BOX into csrc/_ab/librestir_hip_<label>.so (measurement builds do not travel); "-" flags = the product library.
-# Prints per variant: frames in flight (bench.py timed region + sustained), serial sum and the serial stage times; LAT=1 adds frame latency, CFG=<n> uses --config n.
+# Prints per variant: frames in flight (bench.py timed region + sustained), serial sum and the serial stage times; LAT=1 adds frame latency, CFG=<n> uses --config n,
+# BENCH_ARGS="..." is passed to bench.py (round 5: --scene-footprint real).
 R=$GRAFT_REPO_ROOT; T=${1:-r04ab}; O=$R/gpurun_out/$T; mkdir -p $O; shift
 cd $R
 for v in "$@"; do
@@ -13,7 +14,7 @@ for v in "$@"; do
     export RESTIR_HIP_LIB=$R/cis-565-final-vr-raytracer_amd/csrc/_ab/librestir_hip_$label.so
   fi
   [ "$envs" == "-" ] && envs="X_=1"
-  env $envs timeout 900 python bench.py --no-cpu-baseline ${CFG:+--config $CFG} > $O/bench_$label.json 2> $O/bench_$label.err || { echo "$label: bench failed"; tail -3 $O/bench_$label.err; continue; }
+  env $envs timeout 900 python bench.py --no-cpu-baseline ${CFG:+--config $CFG} $BENCH_ARGS > $O/bench_$label.json 2> $O/bench_$label.err || { echo "$label: bench failed"; tail -3 $O/bench_$label.err; continue; }
   python - "$label" $O/bench_$label.json <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])

@@ -19,7 +19,7 @@ W, H = (1920, 1080)
 if len(args) % 2 == 0 and len(args) >= 2 and args[0] >= 640 and args[1] >= 360 and len(args) >= 4:
     W, H = args[0], args[1]; args = args[2:]
 bands = list(zip(args[0::2], args[1::2])) or [(496, 528), (528, 576)]
-sc, env = make_scene(abi.PROC_BISTRO_EXT, 1.0, 1, (2048, 1024))
+sc, env = make_scene(getattr(abi, os.environ.get("WAVE_PROFILE_KIND", "PROC_BISTRO_EXT")), 1.0, 1, (2048, 1024))   # WAVE_PROFILE_KIND=PROC_BISTRO_EXT_REAL: the real-footprint scene
 st = host.default_state(W, H, sc, env)
 r = Renderer().setup(0); r.load_scene(sc.desc(env)); r.update(W, H)
 r.set_overlap(0)
