@@ -188,7 +188,11 @@ def main():
     ap.add_argument("--verify-frames", type=int, default=3, help="N > 1: frames of the tiled == untiled gate after the timed region (0 = skip the gate; the line then says so)")
     ap.add_argument("--single-host", action="store_true", help="N > 1 without --native: time the RCCL host only (default: rank 0 then also runs the native host in a child process and "
                                                                 "reports both, the faster as `value`)")
+    ap.add_argument("--print-workload-key", action="store_true", help="print the key of this workload in profiles/pmc_traffic.json and exit (scripts/pmc.sh)")
     args = ap.parse_args()
+    if args.print_workload_key:
+        print(workload_key(args.config, args.moving_camera or CONFIGS[args.config].get("orbit", False), footprint_of(args)))
+        return None
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -926,7 +926,7 @@ RT_DEV void gangTail(const DevScene& S, float4* pool, uint2* waveStack, Trav& T,
       const uint32_t freeM = leaderBits(__ballot((!working && !mine) ? 1 : 0));
       const bool adopt = !working && !mine;
       if(mine && !working) {   // first round of an owner: what is pending moves to the stack column (the workers share it); pending triangles stay with their worker
-        if(T.ngroup.y > 0x00FFFFFFu) { stackPushW(T, waveStack + g, T.ngroup, j); T.ngroup.y = 0u; }
+        if(T.ngroup.y > 0x00FFFFFFu) { if(__builtin_expect(T.sp >= S.stackEntries, 0)) __builtin_trap(); stackPushW(T, waveStack + g, T.ngroup, j); T.ngroup.y = 0u; }
         og = g;
       }
       if(adopt) {
@@ -1014,6 +1014,9 @@ RT_DEV void gangTail(const DevScene& S, float4* pool, uint2* waveStack, Trav& T,
     const bool push = took && T.ngroup.y > 0x00FFFFFFu;
     const uint32_t pushM = leaderBits(__ballot(push ? 1 : 0)) & wm;
     if(working) {
+      // (the bound above is an argument, not a check: a column that would overflow into the gang mailbox / the next wave's stacks aborts the launch — the
+      //  library then reports RT_ERR_HIP — instead of corrupting LDS silently; advisor finding of round 4)
+      if(__builtin_expect(T.sp + __popc(pushM) > S.stackEntries, 0)) __builtin_trap();
       if(push && j == 0) stack[(T.sp + __popc(pushM & ~((2u << g) - 1u))) * WIDE_RAYS] = T.ngroup;   // farthest first: the nearest group ends on top
       T.sp += __popc(pushM);
       T.ngroup.y = 0u;

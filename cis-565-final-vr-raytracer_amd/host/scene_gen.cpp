@@ -550,7 +550,9 @@ GltfScene makeBistroExteriorReal(float scale, uint32_t seed)
   Builder B(seed);
   std::vector<TexJob> jobs;
   const float s = std::sqrt(scale), one[3] = {1, 1, 1};
-  const int texSize = std::max(64, pow2Floor(int(2048.f * s + 0.5f)));
+  // experiment switch (round 5, profiles/r05_real_reask.txt): RESTIR_SCENE_TEXSIZE=<n> builds the same geometry and materials with n x n textures — what of the
+  // real scene's cost is the texel footprint and what the triangle shapes
+  const int texSize = getenv("RESTIR_SCENE_TEXSIZE") ? std::max(32, pow2Floor(atoi(getenv("RESTIR_SCENE_TEXSIZE")))) : std::max(64, pow2Floor(int(2048.f * s + 0.5f)));
   const float X = 60.f, Z = 40.f;
   // ---- materials ----------------------------------------------------------------------------------------------------------------------------------
   // pattern kinds by use: 0..15 ground (cobbles / mottled), 16..39 walls, 40..51 frames, 52..63 balconies, 64..71 awnings, 72..119 props, 120..123 bark, 124..127 furniture

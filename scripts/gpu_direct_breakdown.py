@@ -6,7 +6,9 @@ import torch  # noqa: F401
 from helpers import abi, host, make_scene
 from restir_amd.renderer import Renderer
 W, H = 1920, 1080
-sc, env = make_scene(abi.PROC_BISTRO_EXT, 1.0, 1, (2048, 1024))
+KIND = sys.argv[1] if len(sys.argv) > 1 else "PROC_BISTRO_EXT"      # round 5: PROC_BISTRO_EXT_REAL (with RESTIR_SCENE_TEXSIZE=<n>: the same geometry, n x n textures)
+sc, env = make_scene(getattr(abi, KIND), 1.0, 1, (2048, 1024))
+print(KIND, "texsize", os.environ.get("RESTIR_SCENE_TEXSIZE", "default"), "split", os.environ.get("RESTIR_BVH_SPLIT", "default"), flush=True)
 r = Renderer().setup(0); r.load_scene(sc.desc(env)); r.update(W, H)
 sc.updateCamera(W, H)
 def timed(fn, n=12):

@@ -14,6 +14,8 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH_ARGS="$*"
+# key "auto": the key bench.py itself uses for these arguments (config, camera, scene footprint)
+[ "$KEY" == "auto" ] && KEY=$(python $GRAFT_REPO_ROOT/bench.py --print-workload-key $BENCH_ARGS 2>/dev/null | tail -1)
 STEPS=${PMC_STEPS:-4}; WARMUP=${PMC_WARMUP:-2}
 case " $BENCH_ARGS " in *" --moving-camera "*|*" --config 5 "*) STEPS=${PMC_STEPS:-100}; WARMUP=${PMC_WARMUP:-20};; esac
 run() { local name=$1 ctrs=$2; shift; shift; env "$@" timeout 600 rocprofv3 --pmc $ctrs --output-format csv -d $OUT -o $name -- python $GRAFT_REPO_ROOT/bench.py --steps $STEPS --warmup $WARMUP --no-cpu-baseline --profile-run $BENCH_ARGS > /dev/null 2>&1; }
@@ -83,7 +85,7 @@ except (OSError, ValueError):
     allw = {}
 allw.setdefault("workloads", {})[key] = traffic
 allw["_lib_sha256_16"] = sha
-if key == "config4":   # the headline workload also at top level (the layout rounds 2-3 committed)
+if key in ("config4", "config4_real"):   # the headline workload also at top level (the layout rounds 2-3 committed; since round 5 the headline is the real footprint)
     for k, v in traffic.items(): allw[k] = v
 json.dump(allw, open(path, "w"), indent=1)
 json.dump(allw, open(out + "/pmc_traffic.json", "w"), indent=1)

@@ -5,7 +5,7 @@
 TAG=${1:-r05_reask}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R
-export BENCH_ARGS="--scene-footprint real"
+export BENCH_ARGS="--scene-footprint real --stream-priorities default"
 bash scripts/variants_bench.sh $TAG "lb55|-|-" "lb45|-DRT_DIRECT_LB=4|-" "lb55_again|-|-" "lb54|-DRT_INDIRECT_LB=4|-" "opaque_cards|-|RESTIR_DEBUG_OPAQUE_LEAVES=1" "split_a5|-|RESTIR_BVH_SPLIT=1 RESTIR_BVH_SPLIT_ALPHA=1e-5" "split_a5_lb45|-DRT_DIRECT_LB=4|RESTIR_BVH_SPLIT=1 RESTIR_BVH_SPLIT_ALPHA=1e-5" 2>&1 | tee $O/variants.txt
 python -c "import restir_amd; from restir_amd import build; build.build_hip(variant='prof', extra_flags=['-DRT_WAVEPROF=1'])" > /dev/null 2>&1
 export RESTIR_HIP_LIB=$R/cis-565-final-vr-raytracer_amd/csrc/_ab/librestir_hip_prof.so

@@ -239,7 +239,8 @@ def _reference(name, kind, scale, stress, n_rays=None):
 
 
 # the GPU leg runs on the driver's clock (the whole -m gpu suite has 1200 s): 40 k rays per scene there — the float64 brute force is what takes the time, and the
-# CPU leg above holds the same arithmetic (the oracle's, bit-identical to the HIP path by every parity test) to 100 k rays per scene
+# CPU leg above holds the same arithmetic (the oracle's, bit-identical to the HIP path by every parity test) to RAYS = 50 k rays per scene by default
+# (100 k until round 4; scripts/fuzz_campaign.sh and scripts/final_measure.sh run both legs with RESTIR_PIN_RAYS=100000 RESTIR_PIN_RAYS_GPU=100000)
 RAYS_GPU = int(os.environ.get("RESTIR_PIN_RAYS_GPU", "40000"))
 
 
