@@ -13,6 +13,9 @@
 #include <memory>
 #include <thread>
 
+#ifndef RT_BVH_ROTATE_DEFAULT
+#define RT_BVH_ROTATE_DEFAULT 0
+#endif
 #ifndef RT_BVH_SPLIT_DEFAULT
 #define RT_BVH_SPLIT_DEFAULT 0
 #endif
@@ -313,6 +316,50 @@ struct BuilderS {
   }
 };
 
+// ---- tree rotations on the finished BVH2 (Kensler, "Tree Rotations for Improving Bounding Volume Hierarchies", RT 2008) ---------------------------------------
+// Bottom-up, for every internal node n with children (L, R): exchanging a child with a grandchild on the other side changes only the box of the child that
+// loses / gains a subtree; the exchange with the largest area reduction is applied.  Children are adjacent records (a, a + 1) and a record carries its
+// subtree by index, so an exchange is a swap of two records.  RESTIR_BVH_ROTATE = number of passes (0 = off).
+inline Box unite(const Box& x, const Box& y) { Box r = x; r.grow(y); return r; }
+uint64_t rotatePass(std::vector<N2>& N, uint32_t count)
+{
+  uint64_t applied = 0;
+  for(uint32_t n = count; n-- > 0;) {   // children have larger indices than their parent: reverse index order is bottom-up
+    N2& P = N[n];
+    if(P.leaf) continue;
+    const uint32_t L = P.a, R = P.a + 1;
+    float best = 0.f; int which = -1;
+    if(!N[R].leaf) {
+      const uint32_t RL = N[R].a, RR = N[R].a + 1;
+      const float base = N[R].b.area();
+      const float d0 = unite(N[L].b, N[RR].b).area() - base;   // L <-> RL
+      const float d1 = unite(N[RL].b, N[L].b).area() - base;   // L <-> RR
+      if(d0 < best) { best = d0; which = 0; }
+      if(d1 < best) { best = d1; which = 1; }
+    }
+    if(!N[L].leaf) {
+      const uint32_t LL = N[L].a, LR = N[L].a + 1;
+      const float base = N[L].b.area();
+      const float d2 = unite(N[R].b, N[LR].b).area() - base;   // R <-> LL
+      const float d3 = unite(N[LL].b, N[R].b).area() - base;   // R <-> LR
+      if(d2 < best) { best = d2; which = 2; }
+      if(d3 < best) { best = d3; which = 3; }
+    }
+    if(which < 0) continue;
+    if(which < 2) {
+      const uint32_t g = N[R].a + uint32_t(which);
+      std::swap(N[L], N[g]);
+      N[R].b = unite(N[N[R].a].b, N[N[R].a + 1].b);
+    } else {
+      const uint32_t g = N[L].a + uint32_t(which - 2);
+      std::swap(N[R], N[g]);
+      N[L].b = unite(N[N[L].a].b, N[N[L].a + 1].b);
+    }
+    applied++;
+  }
+  return applied;
+}
+
 inline int slotSign(int slot, int axis) { return (slot >> axis) & 1 ? 1 : -1; }
 
 }  // namespace
@@ -373,7 +420,7 @@ bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads)
     }
   }
   const size_t n = total;
-  out.nodes.clear(); out.tris.clear(); out.maxDepth = 0; out.sahNodeSteps = out.sahTriSteps = 0; out.references = 0; out.spatialSplits = 0;
+  out.nodes.clear(); out.tris.clear(); out.maxDepth = 0; out.sahNodeSteps = out.sahTriSteps = 0; out.references = 0; out.spatialSplits = 0; out.rotations = 0;
   if(n == 0) {  // a single empty node keeps the kernels branch-free
     Node8 e{}; e.ex = e.ey = e.ez = 127;
     out.nodes.push_back(e);
@@ -423,6 +470,13 @@ bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads)
     B2.build(0, 0, uint32_t(n));
     n2count = B2.nodeCount.load();
     out.references = n; out.spatialSplits = 0;
+  }
+  {
+    // (not with RESTIR_BVH_COLLAPSE=dp: that pass walks the records in index order and relies on children having larger indices than their parent, which a swap breaks)
+    const bool dp = getenv("RESTIR_BVH_COLLAPSE") && strcmp(getenv("RESTIR_BVH_COLLAPSE"), "dp") == 0;
+    const int rotate = dp ? 0 : (getenv("RESTIR_BVH_ROTATE") ? atoi(getenv("RESTIR_BVH_ROTATE")) : RT_BVH_ROTATE_DEFAULT);
+    std::vector<N2>& M = BS ? BS->nodes : B2.nodes;
+    for(int pass = 0; pass < rotate; pass++) { const uint64_t k = rotatePass(M, n2count); out.rotations += k; if(k == 0) break; }
   }
   const std::vector<N2>& N = BS ? BS->nodes : B2.nodes;
   const std::vector<uint32_t>& leafTris = BS ? BS->leafTris : idx;
@@ -663,6 +717,6 @@ extern "C" int rt_bvh8_selfcheck(const rt_scene_desc* scene, int samplesPerTri, 
   std::vector<std::thread> pool;
   for(int i = 0; i < threads; i++) pool.emplace_back(worker);
   for(auto& t : pool) t.join();
-  out[0] = n; out[1] = bo.tris.size(); out[2] = bo.nodes.size(); out[3] = uint64_t(bo.maxDepth); out[4] = bo.spatialSplits; out[5] = uncovered.load(); out[6] = points.load(); out[7] = 0;
+  out[0] = n; out[1] = bo.tris.size(); out[2] = bo.nodes.size(); out[3] = uint64_t(bo.maxDepth); out[4] = bo.spatialSplits; out[5] = uncovered.load(); out[6] = points.load(); out[7] = bo.rotations;
   return 0;
 }

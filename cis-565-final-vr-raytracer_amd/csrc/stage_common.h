@@ -91,6 +91,12 @@ RT_DEV void waveProfFlush(const DevFrame& F, const Ctx& c, int tx, int ty, uint6
   atomicMax(&rec[11], c.tc.nodes); atomicMax(&rec[12], c.tc.tris);
   atomicAdd(&rec[13], c.tc.aTex); atomicAdd(&rec[14], c.tc.aOmm);
   atomicMax(&rec[15], uint32_t(wall_clock64() - w0));
+  // launch-wide histograms of the traversal rounds (record 65534): [0..7] rounds by live lanes, [8..15] rounds by lanes that execute the round (lane 0's counters:
+  // the counters are wave-uniform)
+  if((threadIdx.x & 63) == 0) {
+    uint32_t* h = F.waveProf + size_t(65534) * 16;
+    for(int k = 0; k < 8; k++) { atomicAdd(&h[k], c.tc.hl[k]); atomicAdd(&h[8 + k], c.tc.he[k]); }
+  }
 }
 #endif
 

@@ -31,6 +31,7 @@ struct TravCounters {
   uint32_t rN, rT, rC, cN, cT, cC, aTex, aOmm;   // rounds / cycles by kind (node, triangle, cooperative tail), alpha candidates by resolution
   uint32_t ph[8];                                // wide traversal: cycles by phase of the triangle step (see travTriW), [7] = steps
   uint32_t nph[4];                               // and of the node step (travRoundW), [3] = steps
+  uint32_t hl[8], he[8];                         // throughput build: rounds by live lanes (1-8, 9-16, .. 57-64) and by lanes that EXECUTE the round (the majority kind)
 #endif
 };
 
@@ -546,6 +547,8 @@ RT_DEV bool travRoundMasked(const DevScene& S, Trav& T, bool live, unsigned long
   {
     const uint32_t dc = uint32_t(clock64() - c0);
     if(nLive <= S.coopLive) { tc.rC++; tc.cC += dc; } else if(nT >= nN) { tc.rT++; tc.cT += dc; } else { tc.rN++; tc.cN += dc; }
+    const int ex = nLive <= S.coopLive ? nLive : (nT >= nN ? nT : nN);
+    tc.hl[(nLive - 1) >> 3]++; tc.he[(max(ex, 1) - 1) >> 3]++;
   }
 #endif
   return live && (travHasTris(T) || travHasNodes(T));

@@ -74,6 +74,12 @@ def report_wide(name, rec, ms):
 
 
 def report(name, rec, ms):
+    hist = rec[65534].astype(np.float64); rec = rec[:65534]     # launch-wide histograms of the rounds (csrc/stage_common.h waveProfFlush)
+    if hist.sum() > 0:
+        hl, he = hist[:8], hist[8:]
+        mid = np.arange(8) * 8 + 4.5
+        print("   rounds by LIVE lanes (1-8 .. 57-64), %: " + " ".join(f"{100 * v / hl.sum():.1f}" for v in hl) + f"   mean {(hl * mid).sum() / hl.sum():.1f} lanes")
+        print("   rounds by EXECUTING lanes (the majority kind), %: " + " ".join(f"{100 * v / he.sum():.1f}" for v in he) + f"   mean {(he * mid).sum() / he.sum():.1f} lanes = {100 * (he * mid).sum() / he.sum() / 64:.1f} % of the wave")
     rec = rec[rec[:, 2] > 0]
     if len(rec) == 0:
         print(name, "no records"); return
