@@ -284,7 +284,7 @@ def main():
         r.set_camera(scene.getCamera()); st.time = 999
         if args.stream_priorities == "tune" and not args.profile_run:
             t_tune = time.time()
-            prio_tuning = r.tune_stream_priorities(st, 8)
+            prio_tuning = r.tune_stream_priorities(st, 24)
             prio_tuning["seconds"] = round(time.time() - t_tune, 3)
         elif "," in args.stream_priorities:
             lv = [int(x) for x in args.stream_priorities.split(",")]

@@ -13,6 +13,9 @@
 #include <memory>
 #include <thread>
 
+#ifndef RT_BVH_REINSERT_DEFAULT
+#define RT_BVH_REINSERT_DEFAULT 0
+#endif
 #ifndef RT_BVH_ROTATE_DEFAULT
 #define RT_BVH_ROTATE_DEFAULT 0
 #endif
@@ -360,6 +363,98 @@ uint64_t rotatePass(std::vector<N2>& N, uint32_t count)
   return applied;
 }
 
+// ---- insertion-based optimisation of the finished BVH2 (after Bittner, Hapala, Havran, "Fast Insertion-Based Optimization of Bounding Volume Hierarchies",
+//      CGF 2013) ----------------------------------------------------------------------------------------------------------------------------------------------
+// A top-down SAH build decides every split with what it knows at that level; subtrees that ended up in the wrong place (a rail that runs through three
+// buildings' boxes) stay there.  Here the nodes whose boxes are the least efficient (large, and much larger than their children) are taken apart: each of
+// their children is removed from the tree — its sibling moves up into the parent's place — and put back where it increases the tree's area the least, found by
+// a branch-and-bound search from the root.  Records carry their subtree by index (children are the adjacent records a, a + 1), so removal and insertion move
+// three records and refit the boxes on two root paths.  RESTIR_BVH_REINSERT = passes (0 = off), each over the worst 2 % of the internal nodes.
+struct Reinserter {
+  std::vector<N2>& N;
+  uint32_t count;
+  std::vector<int32_t> parent;
+  uint64_t moved = 0;
+  Reinserter(std::vector<N2>& n, uint32_t c) : N(n), count(c), parent(c, -1)
+  {
+    for(uint32_t i = 0; i < c; i++) if(!N[i].leaf) { parent[N[i].a] = int32_t(i); parent[N[i].a + 1] = int32_t(i); }
+  }
+  void put(uint32_t dst, const N2& rec)
+  {
+    N[dst] = rec;
+    if(!rec.leaf) { parent[rec.a] = int32_t(dst); parent[rec.a + 1] = int32_t(dst); }
+  }
+  void refit(int32_t a)
+  {
+    for(; a >= 0; a = parent[size_t(a)]) {
+      const Box nb = unite(N[N[size_t(a)].a].b, N[N[size_t(a)].a + 1].b);
+      if(memcmp(&nb, &N[size_t(a)].b, sizeof(Box)) == 0) break;
+      N[size_t(a)].b = nb;
+    }
+  }
+  // remove the subtree in slot x and put it back at the best place; false: left where it was
+  bool reinsert(uint32_t x)
+  {
+    const int32_t p = parent[x];
+    if(p <= 0) return false;                       // the root's children stay (the root record does not move)
+    const uint32_t pairBase = N[size_t(p)].a, s = pairBase + (x == pairBase ? 1u : 0u);
+    const N2 X = N[x], S = N[s];
+    const float ax = X.b.area();
+    const int32_t g = parent[size_t(p)];
+    put(uint32_t(p), S);
+    refit(g);
+    // branch and bound: cost of inserting X as the sibling of t = area(t u X) + the growth of every ancestor of t
+    struct Item { float induced; uint32_t node; };
+    auto cmp = [](const Item& a, const Item& b) { return a.induced > b.induced; };
+    std::vector<Item> heap;
+    heap.push_back({0.f, 0u});
+    float best = 3e38f; uint32_t bestT = uint32_t(p);
+    while(!heap.empty()) {
+      std::pop_heap(heap.begin(), heap.end(), cmp);
+      const Item it = heap.back(); heap.pop_back();
+      if(it.induced + ax >= best) break;            // every remaining candidate costs at least its induced part + area(X)
+      const N2& T = N[it.node];
+      const float direct = unite(T.b, X.b).area();
+      const float total = it.induced + direct;
+      if(total < best) { best = total; bestT = it.node; }
+      const float childInduced = total - T.b.area();
+      if(!T.leaf && childInduced + ax < best) {
+        heap.push_back({childInduced, T.a}); std::push_heap(heap.begin(), heap.end(), cmp);
+        heap.push_back({childInduced, T.a + 1}); std::push_heap(heap.begin(), heap.end(), cmp);
+      }
+    }
+    const N2 T = N[bestT];
+    put(pairBase, T); put(pairBase + 1, X);
+    parent[pairBase] = parent[pairBase + 1] = int32_t(bestT);
+    N2 J; J.leaf = false; J.a = pairBase; J.n = 0; J.b = unite(T.b, X.b);
+    N[bestT] = J;
+    refit(parent[bestT]);
+    const bool changed = bestT != uint32_t(p);
+    if(changed) moved++;
+    return changed;
+  }
+  void pass(float fraction)
+  {
+    std::vector<std::pair<float, uint32_t>> cand;
+    cand.reserve(count / 2);
+    for(uint32_t i = 1; i < count; i++) {
+      if(N[i].leaf || parent[i] < 0) continue;
+      const float a = N[i].b.area(), l = N[N[i].a].b.area(), r = N[N[i].a + 1].b.area();
+      const float m = a * (a / std::max(1e-30f, 0.5f * (l + r))) * (a / std::max(1e-30f, std::min(l, r)));   // Bittner et al.: area x (area / mean child) x (area / smallest child)
+      cand.push_back({m, i});
+    }
+    const size_t k = std::max<size_t>(1, size_t(double(cand.size()) * fraction));
+    std::partial_sort(cand.begin(), cand.begin() + std::min(k, cand.size()), cand.end(), [](const auto& x, const auto& y) { return x.first > y.first; });
+    for(size_t c = 0; c < std::min(k, cand.size()); c++) {
+      const uint32_t n = cand[c].second;
+      if(N[n].leaf) continue;                       // (an earlier move may have put a leaf record here)
+      const uint32_t l = N[n].a;
+      reinsert(l);
+      if(!N[n].leaf && N[n].a == l) reinsert(l + 1);   // (n still holds the same pair: its other child; otherwise the record at n is another subtree now)
+    }
+  }
+};
+
 inline int slotSign(int slot, int axis) { return (slot >> axis) & 1 ? 1 : -1; }
 
 }  // namespace
@@ -420,7 +515,7 @@ bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads)
     }
   }
   const size_t n = total;
-  out.nodes.clear(); out.tris.clear(); out.maxDepth = 0; out.sahNodeSteps = out.sahTriSteps = 0; out.references = 0; out.spatialSplits = 0; out.rotations = 0;
+  out.nodes.clear(); out.tris.clear(); out.maxDepth = 0; out.sahNodeSteps = out.sahTriSteps = 0; out.references = 0; out.spatialSplits = 0; out.rotations = 0; out.reinsertions = 0;
   if(n == 0) {  // a single empty node keeps the kernels branch-free
     Node8 e{}; e.ex = e.ey = e.ez = 127;
     out.nodes.push_back(e);
@@ -476,6 +571,12 @@ bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads)
     const bool dp = getenv("RESTIR_BVH_COLLAPSE") && strcmp(getenv("RESTIR_BVH_COLLAPSE"), "dp") == 0;
     const int rotate = dp ? 0 : (getenv("RESTIR_BVH_ROTATE") ? atoi(getenv("RESTIR_BVH_ROTATE")) : RT_BVH_ROTATE_DEFAULT);
     std::vector<N2>& M = BS ? BS->nodes : B2.nodes;
+    const int reins = dp ? 0 : (getenv("RESTIR_BVH_REINSERT") ? atoi(getenv("RESTIR_BVH_REINSERT")) : RT_BVH_REINSERT_DEFAULT);
+    if(reins > 0) {
+      Reinserter RI(M, n2count);
+      for(int pass = 0; pass < reins; pass++) RI.pass(0.02f);
+      out.reinsertions = RI.moved;
+    }
     for(int pass = 0; pass < rotate; pass++) { const uint64_t k = rotatePass(M, n2count); out.rotations += k; if(k == 0) break; }
   }
   const std::vector<N2>& N = BS ? BS->nodes : B2.nodes;
@@ -717,6 +818,6 @@ extern "C" int rt_bvh8_selfcheck(const rt_scene_desc* scene, int samplesPerTri, 
   std::vector<std::thread> pool;
   for(int i = 0; i < threads; i++) pool.emplace_back(worker);
   for(auto& t : pool) t.join();
-  out[0] = n; out[1] = bo.tris.size(); out[2] = bo.nodes.size(); out[3] = uint64_t(bo.maxDepth); out[4] = bo.spatialSplits; out[5] = uncovered.load(); out[6] = points.load(); out[7] = bo.rotations;
+  out[0] = n; out[1] = bo.tris.size(); out[2] = bo.nodes.size(); out[3] = uint64_t(bo.maxDepth); out[4] = bo.spatialSplits; out[5] = uncovered.load(); out[6] = points.load(); out[7] = bo.rotations + (bo.reinsertions << 32);
   return 0;
 }

@@ -17,7 +17,7 @@ struct BuildOutput {
   double sahCost = 0;
   double sahNodeSteps = 0, sahTriSteps = 0;   // SAH expectation of node / triangle steps of a ray that hits the root box (wide tree, build-time boxes)
   uint64_t references = 0;                   // leaf records (= tris.size()): > the triangle count when spatial splits duplicated references
-  uint64_t spatialSplits = 0, rotations = 0;
+  uint64_t spatialSplits = 0, rotations = 0, reinsertions = 0;
   float pad = 0;
 };
 // Host-side build: flatten (instance, triangle) pairs to world space, binned-SAH BVH2, greedy collapse to 8-wide,

@@ -1107,17 +1107,25 @@ int rt_tune_stream_priorities(rt_ctx* c, const rt_state* st, int framesPerCandid
   rt_state s = *st;
   int best = 0; double bestMs = 1e30;
   int f = 0;
+  hipEvent_t evA = nullptr, evB = nullptr;
+  RT_HIP(c, hipEventCreate(&evA)); RT_HIP(c, hipEventCreate(&evB));
+  auto done = [&](int r) { (void)hipEventDestroy(evA); (void)hipEventDestroy(evB); return r; };
   for(int i = 0; i < 5; i++) {
-    if((rc = rt_set_stream_priorities(c, cand[i][0], cand[i][1]))) return rc;
-    for(int k = 0; k < 3; k++) { s.time = 7000 + f; if((rc = rt_render_frame(c, &s, f))) return rc; f++; }   // fill the pipeline (and, first candidate, warm the caches)
-    RT_HIP(c, syncAll(c));
-    const auto t0 = std::chrono::steady_clock::now();
-    for(int k = 0; k < framesPerCandidate; k++) { s.time = 7000 + f; if((rc = rt_render_frame(c, &s, f))) return rc; f++; }
-    RT_HIP(c, syncAll(c));
-    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / framesPerCandidate;
+    if((rc = rt_set_stream_priorities(c, cand[i][0], cand[i][1]))) return done(rc);
+    // the PERIOD of the schedule in steady state: from the completion of a frame's last kernel (compose, filter stream) to the completion of the frame
+    // framesPerCandidate frames later — a wall clock around "issue n frames, drain" would add the latency of the last frame and favour low-latency settings
+    for(int k = 0; k < 3; k++) { s.time = 7000 + f; if((rc = rt_render_frame(c, &s, f))) return done(rc); f++; }   // fill the pipeline (and, first candidate, warm the caches)
+    if(hipEventRecord(evA, c->sideStream) != hipSuccess) return done(fail(c, RT_ERR_HIP, "rt_tune_stream_priorities: hipEventRecord failed"));
+    for(int k = 0; k < framesPerCandidate; k++) { s.time = 7000 + f; if((rc = rt_render_frame(c, &s, f))) return done(rc); f++; }
+    if(hipEventRecord(evB, c->sideStream) != hipSuccess) return done(fail(c, RT_ERR_HIP, "rt_tune_stream_priorities: hipEventRecord failed"));
+    if(syncAll(c) != hipSuccess) return done(fail(c, RT_ERR_HIP, "rt_tune_stream_priorities: synchronisation failed"));
+    float el = 0.f;
+    if(hipEventElapsedTime(&el, evA, evB) != hipSuccess) return done(fail(c, RT_ERR_HIP, "rt_tune_stream_priorities: hipEventElapsedTime failed"));
+    const double ms = double(el) / framesPerCandidate;
     if(msPerFrame) msPerFrame[i] = float(ms);
     if(ms < bestMs * 0.99) { bestMs = ms; best = i; }      // (a later candidate must win by 1 %: the default stays on a tie)
   }
+  (void)hipEventDestroy(evA); (void)hipEventDestroy(evB);
   if((rc = rt_set_stream_priorities(c, cand[best][0], cand[best][1]))) return rc;
   if(chosen) { chosen[0] = cand[best][0]; chosen[1] = cand[best][1]; }
   return rt_resize(c, W, H);   // cold history again: the tuning frames leave no trace
