@@ -566,6 +566,9 @@ RT_DEV void indirectSingleBounceTiles(const DevScene& S, const DevFrame& F, cons
   const int lane = int(threadIdx.x);
   const i2 indSize{st.size.x / 2, st.size.y / 2};
   float4* pool = reinterpret_cast<float4*>(s_stack + size_t(S.stackEntries) * 64);
+#if RT_WAVEPROF
+  const uint64_t prof_c0 = clock64(), prof_w0 = wall_clock64();
+#endif
   Ctx c(S, st, cam, s_stack + lane);
   struct Path { i2 px; uint32_t seed; float primSamplePdf; f3 a, b, pend; bool hasSurface, nvSet, shadow; };
   // a: sampleWi between phase 0 and 1, gi.xs afterwards; b: gi.ns; pend: the NEE term waiting for its visibility
@@ -661,6 +664,10 @@ RT_DEV void indirectSingleBounceTiles(const DevScene& S, const DevFrame& F, cons
     c.imageCoords = p.px;
     restirIndirectFinish(c, F, st, cam, p.px, indSize, primState, -ray0.direction, gi, p.primSamplePdf);
   }
+#if RT_WAVEPROF
+  // (round 5: the K-tile waves were missing from the profile — 75 % of the stage's tiles; their record is keyed by the first tile, bit 17 marks the kind)
+  { const int t0 = int(tiles[0]); waveProfFlush(F, c, (t0 % tilesX) | 0x20000, t0 / tilesX, prof_c0, prof_w0); }
+#endif
   flushCounters(F, c);
 }
 

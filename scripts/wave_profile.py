@@ -93,7 +93,7 @@ def report(name, rec, ms):
     print("   slowest waves: tile(x,y) | wave kcyc | closest kcyc | any kcyc | rounds n/t/c | cyc per round n/t/c | max nodes, tris of a lane | alpha tex/omm")
     for i in order[:12]:
         q = rec[i]
-        print(f"   ({q[0] & 0xffff:4d},{q[1]:3d}){' MB' if q[0] & 0x10000 else '   '} | {q[2] / 1e3:8.1f} | {q[3] / 1e3:8.1f} | {q[4] / 1e3:8.1f} | {q[5]:4d}/{q[6]:4d}/{q[7]:4d} | "
+        print(f"   ({q[0] & 0xffff:4d},{q[1]:3d}){' MB' if q[0] & 0x10000 else (' K3' if q[0] & 0x20000 else '   ')} | {q[2] / 1e3:8.1f} | {q[3] / 1e3:8.1f} | {q[4] / 1e3:8.1f} | {q[5]:4d}/{q[6]:4d}/{q[7]:4d} | "
               f"{q[8] / max(1, q[5]):6.0f}/{q[9] / max(1, q[6]):6.0f}/{q[10] / max(1, q[7]):6.0f} | {q[11]:4d},{q[12]:4d} | {q[13]}/{q[14]}")
     # how much of the slowest wave is traversal
     q = rec[order[0]]
