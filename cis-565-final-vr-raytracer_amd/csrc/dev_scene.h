@@ -85,6 +85,10 @@ struct DevFrame {
   uint32_t* histMiss;
   int32_t stackLds;                 // traversal stack entries per lane kept in LDS by this frame's traced launches (0 = the whole stack); the rest sits in DevScene::stackOvf
   int32_t pad4;
+  // Direct stage, full-frame launches (round 5): rowCost[tile row] = wave cycles the row's tiles took in the LAST direct-stage launch (>> 8, summed by atomics, one
+  // per wave); k_row_order turns it into rowOrder = the tile rows by descending cost, and the launch deals them to the XCDs in that order: the horizon rows, whose
+  // rays cross every tree of the street and whose waves end the launch, start first.  nullptr: identity (row bands, the first frame's all-zero costs sort to identity).
+  uint32_t* rowCost; uint16_t* rowOrder;
 };
 
 }  // namespace rt

@@ -661,6 +661,7 @@ int rt_resize(rt_ctx* c, int w, int h)
   RT_SCRATCH(geomN, n, float4); RT_SCRATCH(geomP, n, float4); RT_SCRATCH(geomNh, nh, float4); RT_SCRATCH(geomPh, nh, float4);
   RT_SCRATCH(postRowSums, size_t(h) * 6, double); RT_SCRATCH(postMean, 8, float);
   RT_SCRATCH(postMipD, n + 64, float4); RT_SCRATCH(postMipI, n + 64, float4);   // levels 1..7 (n/3 texels; up to n for one-pixel-wide images)
+  RT_SCRATCH(rowCost, 4096 + 64, uint32_t); RT_SCRATCH(rowOrder, 4096 + 64, uint16_t);
   RT_SCRATCH(tileOrder, (size_t(w / 2 + 7) / 8) * (size_t(h / 2 + 7) / 8 + 16 * 2) + 64 + 4096, uint32_t);   // 8 per-XCD lists: tiles + one chunk of slack each
 #if RT_WAVEPROF
   RT_SCRATCH(waveProf, WAVEPROF_RECORDS * 16, uint32_t);
@@ -736,6 +737,8 @@ static DevFrame makeFrame(rt_ctx* c, int frames)
   const DevFrame& X = c->scratch;
   F.surf = X.surf; F.status = X.status; F.qcount = X.qcount; F.waveProf = X.waveProf;
   F.histRow0 = c->histRow0; F.histRow1 = c->histRow1; F.histMiss = X.qcount + 250;
+  { static const bool rowOrderOn = !getenv("RESTIR_ROW_ORDER") || atoi(getenv("RESTIR_ROW_ORDER")) != 0;
+    F.rowCost = rowOrderOn ? X.rowCost : nullptr; F.rowOrder = rowOrderOn ? X.rowOrder : nullptr; }
   F.geomN = X.geomN; F.geomP = X.geomP; F.geomNh = X.geomNh; F.geomPh = X.geomPh; F.tileOrder = X.tileOrder; F.postRowSums = X.postRowSums; F.postMean = X.postMean;
   return F;
 }

@@ -46,6 +46,18 @@ RT_DEV TileCoord tileOfBlock(int L, int tilesX, int tilesY)
   return tc;
 }
 RT_DEV TileCoord tileOf(int tilesX, int tilesY) { return tileOfBlock(int(blockIdx.x), tilesX, tilesY); }
+// the same mapping with the tile rows taken in the order of `rowOrder` (whole tile rows per XCD: launches with tileChunk == tilesX)
+RT_DEV TileCoord tileOfOrdered(const uint16_t* rowOrder, int tilesX, int tilesY)
+{
+  if(!rowOrder) return tileOf(tilesX, tilesY);
+  const int L = int(blockIdx.x), xcd = L & 7, k = L >> 3;
+  const int j = k / tilesX, off = k - j * tilesX, s = j * 8 + xcd;
+  TileCoord tc;
+  tc.valid = s < tilesY;
+  tc.y = tc.valid ? int(rowOrder[s]) : 0;
+  tc.x = off;
+  return tc;
+}
 // grid size (in workgroups) that covers tilesX x tilesY tiles with the mapping above
 inline unsigned tileGrid(int tilesX, int tilesY)
 {

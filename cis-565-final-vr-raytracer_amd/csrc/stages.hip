@@ -282,7 +282,8 @@ __global__ __launch_bounds__(64, RT_DIRECT_LB) void k_direct_stage(DevScene S, D
 #if RT_WAVEPROF
   const uint64_t prof_c0 = clock64(), prof_w0 = wall_clock64();
 #endif
-  const TileCoord tile = tileOf(tilesX, tilesY);
+  const uint64_t row_c0 = F.rowCost ? clock64() : 0ull;
+  const TileCoord tile = tileOfOrdered(F.rowOrder, tilesX, tilesY);
   if(!tile.valid) return;
   const int lane = int(threadIdx.x);
   const i2 px{tile.x * 8 + (lane & 7), rowBegin + tile.y * 8 + (lane >> 3)};
@@ -303,6 +304,26 @@ __global__ __launch_bounds__(64, RT_DIRECT_LB) void k_direct_stage(DevScene S, D
 #if RT_WAVEPROF
   waveProfFlush(F, c, tile.x, tile.y, prof_c0, prof_w0);
 #endif
+  // what this tile cost, for the order of the NEXT launch's tile rows (every in-image lane of the wave arrives here together: one atomic per wave)
+  if(F.rowCost) {
+    const unsigned long long act = __ballot(1);
+    if(lane == __builtin_ctzll(act)) atomicAdd(&F.rowCost[tile.y], uint32_t((clock64() - row_c0) >> 8));
+  }
+}
+
+// tile rows by descending cost of the previous launch (stable: equal costs keep the screen order, the first frame's zeros give the identity); clears the costs
+__global__ __launch_bounds__(256) void k_row_order(uint32_t* rowCost, uint16_t* rowOrder, int tilesY)
+{
+  extern __shared__ uint32_t s_cost[];
+  for(int i = int(threadIdx.x); i < tilesY; i += int(blockDim.x)) s_cost[i] = rowCost[i];
+  __syncthreads();
+  for(int i = int(threadIdx.x); i < tilesY; i += int(blockDim.x)) {
+    const uint32_t ci = s_cost[i];
+    int rank = 0;
+    for(int j = 0; j < tilesY; j++) { const uint32_t cj = s_cost[j]; rank += (cj > ci || (cj == ci && j < i)) ? 1 : 0; }
+    rowOrder[rank] = uint16_t(i);
+    rowCost[i] = 0u;
+  }
 }
 #endif
 
@@ -1247,7 +1268,14 @@ hipError_t launchStage(hipStream_t stream, const DevScene& Sin, const DevFrame& 
       if(level != 1 && spatial) return rt::RT_FORWARD::launchStage(stream, Sin, F, st, cam, stage, 2, rowBegin, rowEnd);
 #else
       if(needOvf && grid.x * 64u > S.stackOvfThreads) return hipErrorInvalidConfiguration;   // overflow area missing / too small: an internal sizing error, not the caller's
-      if(level != 2) hipLaunchKernelGGL(k_direct_stage, grid, block, lds, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY);
+      if(level != 2) {
+        // full-frame launches take their tile rows in the order of what they cost last time (DevFrame::rowCost); row bands and chunked launches keep the screen order
+        DevFrame Fd = F;
+        const bool ordered = F.rowOrder && rowBegin == 0 && rowEnd == gh && tileChunk(tilesX, tilesY) == tilesX && tilesY <= 4096;
+        if(ordered) hipLaunchKernelGGL(k_row_order, dim3(1), dim3(256), size_t(tilesY) * sizeof(uint32_t), stream, F.rowCost, F.rowOrder, tilesY);
+        else { Fd.rowCost = nullptr; Fd.rowOrder = nullptr; }
+        hipLaunchKernelGGL(k_direct_stage, grid, block, lds, stream, S, Fd, st, cam, rowBegin, rowEnd, tilesX, tilesY);
+      }
       if(level != 1 && spatial) hipLaunchKernelGGL(k_direct_spatial, grid, block, 0, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY);
 #endif
       break;
