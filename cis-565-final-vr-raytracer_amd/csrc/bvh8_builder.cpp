@@ -327,7 +327,7 @@ struct BuilderS {
 // loses / gains a subtree; the exchange with the largest area reduction is applied.  Children are adjacent records (a, a + 1) and a record carries its
 // subtree by index, so an exchange is a swap of two records.  RESTIR_BVH_ROTATE = number of passes (0 = off).
 inline Box unite(const Box& x, const Box& y) { Box r = x; r.grow(y); return r; }
-uint64_t rotatePass(std::vector<N2>& N, uint32_t count)
+uint64_t rotatePass(std::vector<N2>& N, uint32_t count, bool gg)
 {
   uint64_t applied = 0;
   for(uint32_t n = count; n-- > 0;) {   // children have larger indices than their parent: reverse index order is bottom-up
@@ -351,8 +351,22 @@ uint64_t rotatePass(std::vector<N2>& N, uint32_t count)
       if(d2 < best) { best = d2; which = 2; }
       if(d3 < best) { best = d3; which = 3; }
     }
+    if(gg && !N[L].leaf && !N[R].leaf) {   // grandchild <-> grandchild across the two children: both child boxes change (LL <-> RL, LL <-> RR; the other two are mirror images)
+      const uint32_t LL = N[L].a, LR = N[L].a + 1, RL = N[R].a, RR = N[R].a + 1;
+      const float base = N[L].b.area() + N[R].b.area();
+      const float d4 = unite(N[RL].b, N[LR].b).area() + unite(N[LL].b, N[RR].b).area() - base;   // LL <-> RL
+      const float d5 = unite(N[RR].b, N[LR].b).area() + unite(N[RL].b, N[LL].b).area() - base;   // LL <-> RR
+      if(d4 < best) { best = d4; which = 4; }
+      if(d5 < best) { best = d5; which = 5; }
+      (void)LL;
+    }
     if(which < 0) continue;
-    if(which < 2) {
+    if(which >= 4) {
+      const uint32_t LL = N[L].a, g = N[R].a + uint32_t(which - 4);
+      std::swap(N[LL], N[g]);
+      N[L].b = unite(N[N[L].a].b, N[N[L].a + 1].b);
+      N[R].b = unite(N[N[R].a].b, N[N[R].a + 1].b);
+    } else if(which < 2) {
       const uint32_t g = N[R].a + uint32_t(which);
       std::swap(N[L], N[g]);
       N[R].b = unite(N[N[R].a].b, N[N[R].a + 1].b);
@@ -518,7 +532,7 @@ bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads)
     }
   }
   const size_t n = total;
-  out.nodes.clear(); out.tris.clear(); out.maxDepth = 0; out.sahNodeSteps = out.sahTriSteps = 0; out.references = 0; out.spatialSplits = 0; out.rotations = 0; out.reinsertions = 0;
+  out.nodes.clear(); out.tris.clear(); out.maxDepth = 0; out.sahNodeSteps = out.sahTriSteps = out.sahNodeStepsQ = out.sahTriStepsQ = 0; out.references = 0; out.spatialSplits = 0; out.rotations = 0; out.reinsertions = 0;
   if(n == 0) {  // a single empty node keeps the kernels branch-free
     Node8 e{}; e.ex = e.ey = e.ez = 127;
     out.nodes.push_back(e);
@@ -574,13 +588,14 @@ bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads)
     const bool dp = getenv("RESTIR_BVH_COLLAPSE") && strcmp(getenv("RESTIR_BVH_COLLAPSE"), "dp") == 0;
     const int rotate = dp ? 0 : (getenv("RESTIR_BVH_ROTATE") ? atoi(getenv("RESTIR_BVH_ROTATE")) : RT_BVH_ROTATE_DEFAULT);
     std::vector<N2>& M = BS ? BS->nodes : B2.nodes;
+    const bool rotateGG = getenv("RESTIR_BVH_ROTATE_GG") && atoi(getenv("RESTIR_BVH_ROTATE_GG")) != 0;
     const int reins = dp ? 0 : (getenv("RESTIR_BVH_REINSERT") ? atoi(getenv("RESTIR_BVH_REINSERT")) : RT_BVH_REINSERT_DEFAULT);
     if(reins > 0) {
       Reinserter RI(M, n2count);
       for(int pass = 0; pass < reins; pass++) RI.pass(0.02f);
       out.reinsertions = RI.moved;
     }
-    for(int pass = 0; pass < rotate; pass++) { const uint64_t k = rotatePass(M, n2count); out.rotations += k; if(k == 0) break; }
+    for(int pass = 0; pass < rotate; pass++) { const uint64_t k = rotatePass(M, n2count, rotateGG); out.rotations += k; if(k == 0) break; }
   }
   const std::vector<N2>& N = BS ? BS->nodes : B2.nodes;
   const std::vector<uint32_t>& leafTris = BS ? BS->leafTris : idx;
@@ -744,6 +759,16 @@ bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads)
     const double ra = std::max(1e-30, double(N[0].b.area()));
     out.sahNodeSteps += double(nb.area()) / ra;
     for(int i = 0; i < nc; i++) if(N[ch[i]].leaf) out.sahTriSteps += double(N[ch[i]].b.area()) / ra * double(std::min<uint32_t>(N[ch[i]].n, 3u));
+    // ... and the same expectation with the boxes the GPU tests: the children's boxes on this node's 8-bit grid (a thin triangle in a wide node grows to the grid step)
+    for(int s2 = 0; s2 < 8; s2++) {
+      if(childInSlot[s2] < 0) continue;
+      const N2& cq = N[ch[childInSlot[s2]]];
+      Box q;
+      for(int a = 0; a < 3; a++) { const float step = std::ldexp(1.0f, ex[a]); q.lo[a] = nb.lo[a] + float(qlo[a][s2]) * step; q.hi[a] = nb.lo[a] + float(qhi[a][s2]) * step; }
+      if(cq.leaf) out.sahTriStepsQ += double(q.area()) / ra * double(std::min<uint32_t>(cq.n, 3u));
+      else out.sahNodeStepsQ += double(q.area()) / ra;
+    }
+    if(w.wide == 0) out.sahNodeStepsQ += 1.0;   // the root itself
   }
   return true;
 }
@@ -756,7 +781,7 @@ bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads)
 // triangle.  With spatial splits a triangle has several references, each bounded by the part inside its cell: the check samples points on every triangle
 // (vertices, edge and interior points) and counts the points that no reference covers.  Decodes the nodes the way csrc/traverse.h does.
 extern "C" int rt_bvh8_selfcheck(const rt_scene_desc* scene, int samplesPerTri, uint64_t* out /* [8]: triangles, references, nodes, depth, spatial splits, uncovered points, points, 0 */,
-                                 double* outF /* [3]: SAH node steps, SAH triangle steps, build seconds */)
+                                 double* outF /* [5]: SAH node steps, SAH triangle steps, build seconds, the two SAH figures with the quantised child boxes */)
 {
   if(!scene || !out || !outF) return -1;
   rt::BuildOutput bo;
@@ -764,7 +789,7 @@ extern "C" int rt_bvh8_selfcheck(const rt_scene_desc* scene, int samplesPerTri, 
   const int threads = std::max(1, int(std::thread::hardware_concurrency()));
   if(!rt::buildBvh8(*scene, bo, threads)) return -2;
   outF[2] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  outF[0] = bo.sahNodeSteps; outF[1] = bo.sahTriSteps;
+  outF[0] = bo.sahNodeSteps; outF[1] = bo.sahTriSteps; outF[3] = bo.sahNodeStepsQ; outF[4] = bo.sahTriStepsQ;
   const size_t n = bo.triRef.size();
   // geometry by globalId (any reference of a triangle carries its full record)
   std::vector<const rt::Tri48*> byId(n, nullptr);

@@ -15,6 +15,7 @@ struct BuildOutput {
   std::vector<DevInstance> instances;
   int maxDepth = 0;
   double sahCost = 0;
+  double sahNodeStepsQ = 0, sahTriStepsQ = 0;  // the same with the 8-bit quantised child boxes the traversal tests
   double sahNodeSteps = 0, sahTriSteps = 0;   // SAH expectation of node / triangle steps of a ray that hits the root box (wide tree, build-time boxes)
   uint64_t references = 0;                   // leaf records (= tris.size()): > the triangle count when spatial splits duplicated references
   uint64_t spatialSplits = 0, rotations = 0, reinsertions = 0;

@@ -1,0 +1,90 @@
+"""bench.py's N > 1 bookkeeping that no one-GPU box can execute end to end (round-4 verdict, item 2): the default `--gpus N` run reports BOTH hosts in one line — the
+RCCL host it was launched as and the native host (child process) — with `value` from the faster host whose tiled == untiled gate passed.  The child is faked here; the
+gate itself runs over gloo in tests/test_tiled_gloo.py and on the GPU in tests/test_gpu_bench_cli.py."""
+import json
+import os
+import subprocess
+import sys
+import types
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def _args():
+    return types.SimpleNamespace(gpus=8, steps=20, warmup=5, config=4, scene_footprint="real", scale=1.0, verify_frames=3, moving_camera=False, equal_bands=False, width=0, height=0)
+
+
+def _line(value, ok=True, **kw):
+    d = {"metric": "Mrays/s", "value": value, "ms_per_step": 1000.0 / value, "n_gpus": 8, "tiled_equals_untiled": ok, "tiled_equals_untiled_moving_camera": ok, "history_fallbacks": 0}
+    d.update(kw)
+    return d
+
+
+def _fake_child(monkeypatch, stdout="", returncode=0, stderr="", raises=None):
+    calls = []
+
+    def run(cmd, **kw):
+        calls.append((cmd, kw))
+        if raises:
+            raise raises
+        return types.SimpleNamespace(stdout=stdout, stderr=stderr, returncode=returncode)
+    monkeypatch.setattr(subprocess, "run", run)
+    monkeypatch.setattr(bench.time, "sleep", lambda s: None)
+    return calls
+
+
+def test_faster_verified_host_becomes_the_value(monkeypatch):
+    calls = _fake_child(monkeypatch, stdout="noise\n" + json.dumps(_line(2600.0, host="native", links={"x": 1})) + "\n")
+    monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("WORLD_SIZE", "8"); monkeypatch.setenv("MASTER_PORT", "1234")
+    out = bench.both_hosts(_args(), _line(2100.0, rccl_ranks=8, rccl="ok", peer_access=[[1]]))
+    assert out["host"] == "native" and out["value"] == 2600.0 and out["links"] == {"x": 1}
+    assert out["hosts"]["rccl"]["value"] == 2100.0 and out["hosts"]["native"]["value"] == 2600.0 and out["hosts_all_verified"] is True
+    assert out["rccl_ranks"] == 8 and out["rccl"] == "ok" and out["tiled_equals_untiled"] is True
+    cmd, kw = calls[0]
+    assert "--native" in cmd and cmd[cmd.index("--gpus") + 1] == "8" and cmd[cmd.index("--steps") + 1] == "20" and cmd[cmd.index("--scene-footprint") + 1] == "real"
+    assert not any(k in kw["env"] for k in ("RANK", "WORLD_SIZE", "MASTER_PORT"))      # the child is ONE process: no launcher environment
+
+
+def test_rccl_stays_when_it_is_faster_or_the_child_fails(monkeypatch):
+    _fake_child(monkeypatch, stdout=json.dumps(_line(1500.0, host="native")))
+    out = bench.both_hosts(_args(), _line(2100.0, rccl_ranks=8))
+    assert out["host"] == "rccl" and out["value"] == 2100.0 and out["hosts"]["native"]["value"] == 1500.0
+    _fake_child(monkeypatch, stdout="", returncode=1, stderr="hipErrorNoDevice")
+    out = bench.both_hosts(_args(), _line(2100.0, rccl_ranks=8))
+    assert out["host"] == "rccl" and out["hosts"]["native"] is None and "hipErrorNoDevice" in out["hosts"]["native_error"] and out["hosts_all_verified"] is False
+    _fake_child(monkeypatch, raises=subprocess.TimeoutExpired("bench.py", 1500))
+    out = bench.both_hosts(_args(), _line(2100.0, rccl_ranks=8))
+    assert out["host"] == "rccl" and "TimeoutExpired" in out["hosts"]["native_error"]
+
+
+def test_a_host_whose_gate_failed_never_supplies_the_value(monkeypatch):
+    _fake_child(monkeypatch, stdout=json.dumps(_line(9000.0, ok=False, host="native")), returncode=3)
+    out = bench.both_hosts(_args(), _line(2100.0, rccl_ranks=8))
+    assert out["host"] == "rccl" and out["value"] == 2100.0 and out["tiled_equals_untiled"] is True and out["hosts_all_verified"] is False
+    assert out["hosts"]["native"]["tiled_equals_untiled"] is False
+    _fake_child(monkeypatch, stdout=json.dumps(_line(1800.0, host="native")))
+    out = bench.both_hosts(_args(), _line(2100.0, ok=False, rccl_ranks=8))
+    assert out["host"] == "native" and out["value"] == 1800.0 and out["tiled_equals_untiled"] is True
+    _fake_child(monkeypatch, stdout=json.dumps(_line(1800.0, ok=False, host="native")), returncode=3)
+    out = bench.both_hosts(_args(), _line(2100.0, ok=False, rccl_ranks=8))
+    assert out["tiled_equals_untiled"] is False          # nothing verified: main() then exits non-zero
+
+
+def test_attach_verdict():
+    out = {}
+    bench.attach_verdict(out, None)
+    assert out["tiled_equals_untiled"] is None and "skipped" in out["verify"]
+    ver = {"workload": {"equal": True, "buffers": {}}, "moving_camera": {"equal": False, "buffers": {}}}
+    bench.attach_verdict(out, ver)
+    assert out["tiled_equals_untiled"] is True and out["tiled_equals_untiled_moving_camera"] is False and out["verify"] is ver
+
+
+def test_workload_keys():
+    assert bench.workload_key(4, False, "real") == "config4_real" and bench.workload_key(4, True, "real") == "config4_moving_real"
+    assert bench.workload_key(4, False, "lite") == "config4" and bench.workload_key(5, True, "real") == "config5" and bench.workload_key(3, False, "real") == "config3_real"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--print-workload-key", "--config", "3"], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0 and p.stdout.strip() == "config3_real"

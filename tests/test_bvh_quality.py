@@ -20,7 +20,7 @@ def _check(kind, scale, samples=12, **env):
         os.environ.update({k: str(v) for k, v in env.items()})
         sc = host.Scene().makeProcedural(kind, scale, 1)
         desc = sc.desc(None)
-        out, outf = (C.c_uint64 * 8)(), (C.c_double * 3)()
+        out, outf = (C.c_uint64 * 8)(), (C.c_double * 5)()
         assert L.rt_bvh8_selfcheck(C.byref(desc), samples, out, outf) == 0
         return dict(tris=out[0], refs=out[1], nodes=out[2], depth=out[3], splits=out[4], uncovered=out[5], points=out[6], rotations=out[7] & 0xffffffff,
                     reinsertions=out[7] >> 32, sah_nodes=outf[0], sah_tris=outf[1])
