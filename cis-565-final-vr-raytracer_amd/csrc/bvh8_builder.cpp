@@ -584,8 +584,7 @@ bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads)
     out.references = n; out.spatialSplits = 0;
   }
   {
-    // (not with RESTIR_BVH_COLLAPSE=dp: that pass walks the records in index order and relies on children having larger indices than their parent, which a swap breaks)
-    const bool dp = getenv("RESTIR_BVH_COLLAPSE") && strcmp(getenv("RESTIR_BVH_COLLAPSE"), "dp") == 0;
+    const bool dp = false;   // (the SAH-optimal collapse takes its bottom-up order from the tree itself since round 5: the passes below may run before it)
     const int rotate = dp ? 0 : (getenv("RESTIR_BVH_ROTATE") ? atoi(getenv("RESTIR_BVH_ROTATE")) : RT_BVH_ROTATE_DEFAULT);
     std::vector<N2>& M = BS ? BS->nodes : B2.nodes;
     const bool rotateGG = getenv("RESTIR_BVH_ROTATE_GG") && atoi(getenv("RESTIR_BVH_ROTATE_GG")) != 0;
@@ -618,7 +617,15 @@ bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads)
   std::vector<uint8_t> k8;        // [n]: left child's share of the 8 slots when n becomes a wide node
   if(useDp) {
     cost.assign(size_t(n2count) * 8, 0.f); choice.assign(size_t(n2count) * 8, 0); k8.assign(n2count, 1);
-    for(uint32_t n = n2count; n-- > 0;) {   // children have larger indices than their parent: this order is bottom-up
+    // bottom-up order: children before their parent.  The builders allocate children after their parent, but the quality passes move records (a rotation swaps
+    // two records, a reinsertion moves three), so the order is taken from the tree itself
+    std::vector<uint32_t> post; post.reserve(n2count);
+    {
+      std::vector<uint32_t> st2; st2.push_back(0u);
+      while(!st2.empty()) { const uint32_t q = st2.back(); st2.pop_back(); post.push_back(q); if(!N[q].leaf) { st2.push_back(N[q].a); st2.push_back(N[q].a + 1); } }
+    }
+    for(size_t pi = post.size(); pi-- > 0;) {   // reverse pre-order: every node comes after all of its descendants
+      const uint32_t n = post[pi];
       const N2& x = N[n];
       const float A = x.b.area();
       float* c = &cost[size_t(n) * 8];
