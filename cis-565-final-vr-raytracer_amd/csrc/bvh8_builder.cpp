@@ -141,7 +141,7 @@ struct BuilderS {
   std::atomic<uint64_t> spatialSplits{0};
   int maxThreads;
   float rootArea = 1.f, alpha = 1e-5f;
-  int NB = 16;
+  int NB = 16, NBS = 16;   // bins of the object / of the spatial split search
   float leafSlotCost = 0.25f;
   BuilderS(const std::vector<Tri48>& f, float pad_, size_t n, double budgetFrac, int threads)
     : flat(f), pad(pad_), nodes(2 * (n + size_t(double(n) * budgetFrac)) + 16), leafTris(n + size_t(double(n) * budgetFrac) + 16), budget(int64_t(double(n) * budgetFrac)), maxThreads(threads) {}
@@ -239,23 +239,23 @@ struct BuilderS {
           const float lo = nb.lo[ax], ext = nb.hi[ax] - nb.lo[ax];
           if(!(ext > 0)) continue;
           Box bb[NBMAX]; uint32_t en[NBMAX], exx[NBMAX];
-          for(int i = 0; i < NB; i++) { bb[i].reset(); en[i] = exx[i] = 0; }
-          const float k1 = NB * (1.f - 1e-6f) / ext, w = ext / NB;
+          for(int i = 0; i < NBS; i++) { bb[i].reset(); en[i] = exx[i] = 0; }
+          const float k1 = NBS * (1.f - 1e-6f) / ext, w = ext / NBS;
           for(const Ref& r : refs) {
-            const int b0 = std::min(NB - 1, std::max(0, int((r.b.lo[ax] - lo) * k1))), b1 = std::min(NB - 1, std::max(b0, int((r.b.hi[ax] - lo) * k1)));
+            const int b0 = std::min(NBS - 1, std::max(0, int((r.b.lo[ax] - lo) * k1))), b1 = std::min(NBS - 1, std::max(b0, int((r.b.hi[ax] - lo) * k1)));
             en[b0]++; exx[b1]++;
             if(b0 == b1) { bb[b0].grow(r.b); continue; }
             for(int bi = b0; bi <= b1; bi++) {
               Box cell = r.b, part;
-              cell.lo[ax] = std::max(cell.lo[ax], lo + w * float(bi)); cell.hi[ax] = std::min(cell.hi[ax], bi == NB - 1 ? nb.hi[ax] : lo + w * float(bi + 1));
+              cell.lo[ax] = std::max(cell.lo[ax], lo + w * float(bi)); cell.hi[ax] = std::min(cell.hi[ax], bi == NBS - 1 ? nb.hi[ax] : lo + w * float(bi + 1));
               if(cell.lo[ax] <= cell.hi[ax] && clipBounds(r.tri, cell, part)) bb[bi].grow(part);
             }
           }
           Box rb[NBMAX]; uint32_t rc[NBMAX];
           Box acc; acc.reset(); uint32_t c = 0;
-          for(int i = NB - 1; i > 0; i--) { acc.grow(bb[i]); c += exx[i]; rb[i] = acc; rc[i] = c; }
+          for(int i = NBS - 1; i > 0; i--) { acc.grow(bb[i]); c += exx[i]; rb[i] = acc; rc[i] = c; }
           acc.reset(); c = 0;
-          for(int i = 0; i < NB - 1; i++) {
+          for(int i = 0; i < NBS - 1; i++) {
             acc.grow(bb[i]); c += en[i];
             if(c == 0 || rc[i + 1] == 0 || c >= cnt || rc[i + 1] >= cnt) continue;   // a cut that leaves every reference on one side makes no progress
             const float cost = acc.area() * c + rb[i + 1].area() * rc[i + 1];
@@ -574,6 +574,7 @@ bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads)
     }
     BS->rootArea = std::max(root.area(), 1e-30f); BS->alpha = splitAlpha;
     BS->NB = getenv("RESTIR_BVH_BINS") ? std::min(64, std::max(4, atoi(getenv("RESTIR_BVH_BINS")))) : 16;
+    BS->NBS = getenv("RESTIR_BVH_SBINS") ? std::min(64, std::max(4, atoi(getenv("RESTIR_BVH_SBINS")))) : 16;
     BS->leafSlotCost = getenv("RESTIR_BVH_SLOTCOST") ? float(atof(getenv("RESTIR_BVH_SLOTCOST"))) : 0.25f;
     BS->build(0, std::move(refs));
     n2count = BS->nodeCount.load();
