@@ -202,6 +202,46 @@ def test_tiled_three_ranks_equals_untiled(bistro, mode, monkeypatch):
             assert np.array_equal(got, want.reshape(-1, w * elem)[a:e]), (abi.BUFFER_NAMES[b], rank)
 
 
+@pytest.mark.parametrize("orbit", [False, True], ids=["static-camera", "orbiting-camera"])
+def test_bench_gate_on_three_thread_ranks(bistro, orbit):
+    """bench.py's tiled == untiled gate (restir_amd/verify.py) with the backend and the frame class the RCCL host uses — HIP renderers, frames in flight, rotating G-buffers —
+    on three thread-ranks of ONE GPU: cold history, three frames on an uneven partition, every distributed buffer gathered to rank 0, SHA-256 of all six frame buffers
+    against the untiled frames.  (The transport-independent part of the first real multi-device run; the same function over gloo: tests/test_tiled_gloo.py.)"""
+    import copy
+    import torch
+    from restir_amd import tiled, verify as V
+    sc, env, st, _cam = bistro
+    world, part = 3, [0, 496, 560, H]
+    s2, _ = make_scene(abi.PROC_BISTRO_EXT, 1.0, 1, None)
+    cams = V.verify_cameras(s2, W, H, s2.cameraPose(), orbit, 3)
+    rs = [_renderer(sc, env) for _ in range(world)]
+    shared = {"renderers": rs, "barrier": threading.Barrier(world), "slot": [None] * world, "flags": [False] * world}
+    errors, got = [], {}
+
+    def rank_main(rank):
+        try:
+            torch.cuda.set_device(0)
+            rs[rank].update(W, H)                                   # cold history, as the bench does before the gate
+            st_r = copy.copy(st)
+            fr, cur = V.render_tiled(tiled.PipelinedTiledFrame, tiled.RendererTensors(rs[rank]), ThreadComm(rank, world, shared), W, H, part, cams, st_r, rs[rank].set_camera)
+            rs[rank].sync()
+            if rank == 0:
+                got["tiled"] = V.digests(rs[0].readback, cur); got["cur"] = cur
+        except Exception as e:  # pragma: no cover
+            errors.append(e); shared["barrier"].abort()
+
+    th = [threading.Thread(target=rank_main, args=(i,)) for i in range(world)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not errors, errors
+    ref = _renderer(sc, env)
+    cur = V.render_untiled(ref.run, ref.set_camera, cams, copy.copy(st)); ref.sync()
+    assert cur == got["cur"]
+    verdict = V.compare(got["tiled"], V.digests(ref.readback, cur))
+    assert verdict["equal"] and len(verdict["buffers"]) == 6, verdict
+    for r in rs + [ref]:
+        r.destroy()
+
+
 def test_nccl_single_rank_collectives_on_ctx_buffers():
     """The RCCL code path of restir_amd/tiled.py with world_size 1: in-place all-gathers on the ctx-owned HBM buffers wrapped
     as torch tensors, kernels on torch's current stream.  (Multi-rank logic is covered by tests/test_tiled_gloo.py.)"""
