@@ -702,6 +702,33 @@ bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads)
       }
       done[bc] = true; slotUsed[bs] = true; slotOf[bc] = bs;
     }
+    // RESTIR_BVH_SLOTS=opt (experiment, profiles/r05_bvh_quality_ab.txt): the assignment that MAXIMISES the summed projection (Ylitie et al. 2017 solve it with an
+    // auction; with 8 x 8 an exact subset DP is 2 k steps per node) instead of the greedy best pair above
+    static const bool optSlots = getenv("RESTIR_BVH_SLOTS") && strcmp(getenv("RESTIR_BVH_SLOTS"), "opt") == 0;
+    if(optSlots && nc > 1) {
+      float score[8][8];
+      for(int i = 0; i < nc; i++) {
+        const Box& cb = N[ch[i]].b;
+        const float d[3] = {0.5f * (cb.lo[0] + cb.hi[0]) - cen[0], 0.5f * (cb.lo[1] + cb.hi[1]) - cen[1], 0.5f * (cb.lo[2] + cb.hi[2]) - cen[2]};
+        for(int s2 = 0; s2 < 8; s2++) score[i][s2] = d[0] * slotSign(s2, 0) + d[1] * slotSign(s2, 1) + d[2] * slotSign(s2, 2);
+      }
+      // dp[mask] = best total for children 0 .. popcount(mask) - 1 placed in the slots of mask
+      float dp[256]; int8_t from[256];
+      for(int m = 0; m < 256; m++) { dp[m] = -3e38f; from[m] = -1; }
+      dp[0] = 0.f;
+      for(int m = 0; m < 256; m++) {
+        const int i = __builtin_popcount(unsigned(m));
+        if(i >= nc || dp[m] < -1e38f) continue;
+        for(int s2 = 0; s2 < 8; s2++) {
+          if(m & (1 << s2)) continue;
+          const float v = dp[m] + score[i][s2];
+          if(v > dp[m | (1 << s2)]) { dp[m | (1 << s2)] = v; from[m | (1 << s2)] = int8_t(s2); }
+        }
+      }
+      int bestMask = -1; float bestV = -3e38f;
+      for(int m = 0; m < 256; m++) if(__builtin_popcount(unsigned(m)) == nc && dp[m] > bestV) { bestV = dp[m]; bestMask = m; }
+      for(int i = nc - 1, m = bestMask; i >= 0; i--) { const int s2 = from[m]; slotOf[i] = s2; m &= ~(1 << s2); }
+    }
     int childInSlot[8]; for(int s = 0; s < 8; s++) childInSlot[s] = -1;
     for(int i = 0; i < nc; i++) childInSlot[slotOf[i]] = i;
 

@@ -31,6 +31,10 @@ struct rt_ctx {
   hipEvent_t evD[4] = {}, evI[4] = {}, evDone[4] = {};
   uint64_t seq = 0;          // frames submitted through the pipelined path since the last join
   bool inFlight = false;     // work may be pending on indStream / sideStream
+  // One stream per (role, level), created on first use and kept until rt_destroy: a stream takes a hardware queue of its priority class round-robin at creation, so a
+  // context that destroyed and re-created its streams while trying settings ended with its filter stream on the main stream's queue (the 5th normal-priority stream of
+  // the process lands on the 1st one's queue): 3.38 -> 3.71 ms per frame, found by two back-to-back bench lines in round 5.
+  hipStream_t indStreams[3] = {nullptr, nullptr, nullptr}, sideStreams[3] = {nullptr, nullptr, nullptr};   // index = level + 1
   int prio[3] = {0, 1, 0};   // priority level of the main / indirect / filter stream (-1 low, 0 normal, +1 high): prioSpec() at rt_create, rt_set_stream_priorities, rt_tune_stream_priorities
   bool prioFromEnv = false;  // RESTIR_PRIO was set: the tuner leaves the streams alone (A/B scripts stay in control)
   void* dSky = nullptr;      // SkyPre (csrc/sky.h), valid while sunAndSky.in_use == 1
@@ -356,6 +360,9 @@ int rt_destroy(rt_ctx* c)
   if(c->spareG) (void)hipFree(c->spareG);
   if(c->spareMotion) (void)hipFree(c->spareMotion);
   for(void* p : c->indA) if(p && p != c->bufs[RT_BUF_DENOISE_IND_A]) (void)hipFree(p);
+  for(hipStream_t& q : c->indStreams) { if(q) (void)hipStreamDestroy(q); q = nullptr; }
+  for(hipStream_t& q : c->sideStreams) { if(q) (void)hipStreamDestroy(q); q = nullptr; }
+  c->indStream = c->sideStream = nullptr;
   if(c->indStream) (void)hipStreamDestroy(c->indStream);
   for(int i = 0; i < 4; i++) { if(c->evD[i]) (void)hipEventDestroy(c->evD[i]); if(c->evI[i]) (void)hipEventDestroy(c->evI[i]); if(c->evDone[i]) (void)hipEventDestroy(c->evDone[i]); }
   if(c->dCounters) (void)hipFree(c->dCounters);
@@ -709,8 +716,11 @@ static hipError_t ensureOverlapStreams(rt_ctx* c)
 {
   if(c->sideStream && c->indStream) return hipSuccess;
   hipError_t e = hipSuccess;
-  if(!c->sideStream) e = createStreamLevel(&c->sideStream, 2, c->prio[2]);
-  if(e == hipSuccess && !c->indStream) e = createStreamLevel(&c->indStream, 1, c->prio[1]);
+  hipStream_t& side = c->sideStreams[c->prio[2] + 1];
+  hipStream_t& ind = c->indStreams[c->prio[1] + 1];
+  if(!side) e = createStreamLevel(&side, 2, c->prio[2]);
+  if(e == hipSuccess && !ind) e = createStreamLevel(&ind, 1, c->prio[1]);
+  c->sideStream = side; c->indStream = ind;
   return e;
 }
 
@@ -1090,10 +1100,9 @@ int rt_set_stream_priorities(rt_ctx* c, int indirectLevel, int filterLevel)
   RT_HIP(c, hipSetDevice(c->device));
   RT_HIP(c, syncAll(c));
   if(c->prio[1] == indirectLevel && c->prio[2] == filterLevel) return RT_OK;
-  if(c->indStream) { (void)hipStreamDestroy(c->indStream); c->indStream = nullptr; }
-  if(c->sideStream) { (void)hipStreamDestroy(c->sideStream); c->sideStream = nullptr; }
   c->prio[1] = indirectLevel; c->prio[2] = filterLevel;
-  return RT_OK;   // (the streams are created on first use: ensureOverlapStreams)
+  c->indStream = c->sideStream = nullptr;   // (selected — and created, once per level — on first use: ensureOverlapStreams; streams of other levels stay alive, idle)
+  return RT_OK;
 }
 
 /* One-time tuning at load time (like the BVH build: before the first frame, outside any timed region): renders `framesPerCandidate` frames in flight under each

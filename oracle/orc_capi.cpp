@@ -140,6 +140,7 @@ int orc_get_counters(void* p, rt_counters* out)
 {
   Ctx* c = static_cast<Ctx*>(p);
   memset(out, 0, sizeof(*out));
+  c->scene.counters.flush();   // (what the calling thread itself counted: single-threaded stages, orc_trace_*)
   out->closestHitRays = c->scene.counters.closestHitRays; out->anyHitRays = c->scene.counters.anyHitRays;
   out->nodesVisited = c->scene.counters.nodesVisited; out->trisTested = c->scene.counters.trisTested;
   out->hitsShaded = c->scene.counters.hitsShaded; out->risCandidates = c->scene.counters.risCandidates;

@@ -221,7 +221,7 @@ struct RaySlab {
 
 Hit Scene::closestHit(vec3 o, vec3 d, uint32_t raySeed) const
 {
-  counters.closestHitRays++;
+  Counters::local().closestHitRays++;
   Hit best;
   if(tris.empty() || hasNan(o) || hasNan(d)) return best;
   RaySlab R(o, d);
@@ -255,13 +255,13 @@ Hit Scene::closestHit(vec3 o, vec3 d, uint32_t raySeed) const
       else if(hb) stack[sp++] = n.left + 1;
     }
   }
-  counters.nodesVisited += nv; counters.trisTested += tt;
+  Counters::local().nodesVisited += nv; Counters::local().trisTested += tt;
   return best;
 }
 
 bool Scene::anyHit(vec3 o, vec3 d, float tmax, uint32_t raySeed) const
 {
-  counters.anyHitRays++;
+  Counters::local().anyHitRays++;
   if(tris.empty() || hasNan(o) || hasNan(d) || !(tmax > 0.0f)) return false;
   RaySlab R(o, d);
   uint32_t stack[128]; int sp = 0;
@@ -286,7 +286,7 @@ bool Scene::anyHit(vec3 o, vec3 d, float tmax, uint32_t raySeed) const
       }
     } else { stack[sp++] = n.left; stack[sp++] = n.left + 1; }
   }
-  counters.nodesVisited += nv; counters.trisTested += tt;
+  Counters::local().nodesVisited += nv; Counters::local().trisTested += tt;
   return found;
 }
 

@@ -40,9 +40,25 @@ struct Hit {
   float u = 0, v = 0;
 };
 
+// Ray / step counters.  Every thread counts into its own thread-local block (`local()`) and adds it to the shared totals when it has finished a row
+// (`flush()`; Frame::parallelRows, the C entry points): until round 5 every ray did four atomic increments on ONE cache line shared by all worker threads,
+// which capped the 256-thread CPU baseline of bench.py at 1.6-3.3x of a single thread and made it bimodal (profiles/r05_cpu_baseline.txt).
 struct Counters {
+  struct Local { uint64_t closestHitRays = 0, anyHitRays = 0, nodesVisited = 0, trisTested = 0, hitsShaded = 0, risCandidates = 0; };
   std::atomic<uint64_t> closestHitRays{0}, anyHitRays{0}, nodesVisited{0}, trisTested{0}, hitsShaded{0}, risCandidates{0};
-  void reset() { closestHitRays = anyHitRays = nodesVisited = trisTested = hitsShaded = risCandidates = 0; }
+  static Local& local() { static thread_local Local l; return l; }
+  void flush()
+  {
+    Local& l = local();
+    if(l.closestHitRays) closestHitRays += l.closestHitRays;
+    if(l.anyHitRays) anyHitRays += l.anyHitRays;
+    if(l.nodesVisited) nodesVisited += l.nodesVisited;
+    if(l.trisTested) trisTested += l.trisTested;
+    if(l.hitsShaded) hitsShaded += l.hitsShaded;
+    if(l.risCandidates) risCandidates += l.risCandidates;
+    l = Local{};
+  }
+  void reset() { local() = Local{}; closestHitRays = anyHitRays = nodesVisited = trisTested = hitsShaded = risCandidates = 0; }
 };
 
 struct Texture {

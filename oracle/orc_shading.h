@@ -363,7 +363,7 @@ struct Shader {
   // ------------------------------------------------------------------------------------ shade_state.glsl
   State GetState(vec3 rayDir) const  // GetState, shade_state.glsl:147-221 (payload = last ClosestHit)
   {
-    S.counters.hitsShaded++;
+    Counters::local().hitsShaded++;
     State state;
     const Tri& T = S.tris[hitTri];
     const rt_instance& inst = S.instances[T.inst];
@@ -546,7 +546,7 @@ struct Shader {
   }
   float SampleDirectLightNoVisibility(vec3 pos, rt_light_sample& ls)  // :161-183
   {
-    S.counters.risCandidates++;
+    Counters::local().risCandidates++;
     lastLightId = 0xffffffffu;
     ls = zeroLightSample();
     float r = rnd(seed);

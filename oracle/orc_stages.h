@@ -79,7 +79,8 @@ void Frame::parallelRows(int rows, int rowBegin, int rowEnd, F&& fn) const
   if(rowEnd <= 0 || rowEnd > rows) rowEnd = rows;
   if(rowBegin < 0) rowBegin = 0;
   int nt = std::max(1, std::min(threads, rowEnd - rowBegin));
-  if(nt == 1) { for(int y = rowBegin; y < rowEnd; y++) fn(y); return; }
+  Counters& cnt = const_cast<Counters&>(scene->counters);
+  if(nt == 1) { for(int y = rowBegin; y < rowEnd; y++) fn(y); cnt.flush(); return; }
   std::vector<std::thread> pool;
   std::atomic<int> next{rowBegin};
   std::vector<int> cpus;
@@ -88,7 +89,7 @@ void Frame::parallelRows(int rows, int rowBegin, int rowEnd, F&& fn) const
     if(sched_getaffinity(0, sizeof(set), &set) == 0) for(int c = 0; c < CPU_SETSIZE; c++) if(CPU_ISSET(c, &set)) cpus.push_back(c);
   }
   for(int t = 0; t < nt; t++) {
-    pool.emplace_back([&] { for(;;) { int y = next.fetch_add(1); if(y >= rowEnd) break; fn(y); } });
+    pool.emplace_back([&] { for(;;) { int y = next.fetch_add(1); if(y >= rowEnd) break; fn(y); } cnt.flush(); });
     if(!cpus.empty()) { cpu_set_t one; CPU_ZERO(&one); CPU_SET(cpus[size_t(t) % cpus.size()], &one); (void)pthread_setaffinity_np(pool.back().native_handle(), sizeof(one), &one); }
   }
   for(auto& th : pool) th.join();
