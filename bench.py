@@ -282,10 +282,43 @@ def main():
         # load-time choice of the stream priorities (round 5): which of the indirect / filter streams should be high or low depends on the workload
         # (profiles/r05_prio_by_config_ab.txt); the tuner renders a few throw-away frames per setting and leaves the history cold — setup, like the BVH build
         r.set_camera(scene.getCamera()); st.time = 999
-        if args.stream_priorities == "tune" and not args.profile_run:
+        if args.stream_priorities == "tune" and not args.profile_run and orbit and os.environ.get("RESTIR_PRIO") is None:
+            # a moving camera: the library's tuner renders the CURRENT camera, and what is critical under motion (less temporal reuse, other rows in view) is not what is
+            # critical at rest (config 5: the static frames prefer the filter stream low, the orbit prefers it high) — so the candidates are timed here on the workload's
+            # own camera path (the same five settings, rt_set_stream_priorities), then the history is re-initialised and the path starts over
+            t_tune = time.time()
+            cands = [(1, 0), (1, 1), (0, 1), (0, -1), (1, -1)]
+            names = ["ind+ filter0", "ind+ filter+", "ind0 filter+", "ind0 filter-", "ind+ filter-"]
+            ms_c, ft = [], 0
+
+            def tune_frame(ft):
+                st.time = 1000 + ft
+                a = np.deg2rad(0.5 * (ft + 1))
+                rot = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], dtype=np.float32)
+                scene.setCamera(center0 + rot @ (eye0 - center0), center0, up0, fov0)
+                scene.updateCamera(W, H); r.set_camera(scene.getCamera()); r.run(st, ft)
+            for lv in cands:
+                r.set_stream_priorities(*lv)
+                for _k in range(6):
+                    tune_frame(ft); ft += 1
+                r.sync(); t1 = time.perf_counter()
+                for _k in range(40):
+                    tune_frame(ft); ft += 1
+                r.sync(); ms_c.append((time.perf_counter() - t1) / 40 * 1e3)
+            best = 0
+            for i in range(1, 5):
+                if ms_c[i] < ms_c[best] * 0.99:
+                    best = i
+            r.set_stream_priorities(*cands[best])
+            r.update(W, H)                                    # cold history; the camera path starts over
+            scene.setCamera(eye0, center0, up0, fov0); scene.updateCamera(W, H); scene.updateCamera(W, H)
+            prio_tuning = {"chosen": list(cands[best]), "ms_per_frame": {n: round(v, 4) for n, v in zip(names, ms_c)}, "seconds": round(time.time() - t_tune, 3),
+                           "how": "bench.py on the workload's own camera path (40 frames per setting, wall clock)"}
+        elif args.stream_priorities == "tune" and not args.profile_run:
             t_tune = time.time()
             prio_tuning = r.tune_stream_priorities(st, 24)
             prio_tuning["seconds"] = round(time.time() - t_tune, 3)
+            prio_tuning["how"] = "rt_tune_stream_priorities (24 frames per setting at the current camera, steady-state period from events)"
         elif "," in args.stream_priorities:
             lv = [int(x) for x in args.stream_priorities.split(",")]
             r.set_stream_priorities(lv[0], lv[1])
