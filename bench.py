@@ -182,9 +182,8 @@ def main():
                                                          "event-ordered peer pulls) instead of one process per GPU over RCCL; same JSON line plus the measured link time of every pull group")
     ap.add_argument("--devices", type=str, default="", help="--native: explicit device list, e.g. 0,1,2,3; a list with repeats (0,0) runs several ranks on one device — a functional check "
                                                             "of the host (tests/test_gpu_bench_cli.py), reported with n_gpus = the number of DISTINCT devices")
-    ap.add_argument("--stream-priorities", type=str, default="tune", help="N = 1: `tune` (default) = load-time tuning of the indirect / filter stream priorities "
-                    "(rt_tune_stream_priorities, outside the timed region, reported in the line), `default` = the library default (+1, 0), or `i,f` with levels -1 / 0 / +1; "
-                    "--profile-run uses the library default unless levels are given")
+    ap.add_argument("--stream-priorities", type=str, default="auto", help="N = 1: `auto` (default) = the library decides at its first frame (rt_render_frame; reported in the "
+                    "line), `default` = the levels of rounds 2-4 (+1, 0), or `i,f` with levels -1 / 0 / +1")
     ap.add_argument("--verify-frames", type=int, default=3, help="N > 1: frames of the tiled == untiled gate after the timed region (0 = skip the gate; the line then says so)")
     ap.add_argument("--single-host", action="store_true", help="N > 1 without --native: time the RCCL host only (default: rank 0 then also runs the native host in a child process and "
                                                                 "reports both, the faster as `value`)")
@@ -277,52 +276,14 @@ def main():
 
     eye0, center0, up0, fov0 = scene.cameraPose()
     scene.updateCamera(W, H)  # prime the camera history (static camera unless --moving-camera / config 5: SURVEY.md §8d)
-    prio_tuning = None
-    if world == 1 and not di_only:
-        # load-time choice of the stream priorities (round 5): which of the indirect / filter streams should be high or low depends on the workload
-        # (profiles/r05_prio_by_config_ab.txt); the tuner renders a few throw-away frames per setting and leaves the history cold — setup, like the BVH build
-        r.set_camera(scene.getCamera()); st.time = 999
-        if args.stream_priorities == "tune" and not args.profile_run and orbit and os.environ.get("RESTIR_PRIO") is None:
-            # a moving camera: the library's tuner renders the CURRENT camera, and what is critical under motion (less temporal reuse, other rows in view) is not what is
-            # critical at rest (config 5: the static frames prefer the filter stream low, the orbit prefers it high) — so the candidates are timed here on the workload's
-            # own camera path (the same five settings, rt_set_stream_priorities), then the history is re-initialised and the path starts over
-            t_tune = time.time()
-            cands = [(1, 0), (1, 1), (0, 1), (0, -1), (1, -1)]
-            names = ["ind+ filter0", "ind+ filter+", "ind0 filter+", "ind0 filter-", "ind+ filter-"]
-            ms_c, ft = [], 0
-
-            def tune_frame(ft):
-                st.time = 1000 + ft
-                a = np.deg2rad(0.5 * (ft + 1))
-                rot = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], dtype=np.float32)
-                scene.setCamera(center0 + rot @ (eye0 - center0), center0, up0, fov0)
-                scene.updateCamera(W, H); r.set_camera(scene.getCamera()); r.run(st, ft)
-            for lv in cands:
-                r.set_stream_priorities(*lv)
-                for _k in range(6):
-                    tune_frame(ft); ft += 1
-                r.sync(); t1 = time.perf_counter()
-                for _k in range(40):
-                    tune_frame(ft); ft += 1
-                r.sync(); ms_c.append((time.perf_counter() - t1) / 40 * 1e3)
-            best = 0
-            for i in range(1, 5):
-                if ms_c[i] < ms_c[best] * 0.99:
-                    best = i
-            r.set_stream_priorities(*cands[best])
-            r.update(W, H)                                    # cold history; the camera path starts over
-            scene.setCamera(eye0, center0, up0, fov0); scene.updateCamera(W, H); scene.updateCamera(W, H)
-            prio_tuning = {"chosen": list(cands[best]), "ms_per_frame": {n: round(v, 4) for n, v in zip(names, ms_c)}, "seconds": round(time.time() - t_tune, 3),
-                           "how": "bench.py on the workload's own camera path (40 frames per setting, wall clock)"}
-        elif args.stream_priorities == "tune" and not args.profile_run:
-            t_tune = time.time()
-            prio_tuning = r.tune_stream_priorities(st, 24)
-            prio_tuning["seconds"] = round(time.time() - t_tune, 3)
-            prio_tuning["how"] = "rt_tune_stream_priorities (24 frames per setting at the current camera, steady-state period from events)"
-        elif "," in args.stream_priorities:
-            lv = [int(x) for x in args.stream_priorities.split(",")]
-            r.set_stream_priorities(lv[0], lv[1])
-            prio_tuning = {"chosen": lv, "ms_per_frame": None}
+    prio_explicit = None
+    if args.stream_priorities == "default":
+        args.stream_priorities = "1,0"
+    if world == 1 and not di_only and "," in args.stream_priorities:
+        # (unset, the context decides at its first frame — rt_render_frame: filter stream high next to the indirect stream when the filter chain is >= 20 % of the traced
+        #  stages' time; profiles/r05_prio_by_config_ab.txt.  The choice is reported in the line: `stream_priorities`.)
+        prio_explicit = [int(x) for x in args.stream_priorities.split(",")]
+        r.set_stream_priorities(prio_explicit[0], prio_explicit[1])
 
     def step(f):
         st.time = 1000 + f
@@ -464,8 +425,11 @@ def main():
                               "median over the frames of a separate pass; frame_latency_ms = first launch to last launch of one frame while frames are in flight")
         if sustained:
             out["sustained"] = sustained
-        if prio_tuning:
-            out["stream_priorities"] = prio_tuning
+        if world == 1 and not di_only:
+            sp = r.stream_priorities()
+            sp["how"] = "given on the command line" if prio_explicit else ("RESTIR_PRIO" if os.environ.get("RESTIR_PRIO") else
+                                                                         "rt_render_frame's rule on the first frame's stage times (filter stream high when filter_share >= 0.2)")
+            out["stream_priorities"] = sp
         if frame is not None:   # what rank 0 received for the last timed frame, by purpose (restir_amd/tiled.py accounting), and the exact fallbacks of the run
             out["halo_bytes_rank0"] = dict(frame.halo_bytes)
             out["history_fallbacks"] = int(frame.history_fallbacks)

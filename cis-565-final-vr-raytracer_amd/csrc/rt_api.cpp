@@ -35,8 +35,11 @@ struct rt_ctx {
   // context that destroyed and re-created its streams while trying settings ended with its filter stream on the main stream's queue (the 5th normal-priority stream of
   // the process lands on the 1st one's queue): 3.38 -> 3.71 ms per frame, found by two back-to-back bench lines in round 5.
   hipStream_t indStreams[3] = {nullptr, nullptr, nullptr}, sideStreams[3] = {nullptr, nullptr, nullptr};   // index = level + 1
+  std::vector<hipStream_t> padStreams;   // idle streams of the creation-order probe (RESTIR_STREAM_PAD)
   int prio[3] = {0, 1, 0};   // priority level of the main / indirect / filter stream (-1 low, 0 normal, +1 high): prioSpec() at rt_create, rt_set_stream_priorities, rt_tune_stream_priorities
-  bool prioFromEnv = false;  // RESTIR_PRIO was set: the tuner leaves the streams alone (A/B scripts stay in control)
+  bool prioFromEnv = false;  // RESTIR_PRIO was set (A/B scripts stay in control)
+  bool prioDecided = false;  // the levels are final (environment, rt_set_stream_priorities, or the rule applied to the first frame's stage times)
+  float filterShare = -1.f;  // filters / (direct + indirect) of the first frame, stages run alone (the rule's input); -1: not measured
   void* dSky = nullptr;      // SkyPre (csrc/sky.h), valid while sunAndSky.in_use == 1
   void* dPick = nullptr;     // rt_pick_result written by k_pick
   rt_sun_and_sky sunAndSky{};
@@ -330,7 +333,7 @@ int rt_create(rt_ctx** out, int device)
   g_liveCtx.fetch_add(1);   // counted from here on: every exit below goes through rt_destroy, which un-counts it
   c->device = device;
   {
-    prioSpec(c->prio); c->prioFromEnv = getenv("RESTIR_PRIO") != nullptr;
+    prioSpec(c->prio); c->prioFromEnv = getenv("RESTIR_PRIO") != nullptr; c->prioDecided = c->prioFromEnv;
     bool ok = createStreamLevel(&c->ownStream, 0, c->prio[0]) == hipSuccess;
     if(!ok) { g_createErr = "rt_create: hipStreamCreate failed"; rt_destroy(c); return RT_ERR_HIP; }
     c->stream = c->ownStream;
@@ -360,6 +363,7 @@ int rt_destroy(rt_ctx* c)
   if(c->spareG) (void)hipFree(c->spareG);
   if(c->spareMotion) (void)hipFree(c->spareMotion);
   for(void* p : c->indA) if(p && p != c->bufs[RT_BUF_DENOISE_IND_A]) (void)hipFree(p);
+  for(hipStream_t q : c->padStreams) if(q) (void)hipStreamDestroy(q);
   for(hipStream_t& q : c->indStreams) { if(q) (void)hipStreamDestroy(q); q = nullptr; }
   for(hipStream_t& q : c->sideStreams) { if(q) (void)hipStreamDestroy(q); q = nullptr; }
   c->indStream = c->sideStream = nullptr;
@@ -718,8 +722,13 @@ static hipError_t ensureOverlapStreams(rt_ctx* c)
   hipError_t e = hipSuccess;
   hipStream_t& side = c->sideStreams[c->prio[2] + 1];
   hipStream_t& ind = c->indStreams[c->prio[1] + 1];
-  if(!side) e = createStreamLevel(&side, 2, c->prio[2]);
-  if(e == hipSuccess && !ind) e = createStreamLevel(&ind, 1, c->prio[1]);
+  // probe (round 5, scripts/r05_stream_pad_probe.sh): RESTIR_STREAM_PAD="a,b[,level]" creates a / b idle streams before the filter / the indirect stream — how a stream's
+  // position in the process's creation order maps to the hardware queue it shares
+  static int padA = -1, padB = 0, padL = 0;
+  if(padA < 0) { padA = 0; if(const char* pe = getenv("RESTIR_STREAM_PAD")) (void)sscanf(pe, "%d,%d,%d", &padA, &padB, &padL); }
+  auto pad = [&](int n) { for(int i = 0; i < n; i++) { hipStream_t d = nullptr; (void)createStreamLevel(&d, 2, padL); c->padStreams.push_back(d); } };
+  if(!side) { pad(padA); e = createStreamLevel(&side, 2, c->prio[2]); }
+  if(e == hipSuccess && !ind) { pad(padB); e = createStreamLevel(&ind, 1, c->prio[1]); }
   c->sideStream = side; c->indStream = ind;
   return e;
 }
@@ -799,9 +808,18 @@ int rt_render_frame(rt_ctx* c, const rt_state* st, int frames)
     for(int i = 0; i < rt_ctx::MAX_EV; i++) RT_HIP(c, hipEventCreate(&E.ev[i]));
     c->evSets.push_back(E);
   }
+  // The FIRST frame of a frames-in-flight context runs every stage alone on the main stream, is timed, and decides the priorities of the two other streams BEFORE they
+  // are created (below): filter stream high as well when the filter chain is a sizeable part of the frame's work.  Measured (profiles/r05_prio_by_config_ab.txt, every
+  // setting in a fresh process): filters / (direct + indirect) = 0.16 (real exterior scene: indirect-high alone is best), 0.22 (lite: both high -1.8 %), 0.48 (config 5:
+  // -6.4 %), 0.50 (config 3: -8.2 %).  The decision has to come first: a stream's place in the process's creation order changes what the schedule gets out of it (a
+  // setting introduced after another one's streams exist ran 15-45 % slower than in a fresh process), so settings cannot be compared in place.
+  const bool decide = c->overlap >= 2 && !c->prioDecided && c->spareG && c->spareMotion;
+  if(decide) { RT_HIP(c, syncAll(c)); harvestTimings(c); }
+  const double tracedBefore = c->accStage[RT_STAGE_DIRECT] + c->accStage[RT_STAGE_INDIRECT];
+  const double filterBefore = c->accStage[RT_STAGE_DENOISE_DIRECT] + c->accStage[RT_STAGE_DENOISE_INDIRECT] + c->accStage[RT_STAGE_COMPOSE];
   rt_ctx::EvSet& E = c->evSets[c->evUsed];
-  if(c->overlap >= 1) RT_HIP(c, ensureOverlapStreams(c));
-  const bool pipelined = c->overlap >= 2 && c->sideStream && c->indStream && c->spareG && c->spareMotion;
+  if(c->overlap >= 1 && !decide) RT_HIP(c, ensureOverlapStreams(c));
+  const bool pipelined = !decide && c->overlap >= 2 && c->sideStream && c->indStream && c->spareG && c->spareMotion;
   if(pipelined) {
     // Rotate the G-buffer (3 physical buffers) and the motion buffer (2): direct(f+1) must not overwrite what indirect(f)
     // still reads (its own G-buffer + motion, and G(f-1) for temporal reprojection).  The boundary ids keep their meaning:
@@ -872,7 +890,7 @@ int rt_render_frame(rt_ctx* c, const rt_state* st, int frames)
   // Renderer::run, renderer.cpp:163-205.  The direct A-Trous chain only depends on the direct stage and the indirect stage
   // + its A-Trous chain only on the G-buffer, so the two chains run on two streams and join before compose: the direct
   // filter (ALU bound, full occupancy) fills the CUs that the indirect stage's long tail of multi-bounce tiles leaves idle.
-  const bool fork = c->overlap && st->denoise > 0 && c->sideStream;
+  const bool fork = !decide && c->overlap && st->denoise > 0 && c->sideStream;
   if((rc = run(c->stream, RT_STAGE_DIRECT, 0))) return rc;
   if(fork) {
     RT_HIP(c, hipEventRecord(c->evFork, c->stream));
@@ -890,6 +908,16 @@ int rt_render_frame(rt_ctx* c, const rt_state* st, int frames)
   if((rc = run(c->stream, RT_STAGE_COMPOSE, 0))) return rc;
   E.count = k; E.last = lastMain;
   c->evUsed++;
+  if(decide) {
+    RT_HIP(c, syncAll(c));
+    harvestTimings(c);
+    const double traced = (c->accStage[RT_STAGE_DIRECT] + c->accStage[RT_STAGE_INDIRECT]) - tracedBefore;
+    const double filt = (c->accStage[RT_STAGE_DENOISE_DIRECT] + c->accStage[RT_STAGE_DENOISE_INDIRECT] + c->accStage[RT_STAGE_COMPOSE]) - filterBefore;
+    c->filterShare = traced > 0.0 ? float(filt / traced) : -1.f;
+    c->prio[1] = 1; c->prio[2] = (c->filterShare >= 0.2f) ? 1 : 0;
+    c->prioDecided = true;
+    c->indStream = c->sideStream = nullptr;   // (created with these levels by the next frame: filter stream first, then the indirect stream)
+  }
   return RT_OK;
 }
 
@@ -1091,58 +1119,31 @@ int rt_set_overlap(rt_ctx* c, int mode)
 }
 
 /* Priorities of the indirect and the filter stream of the frames-in-flight schedule (levels -1 low, 0 normal, +1 high; the main stream keeps the level it was
- * created with).  Which setting is fastest depends on the workload — where the filter chain is the critical path (cheap traced stages: configs 3 and 5) the
- * filter stream wants to be high, where traversal dominates (the real-footprint exterior scene) it wants to be LOW, profiles/r05_prio_by_config_ab.txt — so the
- * library offers the knob and a tuner instead of one compiled-in answer.  Results are identical under every setting. */
+ * created with).  Which setting is fastest depends on the workload (profiles/r05_prio_by_config_ab.txt); unset, the context decides at its first frame
+ * (rt_render_frame: the rule and its data).  Best called BEFORE the first frame: a stream created after others exist may share a hardware queue with them.
+ * Results are identical under every setting. */
 int rt_set_stream_priorities(rt_ctx* c, int indirectLevel, int filterLevel)
 {
   if(!c || indirectLevel < -1 || indirectLevel > 1 || filterLevel < -1 || filterLevel > 1) return RT_ERR_INVALID_ARG;
   RT_HIP(c, hipSetDevice(c->device));
   RT_HIP(c, syncAll(c));
+  c->prioDecided = true;   // an explicit choice: the first-frame rule stays out of it
   if(c->prio[1] == indirectLevel && c->prio[2] == filterLevel) return RT_OK;
   c->prio[1] = indirectLevel; c->prio[2] = filterLevel;
   c->indStream = c->sideStream = nullptr;   // (selected — and created, once per level — on first use: ensureOverlapStreams; streams of other levels stay alive, idle)
   return RT_OK;
 }
 
-/* One-time tuning at load time (like the BVH build: before the first frame, outside any timed region): renders `framesPerCandidate` frames in flight under each
- * candidate setting with the CURRENT camera and `state`, keeps the fastest, and leaves every screen-space buffer as rt_resize left it (cold history), so the frames
- * that follow are the frames of a context that was never tuned.  chosen[0..1] = the levels kept, msPerFrame[0..4] = the measured period of each candidate
- * (order: {+1,0}, {+1,+1}, {0,+1}, {0,-1}, {+1,-1}; 0 = not measured).  With RESTIR_PRIO set in the environment the call measures nothing and reports that setting. */
-int rt_tune_stream_priorities(rt_ctx* c, const rt_state* st, int framesPerCandidate, int* chosen, float* msPerFrame)
+/* The levels in use and the measurement behind them: filterShare = filters / (direct + indirect) of the first frame with every stage alone (-1: no frame yet, or the
+ * levels were set explicitly / by RESTIR_PRIO); decided = 0 while the first frame has not been rendered. */
+int rt_get_stream_priorities(rt_ctx* c, int* indirectLevel, int* filterLevel, float* filterShare, int* decided)
 {
-  int rc = checkReady(c, st);
-  if(rc) return rc;
-  static const int cand[5][2] = {{1, 0}, {1, 1}, {0, 1}, {0, -1}, {1, -1}};
-  if(msPerFrame) for(int i = 0; i < 5; i++) msPerFrame[i] = 0.f;
-  if(c->prioFromEnv || c->overlap != 2 || framesPerCandidate < 2) { if(chosen) { chosen[0] = c->prio[1]; chosen[1] = c->prio[2]; } return RT_OK; }
-  RT_HIP(c, hipSetDevice(c->device));
-  const int W = c->W, H = c->H;
-  rt_state s = *st;
-  int best = 0; double bestMs = 1e30;
-  int f = 0;
-  hipEvent_t evA = nullptr, evB = nullptr;
-  RT_HIP(c, hipEventCreate(&evA)); RT_HIP(c, hipEventCreate(&evB));
-  auto done = [&](int r) { (void)hipEventDestroy(evA); (void)hipEventDestroy(evB); return r; };
-  for(int i = 0; i < 5; i++) {
-    if((rc = rt_set_stream_priorities(c, cand[i][0], cand[i][1]))) return done(rc);
-    // the PERIOD of the schedule in steady state: from the completion of a frame's last kernel (compose, filter stream) to the completion of the frame
-    // framesPerCandidate frames later — a wall clock around "issue n frames, drain" would add the latency of the last frame and favour low-latency settings
-    for(int k = 0; k < 3; k++) { s.time = 7000 + f; if((rc = rt_render_frame(c, &s, f))) return done(rc); f++; }   // fill the pipeline (and, first candidate, warm the caches)
-    if(hipEventRecord(evA, c->sideStream) != hipSuccess) return done(fail(c, RT_ERR_HIP, "rt_tune_stream_priorities: hipEventRecord failed"));
-    for(int k = 0; k < framesPerCandidate; k++) { s.time = 7000 + f; if((rc = rt_render_frame(c, &s, f))) return done(rc); f++; }
-    if(hipEventRecord(evB, c->sideStream) != hipSuccess) return done(fail(c, RT_ERR_HIP, "rt_tune_stream_priorities: hipEventRecord failed"));
-    if(syncAll(c) != hipSuccess) return done(fail(c, RT_ERR_HIP, "rt_tune_stream_priorities: synchronisation failed"));
-    float el = 0.f;
-    if(hipEventElapsedTime(&el, evA, evB) != hipSuccess) return done(fail(c, RT_ERR_HIP, "rt_tune_stream_priorities: hipEventElapsedTime failed"));
-    const double ms = double(el) / framesPerCandidate;
-    if(msPerFrame) msPerFrame[i] = float(ms);
-    if(ms < bestMs * 0.99) { bestMs = ms; best = i; }      // (a later candidate must win by 1 %: the default stays on a tie)
-  }
-  (void)hipEventDestroy(evA); (void)hipEventDestroy(evB);
-  if((rc = rt_set_stream_priorities(c, cand[best][0], cand[best][1]))) return rc;
-  if(chosen) { chosen[0] = cand[best][0]; chosen[1] = cand[best][1]; }
-  return rt_resize(c, W, H);   // cold history again: the tuning frames leave no trace
+  if(!c) return RT_ERR_INVALID_ARG;
+  if(indirectLevel) *indirectLevel = c->prio[1];
+  if(filterLevel) *filterLevel = c->prio[2];
+  if(filterShare) *filterShare = c->filterShare;
+  if(decided) *decided = c->prioDecided ? 1 : 0;
+  return RT_OK;
 }
 
 /* extra introspection used by bench.py / DESIGN.md numbers (not part of the reference-facing surface) */

@@ -43,11 +43,10 @@ class Renderer {
     if(rt_render_frame(m_ctx, &state, frames) != RT_OK) { fprintf(stderr, "Renderer::run: %s\n", rt_last_error(m_ctx)); return false; }
     return true;
   }
-  // (no counterpart in the reference, which records into one queue) load-time choice of the priorities of the schedule's streams for this scene / size / state:
-  // call once after update() and the first updateCamera, before the first run(); leaves the history cold (rt_tune_stream_priorities)
-  bool tuneStreams(const rt_state& state, int framesPerCandidate = 8)
+  // (no counterpart in the reference, which records into one queue) priorities of the schedule's indirect / filter streams; unset, the context decides at its first frame
+  bool setStreamPriorities(int indirectLevel, int filterLevel)
   {
-    if(rt_tune_stream_priorities(m_ctx, &state, framesPerCandidate, nullptr, nullptr) != RT_OK) { fprintf(stderr, "Renderer::tuneStreams: %s\n", rt_last_error(m_ctx)); return false; }
+    if(rt_set_stream_priorities(m_ctx, indirectLevel, filterLevel) != RT_OK) { fprintf(stderr, "Renderer::setStreamPriorities: %s\n", rt_last_error(m_ctx)); return false; }
     return true;
   }
   const std::string name() { return std::string("HIP-gfx950"); }  // renderer.hpp:55 returns "RQ"

@@ -15,7 +15,7 @@ _lib = None
 # every symbol include/rt_abi.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_build_accel", "rt_resize", "rt_set_camera",
                "rt_render_frame", "rt_run_stage", "rt_readback", "rt_upload_history", "rt_buffer_bytes", "rt_device_ptr",
-               "rt_set_counting", "rt_get_counters", "rt_sync", "rt_last_error", "rt_abi_version", "rt_set_traversal", "rt_set_history_rows", "rt_history_miss", "rt_set_overlap", "rt_tonemap", "rt_set_sun_and_sky", "rt_pick", "rt_trace_rays", "rt_history_miss_stage", "rt_rotate_buffers", "rt_select_frame", "rt_measure_valu_peak", "rt_set_stream_priorities", "rt_tune_stream_priorities",
+               "rt_set_counting", "rt_get_counters", "rt_sync", "rt_last_error", "rt_abi_version", "rt_set_traversal", "rt_set_history_rows", "rt_history_miss", "rt_set_overlap", "rt_tonemap", "rt_set_sun_and_sky", "rt_pick", "rt_trace_rays", "rt_history_miss_stage", "rt_rotate_buffers", "rt_select_frame", "rt_measure_valu_peak", "rt_set_stream_priorities", "rt_get_stream_priorities",
                "rt_mgpu_create", "rt_mgpu_destroy", "rt_mgpu_upload_scene", "rt_mgpu_resize", "rt_mgpu_set_camera", "rt_mgpu_render_frame", "rt_mgpu_readback",
                "rt_mgpu_sync", "rt_mgpu_set_balance", "rt_mgpu_set_serialize", "rt_mgpu_set_pipeline", "rt_mgpu_set_gather", "rt_mgpu_set_solo", "rt_mgpu_set_bands", "rt_mgpu_get_stats", "rt_mgpu_get_link_stats", "rt_mgpu_last_error", "rt_mgpu_plan_bands"]
 
@@ -83,7 +83,7 @@ def hip_lib():
         L.rt_mgpu_last_error.argtypes = [C.c_void_p]; L.rt_mgpu_last_error.restype = C.c_char_p
         L.rt_mgpu_plan_bands.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.rt_set_stream_priorities.argtypes = [C.c_void_p, C.c_int, C.c_int]
-        L.rt_tune_stream_priorities.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.rt_get_stream_priorities.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rt_accel_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
         L.rt_accel_quality.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _lib = L
@@ -255,12 +255,11 @@ class Renderer:
         """levels -1 / 0 / +1 of the indirect-stage stream and the filter stream of the frames-in-flight schedule (same bits under every setting)"""
         self._chk(hip_lib().rt_set_stream_priorities(self._h, int(indirect_level), int(filter_level)), "rt_set_stream_priorities")
 
-    def tune_stream_priorities(self, state, frames_per_candidate=8):
-        """load-time tuning (rt_tune_stream_priorities): {"chosen": [indirect, filter], "ms_per_frame": {setting: ms}}; leaves the screen buffers cold"""
-        ch, ms = (C.c_int * 2)(), (C.c_float * 5)()
-        self._chk(hip_lib().rt_tune_stream_priorities(self._h, C.byref(state), int(frames_per_candidate), ch, ms), "rt_tune_stream_priorities")
-        names = ["ind+ filter0", "ind+ filter+", "ind0 filter+", "ind0 filter-", "ind+ filter-"]
-        return {"chosen": [int(ch[0]), int(ch[1])], "ms_per_frame": {n: round(float(v), 4) for n, v in zip(names, ms) if v > 0}}
+    def stream_priorities(self):
+        """{"chosen": [indirect, filter], "filter_share": filters / (direct + indirect) of the first frame or None, "decided": bool} (rt_get_stream_priorities)"""
+        a, b, sh, d = C.c_int(), C.c_int(), C.c_float(), C.c_int()
+        self._chk(hip_lib().rt_get_stream_priorities(self._h, C.byref(a), C.byref(b), C.byref(sh), C.byref(d)), "rt_get_stream_priorities")
+        return {"chosen": [a.value, b.value], "filter_share": (round(sh.value, 4) if sh.value >= 0 else None), "decided": bool(d.value)}
 
     def accel_stats(self):
         n, t, d = C.c_uint64(), C.c_uint64(), C.c_int()

@@ -417,17 +417,16 @@ int rt_set_sun_and_sky(rt_ctx* ctx, const rt_sun_and_sky* ss);
  * G-buffers and the motion buffer are invalidated by rt_render_frame (rt_run_stage never rotates buffers).
  * Also settable with RESTIR_OVERLAP=0|1|2 before rt_create. */
 int rt_set_overlap(rt_ctx* ctx, int mode);
-/* Priorities of the indirect-stage stream and the filter stream of mode 2 (levels: -1 low, 0 normal, +1 high; default +1 / 0, or RESTIR_PRIO before rt_create).
- * The reference submits its dispatches to ONE queue (src/renderer.cpp:154-206) and has no such choice; here three streams share the chip and the fastest
- * setting depends on the workload (profiles/r05_prio_by_config_ab.txt: filter stream high where the filter chain is the critical path, low where traversal
- * dominates).  Results are identical under every setting.  Drains the context. */
+/* Priorities of the indirect-stage stream and the filter stream of mode 2 (levels: -1 low, 0 normal, +1 high).  The reference submits its dispatches to ONE queue
+ * (src/renderer.cpp:154-206) and has no such choice; here three streams share the chip and the fastest setting depends on the workload
+ * (profiles/r05_prio_by_config_ab.txt).  Unset (no call, no RESTIR_PRIO), the context decides at its FIRST mode-2 frame: that frame runs every stage alone on the main
+ * stream, is timed, and the filter stream becomes high next to the indirect stream when filters / (direct + indirect) >= 0.2; the two streams are created afterwards.
+ * An explicit call is best made before the first frame: a stream created after others exist may share a hardware queue with them.  Results are identical under every
+ * setting.  Drains the context. */
 int rt_set_stream_priorities(rt_ctx* ctx, int indirectLevel, int filterLevel);
-/* One-time tuning at load time (after rt_resize and rt_set_camera, before the first frame; like rt_build_accel not part of any frame): renders
- * framesPerCandidate (>= 2) frames in flight under each of five settings — {+1,0} {+1,+1} {0,+1} {0,-1} {+1,-1} — with `state` and the current camera, keeps
- * the fastest (the default unless another wins by > 1 %) and re-initialises every screen-space buffer as rt_resize does, so the frames that follow are those of
- * a context that was never tuned.  chosen[2] (may be NULL) receives the levels kept, msPerFrame[5] (may be NULL) the measured periods.  Does nothing (and
- * reports the current levels) when RESTIR_PRIO is set or the overlap mode is not 2. */
-int rt_tune_stream_priorities(rt_ctx* ctx, const rt_state* state, int framesPerCandidate, int* chosen, float* msPerFrame);
+/* The levels in use; filterShare = the first frame's filters / (direct + indirect) (-1: not measured: no frame yet, or the levels were given); decided = 0 before the
+ * first frame of a context that decides for itself.  Any pointer may be NULL. */
+int rt_get_stream_priorities(rt_ctx* ctx, int* indirectLevel, int* filterLevel, float* filterShare, int* decided);
 /* ------------------------------------------------------------------------------------------------------------------
  * Multi-GPU context (csrc/mgpu.cpp): the row-tiled frame of BASELINE.json / SURVEY.md §8(e) for a host that owns all the
  * GPUs of the node from ONE process — "multi-GPU ctx internally drives 8 streams" (§8b threading row).  One worker thread,
@@ -502,7 +501,7 @@ int rt_measure_valu_peak(rt_ctx* ctx, int variant, int wavesPerSimd, double* wav
 int rt_sync(rt_ctx* ctx);
 /* Last error message of this ctx (or of rt_create when ctx == NULL). Never NULL. */
 const char* rt_last_error(rt_ctx* ctx);
-/* ABI version: (major<<16)|minor.  2.2 (round 5): + rt_set_stream_priorities, rt_tune_stream_priorities.  2.1 (round 4): + rt_mgpu_get_link_stats.  2.0 (round 3): rt_set_pipeline -> rt_set_traversal; RT_STAGE_DIRECT levels 1 / 2 are rejected outside the
+/* ABI version: (major<<16)|minor.  2.2 (round 5): + rt_set_stream_priorities, rt_get_stream_priorities.  2.1 (round 4): + rt_mgpu_get_link_stats.  2.0 (round 3): rt_set_pipeline -> rt_set_traversal; RT_STAGE_DIRECT levels 1 / 2 are rejected outside the
  * spatial modes; 1.1 would have been round 2's additions (rt_mgpu_*, rt_measure_valu_peak, the `level` halves of RT_STAGE_DIRECT). */
 #define RT_ABI_VERSION_MAJOR 2u
 #define RT_ABI_VERSION_MINOR 2u

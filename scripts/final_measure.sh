@@ -29,7 +29,6 @@ print(sys.argv[1].split("/")[-1], d["ms_per_step"], d["value"], "bound", r.get("
 PY
 done
 cd /tmp && export TMPDIR=/tmp
-# (the profiled command runs with the stream priorities the bench line's tuner chose: --profile-run itself does not tune)
-PRIO=$(python -c "import json; d = json.loads(open('$O/bench.json').read().strip().splitlines()[-1]); print(','.join(str(v) for v in d['stream_priorities']['chosen']))")
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o stats -- python $R/bench.py --steps 100 --warmup 20 --no-cpu-baseline --profile-run --stream-priorities $PRIO > $O/prof_bench.json 2> $O/prof.err
+# (the profiled command decides its stream priorities like the bench line does: at its first frame)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o stats -- python $R/bench.py --steps 100 --warmup 20 --no-cpu-baseline --profile-run > $O/prof_bench.json 2> $O/prof.err
 ls $O/prof | head
