@@ -252,16 +252,12 @@ static bool cuSplitRange(int which, int& lo, int& hi)
 // Stream priorities of the frames-in-flight schedule.  RESTIR_PRIO = 0..3 (rounds 2-4: 0 none, 1 indirect + filter streams high, 2 indirect stream high — the
 // default —, 3 filter stream high) or three characters over {-, 0, +} for the main (direct stage) / indirect / filter stream: "+00" = main stream high, "0+-" =
 // indirect high and filters low.  level: -1 low, 0 normal, +1 high.
-static void prioSpec(int level[3])
+static void prioSpec(int level[3])   // (read at every rt_create: a host may change RESTIR_PRIO between contexts)
 {
-  static int cached[3] = {0, 1, 0}; static bool have = false;
-  if(!have) {
-    have = true;
-    const char* e = getenv("RESTIR_PRIO");
-    if(e && strlen(e) == 3 && strspn(e, "-0+") == 3) { for(int i = 0; i < 3; i++) cached[i] = e[i] == '+' ? 1 : (e[i] == '-' ? -1 : 0); }
-    else if(e) { const int m = atoi(e); cached[0] = 0; cached[1] = (m == 1 || m == 2) ? 1 : 0; cached[2] = (m == 1 || m == 3) ? 1 : 0; }
-  }
-  for(int i = 0; i < 3; i++) level[i] = cached[i];
+  level[0] = 0; level[1] = 1; level[2] = 0;
+  const char* e = getenv("RESTIR_PRIO");
+  if(e && strlen(e) == 3 && strspn(e, "-0+") == 3) { for(int i = 0; i < 3; i++) level[i] = e[i] == '+' ? 1 : (e[i] == '-' ? -1 : 0); }
+  else if(e) { const int m = atoi(e); level[0] = 0; level[1] = (m == 1 || m == 2) ? 1 : 0; level[2] = (m == 1 || m == 3) ? 1 : 0; }
 }
 static hipError_t createStreamLevel(hipStream_t* s, int which, int level);
 static hipError_t createStream(hipStream_t* s, int which, bool high) { return createStreamLevel(s, which, high ? 1 : 0); }
@@ -914,7 +910,7 @@ int rt_render_frame(rt_ctx* c, const rt_state* st, int frames)
     const double traced = (c->accStage[RT_STAGE_DIRECT] + c->accStage[RT_STAGE_INDIRECT]) - tracedBefore;
     const double filt = (c->accStage[RT_STAGE_DENOISE_DIRECT] + c->accStage[RT_STAGE_DENOISE_INDIRECT] + c->accStage[RT_STAGE_COMPOSE]) - filterBefore;
     c->filterShare = traced > 0.0 ? float(filt / traced) : -1.f;
-    c->prio[1] = 1; c->prio[2] = (c->filterShare >= 0.2f) ? 1 : 0;
+    c->prio[1] = 1; c->prio[2] = (c->filterShare >= 0.14f) ? 1 : 0;
     c->prioDecided = true;
     c->indStream = c->sideStream = nullptr;   // (created with these levels by the next frame: filter stream first, then the indirect stream)
   }

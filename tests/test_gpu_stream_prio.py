@@ -32,7 +32,7 @@ def test_first_frame_rule_decides_and_reports(monkeypatch):
     _, (before, after) = _render(lambda r, st: None)
     assert before["decided"] is False and before["filter_share"] is None
     assert after["decided"] is True and after["filter_share"] is not None and after["filter_share"] > 0
-    assert after["chosen"] == [1, 1 if after["filter_share"] >= 0.2 else 0]
+    assert after["chosen"] == [1, 1 if after["filter_share"] >= 0.14 else 0]
 
 
 def test_explicit_levels_and_the_environment_override_the_rule(monkeypatch):
