@@ -290,8 +290,11 @@ struct BuilderS {
         }
         if(left.empty() || right.empty() || left.size() >= cnt || right.size() >= cnt) { left.clear(); right.clear(); }   // no progress: the object split below
         else {
-          budget.fetch_sub(int64_t(left.size() + right.size()) - int64_t(cnt));
-          spatialSplits++;
+          // the references this split adds are RESERVED: the subtrees are built by several threads and the check above read a budget another thread may have spent
+          // since (leafTris is sized for triangles + budget: an overdraft would write past it)
+          const int64_t added = int64_t(left.size() + right.size()) - int64_t(cnt);
+          if(added > 0 && budget.fetch_sub(added) < added) { budget.fetch_add(added); left.clear(); right.clear(); }
+          else spatialSplits++;
         }
       }
       if(left.empty()) {
