@@ -209,7 +209,13 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     # --gpus N means N devices, whoever launched this process.  A plain `python bench.py --gpus 8` (no WORLD_SIZE) used to render on ONE device and print
     # "n_gpus": 1 (round-3 verdict): it now refuses when fewer than N devices are visible and otherwise launches the N ranks itself.
-    if args.gpus > 1 and torch.cuda.device_count() < args.gpus and not (args.native and args.devices):
+    # TEST HOOK (tests/test_gpu_bench_cli.py): RESTIR_BENCH_SHARE_DEVICE=1 lets the ranks of a `--gpus N` run share the devices there are (rank r on device r % count) so
+    # that the N > 1 code path of THIS file — band planning, the gate, the rank report, both hosts — executes on a one-GPU box; with RESTIR_DIST_BACKEND=gloo as the
+    # transport (RCCL refuses two ranks on one device).  The line then says n_gpus = the DISTINCT devices and carries a note: a functional check, never a result.
+    share = os.environ.get("RESTIR_BENCH_SHARE_DEVICE") == "1"
+    if share and args.native and not args.devices:
+        args.devices = ",".join(str(q % torch.cuda.device_count()) for q in range(args.gpus))
+    if args.gpus > 1 and torch.cuda.device_count() < args.gpus and not (args.native and args.devices) and not share:
         raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} device(s) visible on this host — refusing to report a {args.gpus}-GPU number "
                          f"from fewer devices (use --emulate-world {args.gpus} for the one-device per-rank instrument)")
     if args.gpus > 1 and args.native:
@@ -218,6 +224,8 @@ def main():
         return native_world(args, abi, host, Renderer, torch)
     if args.gpus > 1 and world == 1:
         return self_launch(args)
+    if share:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -226,7 +234,11 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this host driver
         # a stuck exchange should end the run with an error instead of hanging it
         try:
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"), timeout=datetime.timedelta(seconds=300))
+            backend = os.environ.get("RESTIR_DIST_BACKEND", "nccl")
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"), timeout=datetime.timedelta(seconds=300))
+            else:
+                dist.init_process_group(backend, timeout=datetime.timedelta(seconds=300))
             probe = torch.ones(1, device="cuda")
             dist.all_reduce(probe)                       # the first collective builds the communicator: a broken fabric / IPC setup fails HERE, not in the timed region
             if int(probe.item()) != world:
@@ -585,7 +597,10 @@ def main():
             ver = verify_rccl(args, abi, tiled, torch, Renderer, comm, Frame, r, list(frame.part), scene, (eye0, center0, up0, fov0), st, desc, W, H, orbit, rank, local_rank)
         if rank == 0 and out is not None:
             out["rccl_ranks"] = world
-            out["rccl"] = "ok"
+            out["rccl"] = "ok" if comm.nccl else f"not used: RESTIR_DIST_BACKEND={os.environ.get('RESTIR_DIST_BACKEND')} (test hook)"
+            if share:
+                out["n_gpus"] = min(world, torch.cuda.device_count())
+                out["note"] = f"{world} ranks on {out['n_gpus']} device(s) (RESTIR_BENCH_SHARE_DEVICE): a functional check of the one-process-per-GPU host, NOT a benchmark result"
             out["peer_access"] = peer_matrix(torch, world)
             out["rank_report"] = [{"rank": q, "rows": [int(v[0]), int(v[1])], "traced_stages_alone_ms": (round(v[2], 4) if v[2] >= 0 else None),
                                    "ms_per_step_local": round(v[3], 4), "history_fallbacks": int(v[4])} for q, v in enumerate(per_rank)]
@@ -674,6 +689,7 @@ def both_hosts(args, rccl_line):
             "--scale", str(args.scale), "--verify-frames", str(args.verify_frames)]
     keep += (["--moving-camera"] if args.moving_camera else []) + (["--equal-bands"] if args.equal_bands else [])
     keep += (["--width", str(args.width)] if args.width else []) + (["--height", str(args.height)] if args.height else [])
+    keep += (["--devices", args.devices] if args.devices else [])
     env = {k: v for k, v in os.environ.items() if not (k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE",
                                                                "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS") or k.startswith(("TORCHELASTIC_", "NCCL_ASYNC", "TORCH_NCCL")))}
     nat, err = None, None

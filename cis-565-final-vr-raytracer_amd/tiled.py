@@ -103,6 +103,8 @@ class Pending:
                 self.comm.torch.cuda.current_stream().wait_event(self.event)
             return
         self.comm._wait_works(self.works)
+        if self.works and not self.comm.nccl and self.comm.torch.cuda.is_available() and self.comm.torch.cuda.is_initialized():
+            self.comm.torch.cuda.synchronize()
         for dst, src in self.unpack:
             if self.comm.nccl:
                 src.record_stream(self.comm.torch.cuda.current_stream())   # staged on the posting stream, read here on the consumer's: the allocator must not
@@ -221,6 +223,9 @@ class TorchComm:
     # send/recv; both sides enumerate the segments of a pair in the same order (the receiver's need list), which is what NCCL's
     # in-order matching of a group requires.  Bands may be narrower than a halo (a halo then spans several ranks).
     def _batch(self, ops, unpack, async_op):
+        host_sync = bool(ops) and not self.nccl and ops[0].tensor.is_cuda
+        if host_sync:
+            self.torch.cuda.synchronize()    # (gloo moving device tensors — bench.py's one-device test hook: the transport knows nothing of our streams)
         works = self.dist.batch_isend_irecv(ops) if ops else []
         p = Pending(self, [w for w in works if w is not None], unpack, keep=[op.tensor for op in ops], corrupt=self._rx_log)   # packed send buffers live until the exchange is waited for
         self._rx_log = []

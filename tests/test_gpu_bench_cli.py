@@ -81,3 +81,21 @@ def test_rccl_host_line_carries_the_gate():
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["tiled_equals_untiled"] is True and d["rccl_ranks"] == n and d["host"] in ("rccl", "native")
     assert d["hosts"]["rccl"]["tiled_equals_untiled"] is True and d["hosts"]["native"]["tiled_equals_untiled"] is True and d["hosts_all_verified"] is True
+
+
+def test_one_process_per_gpu_code_path_on_shared_device():
+    """Everything `bench.py --gpus 2` executes as the driver launches it (torch.distributed.run, one process per rank: band planning, timed region, rank report, the gate on
+    the RendererTensors backend, then the native host in a child process and both hosts in one line) on the devices there are: two ranks share device 0 through the
+    RESTIR_BENCH_SHARE_DEVICE hook, gloo carries the exchanges (RCCL refuses two ranks on one device).  The first real multi-device run must not be the first run of this code."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ); env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", RESTIR_BENCH_SHARE_DEVICE="1", RESTIR_DIST_BACKEND="gloo")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--band-rounds", "2", "--diffuse-rounds", "2"] + SMALL, capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-2500:])
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["tiled_equals_untiled"] is True and d["rccl_ranks"] == 2 and d["host"] in ("rccl", "native") and "note" in d
+    h = d["hosts"]
+    assert h["rccl"]["tiled_equals_untiled"] is True and h["rccl"]["tiled_equals_untiled_moving_camera"] is True and h["rccl"]["value"] > 0
+    assert h["native"] is not None and h["native"]["tiled_equals_untiled"] is True and d["hosts_all_verified"] is True
