@@ -719,6 +719,9 @@ def both_hosts(args, rccl_line):
     out["hosts"] = hosts
     out["rccl_ranks"] = rccl_line.get("rccl_ranks"); out["rccl"] = rccl_line.get("rccl", "ok")
     out.setdefault("peer_access", rccl_line.get("peer_access"))
+    if out.get("rank_report") is None:      # (the native line won: the one-process-per-GPU host's per-rank report and digests stay in the line)
+        out["rank_report"] = rccl_line.get("rank_report")
+        out["hosts"]["rccl"]["verify"] = rccl_line.get("verify")
     out["hosts_all_verified"] = all(h is not None and h.get("tiled_equals_untiled") is True for h in (hosts["rccl"], hosts["native"]))
     return out
 
