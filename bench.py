@@ -689,7 +689,7 @@ def both_hosts(args, rccl_line):
             "--scale", str(args.scale), "--verify-frames", str(args.verify_frames)]
     keep += (["--moving-camera"] if args.moving_camera else []) + (["--equal-bands"] if args.equal_bands else [])
     keep += (["--width", str(args.width)] if args.width else []) + (["--height", str(args.height)] if args.height else [])
-    keep += (["--devices", args.devices] if args.devices else [])
+    keep += (["--devices", args.devices] if getattr(args, "devices", "") else [])
     env = {k: v for k, v in os.environ.items() if not (k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE",
                                                                "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS") or k.startswith(("TORCHELASTIC_", "NCCL_ASYNC", "TORCH_NCCL")))}
     nat, err = None, None

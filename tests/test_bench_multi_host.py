@@ -15,7 +15,7 @@ import bench  # noqa: E402
 
 
 def _args():
-    return types.SimpleNamespace(gpus=8, steps=20, warmup=5, config=4, scene_footprint="real", scale=1.0, verify_frames=3, moving_camera=False, equal_bands=False, width=0, height=0)
+    return types.SimpleNamespace(gpus=8, steps=20, warmup=5, config=4, scene_footprint="real", scale=1.0, verify_frames=3, moving_camera=False, equal_bands=False, width=0, height=0, devices="")
 
 
 def _line(value, ok=True, **kw):
