@@ -1093,7 +1093,7 @@ def cpu_baseline(abi, host, scene, env, st, desc, W, H, frame0, di_only=False):
     allp = max(pts, key=lambda q: q["mrays_s"])
     load1 = os.getloadavg()
     y0, y1 = allp["rows"]
-    return {"value": allp["mrays_s"], "unit": "Mrays/s", "cores": ncpu, "threads_used": allp["threads"], "per_thread": allp["per_thread_mrays_s"], "kind": "port",
+    return {"value": allp["mrays_s"], "unit": "Mrays/s", "cores": allp["threads"], "host_cpus": ncpu, "threads_used": allp["threads"], "per_thread": allp["per_thread_mrays_s"], "kind": "port",
             "single_thread": pts[0]["mrays_s"], "pinned": True, "statistic": "best pass of each point; value = the best point", "scaling": pts,
             "parallel_efficiency_vs_1": round(allp["per_thread_mrays_s"] / max(1e-12, pts[0]["per_thread_mrays_s"]), 3),
             "host_loadavg_before_after": [round(load0[0], 2), round(load1[0], 2)],
