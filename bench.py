@@ -292,7 +292,7 @@ def main():
     if args.stream_priorities == "default":
         args.stream_priorities = "1,0"
     if world == 1 and not di_only and "," in args.stream_priorities:
-        # (unset, the context decides at its first frame — rt_render_frame: filter stream high next to the indirect stream when the filter chain is >= 20 % of the traced
+        # (unset, the context decides at its first frame — rt_render_frame: filter stream high next to the indirect stream when the filter chain is >= 14 % of the traced
         #  stages' time; profiles/r05_prio_by_config_ab.txt.  The choice is reported in the line: `stream_priorities`.)
         prio_explicit = [int(x) for x in args.stream_priorities.split(",")]
         r.set_stream_priorities(prio_explicit[0], prio_explicit[1])
@@ -440,7 +440,7 @@ def main():
         if world == 1 and not di_only:
             sp = r.stream_priorities()
             sp["how"] = "given on the command line" if prio_explicit else ("RESTIR_PRIO" if os.environ.get("RESTIR_PRIO") else
-                                                                         "rt_render_frame's rule on the first frame's stage times (filter stream high when filter_share >= 0.2)")
+                                                                         "rt_render_frame's rule on the first frame's stage times (filter stream high when filter_share >= 0.14)")
             out["stream_priorities"] = sp
         if frame is not None:   # what rank 0 received for the last timed frame, by purpose (restir_amd/tiled.py accounting), and the exact fallbacks of the run
             out["halo_bytes_rank0"] = dict(frame.halo_bytes)

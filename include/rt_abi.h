@@ -420,7 +420,7 @@ int rt_set_overlap(rt_ctx* ctx, int mode);
 /* Priorities of the indirect-stage stream and the filter stream of mode 2 (levels: -1 low, 0 normal, +1 high).  The reference submits its dispatches to ONE queue
  * (src/renderer.cpp:154-206) and has no such choice; here three streams share the chip and the fastest setting depends on the workload
  * (profiles/r05_prio_by_config_ab.txt).  Unset (no call, no RESTIR_PRIO), the context decides at its FIRST mode-2 frame: that frame runs every stage alone on the main
- * stream, is timed, and the filter stream becomes high next to the indirect stream when filters / (direct + indirect) >= 0.2; the two streams are created afterwards.
+ * stream, is timed, and the filter stream becomes high next to the indirect stream when filters / (direct + indirect) >= 0.14; the two streams are created afterwards.
  * An explicit call is best made before the first frame: a stream created after others exist may share a hardware queue with them.  Results are identical under every
  * setting.  Drains the context. */
 int rt_set_stream_priorities(rt_ctx* ctx, int indirectLevel, int filterLevel);
