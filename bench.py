@@ -1091,6 +1091,13 @@ def cpu_baseline(abi, host, scene, env, st, desc, W, H, frame0, di_only=False):
     counts = sorted({1, min(ncpu, 32), min(ncpu, 128), ncpu})
     pts = [point(t, 8 if t == 1 else rows_for(t), 3, 3.0 if t > 1 else 0.0) for t in counts]
     allp = max(pts, key=lambda q: q["mrays_s"])
+    # the best thread count once more at the end of the leg (the neighbours' load moves within seconds): the better of its two visits is the point
+    again = point(allp["threads"], allp["rows"][1] - allp["rows"][0], 4, 4.0)
+    if again["mrays_s"] > allp["mrays_s"]:
+        again["passes"] += allp["passes"]; again["spread"] = [min(again["spread"][0], allp["spread"][0]), again["spread"][1]]
+        pts[pts.index(allp)] = again; allp = again
+    else:
+        allp["passes"] += again["passes"]; allp["spread"] = [min(again["spread"][0], allp["spread"][0]), allp["spread"][1]]
     load1 = os.getloadavg()
     y0, y1 = allp["rows"]
     return {"value": allp["mrays_s"], "unit": "Mrays/s", "cores": allp["threads"], "host_cpus": ncpu, "threads_used": allp["threads"], "per_thread": allp["per_thread_mrays_s"], "kind": "port",
