@@ -16,6 +16,8 @@ The JSON line carries
                 / hit / RIS-candidate gathers x declared sizes) / its mean launch time from HIP events on the launch stream
   cpu_baseline  the CPU oracle (oracle/, "port") timed on a bounded band of the same frame on the host cores (N=1 only)
 """
+import time as _time_mod
+_T_START = _time_mod.time()   # wall clock of this process: `wall_s` of the N > 1 lines (the driver's limit for the command is 1 800 s)
 import argparse
 import json
 import os
@@ -177,6 +179,9 @@ def main():
     ap.add_argument("--diffuse-rounds", type=int, default=10, help="N > 1: after the cost-model rounds the band boundaries diffuse one 16-row stripe per round towards the slower "
                                                                   "neighbour (restir_amd/tiled.py diffuse_bands); the best partition seen is kept")
     ap.add_argument("--no-period", action="store_true", help="--emulate-world: skip the frames-in-flight period pass")
+    ap.add_argument("--solo-fresh", type=int, default=0, help="--emulate-world: re-measure the period of the K slowest ranks, each in a FRESH child process in which only that rank ever "
+                    "creates its two extra streams (round 6: a stream's worth depends on how many streams the process created before it; in-process, every rank measured earlier has left its streams behind)")
+    ap.add_argument("--emulate-child", type=str, default="", help="(internal, --solo-fresh) `rank:b0,b1,...,bN`: measure that rank's period on that partition and print one JSON line")
     ap.add_argument("--period-rounds", type=int, default=4, help="--emulate-world: re-planning rounds of the band heights on the measured per-rank periods")
     ap.add_argument("--native", action="store_true", help="N > 1: ONE process drives the N devices through the native context (rt_mgpu_*, csrc/mgpu.cpp: frames in flight per rank, "
                                                          "event-ordered peer pulls) instead of one process per GPU over RCCL; same JSON line plus the measured link time of every pull group")
@@ -228,6 +233,13 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
+    r = Renderer().setup(local_rank)
+    ctx_streams = None
+    if world > 1:
+        # Round 6: the rank renders on its CONTEXT's three streams (rt_get_streams: created here, filter stream first, then the indirect stream — the layout the schedule
+        # was tuned on) instead of on three streams of torch's pool, and they exist BEFORE the process group does: RCCL's communicator brings streams of its own, and a
+        # stream's worth depends on how many the process created before it (profiles/r05_prio_by_config_ab.txt section 2; profiles/r06_mgpu_streams_ab.txt).
+        ctx_streams = tiled.RendererTensors.create_streams(r)
     if world > 1:
         import torch.distributed as dist
         import datetime
@@ -270,13 +282,14 @@ def main():
         setattr(st, k, v)
     di_only = cfg.get("di_only", False)
     desc = scene.desc(env)
-    r = Renderer().setup(local_rank)
+    if world == 1 and args.emulate_world > 1 and args.emulate_child:
+        return emulate_child(args, abi, host, scene, env, st, desc, r, W, H, local_rank)
     t0 = time.time()
     r.load_scene(desc)
     build_s = time.time() - t0
     r.update(W, H)
     # kernels and RCCL ops share one HIP runtime (torch's) and one stream: ordered by torch's stream semantics, no host syncs
-    stream = torch.cuda.Stream() if world > 1 else None
+    stream = torch.cuda.ExternalStream(ctx_streams["main"]) if world > 1 else None
     if stream is not None:
         torch.cuda.set_stream(stream)
         r.set_stream(stream.cuda_stream)
@@ -327,7 +340,7 @@ def main():
         # Cost-weighted band heights (SURVEY 8(e) "expected scaling limit"), planned before the warm-up: a few rounds of {two real
         # frames, every rank times its band's two traced stages launched alone, the times are gathered, the boundaries move}.  The
         # partition is then fixed: nothing of this runs in the warm-up or in the timed region.
-        tstream = torch.cuda.Stream()
+        tstream = stream   # (the stages of a band launched alone: the rank's main stream, idle after the fence — no fourth stream, round 6)
 
         def band_ms():
             """two real frames on the current partition, then this rank's two traced stages launched alone on its band (ms per pair)"""
@@ -602,6 +615,10 @@ def main():
                 out["n_gpus"] = min(world, torch.cuda.device_count())
                 out["note"] = f"{world} ranks on {out['n_gpus']} device(s) (RESTIR_BENCH_SHARE_DEVICE): a functional check of the one-process-per-GPU host, NOT a benchmark result"
             out["peer_access"] = peer_matrix(torch, world)
+            # where this rank's streams sit in the process's creation order (round-5 finding: that order is worth 15-75 % of a frame): the three context streams were
+            # created before the process group (rt_get_streams), nothing in the timed path takes a stream from torch's pool
+            out["stream_layout"] = dict(r.stream_layout(), torch_pool_streams_in_timed_path=0, created_before_process_group=True, levels=r.stream_priorities()["chosen"],
+                                        note="library-created streams only; RCCL's internal streams are created at init_process_group, after the context's")
             out["rank_report"] = [{"rank": q, "rows": [int(v[0]), int(v[1])], "traced_stages_alone_ms": (round(v[2], 4) if v[2] >= 0 else None),
                                    "ms_per_step_local": round(v[3], 4), "history_fallbacks": int(v[4])} for q, v in enumerate(per_rank)]
             attach_verdict(out, ver)
@@ -610,7 +627,9 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         if world > 1 and not args.single_host and not args.profile_run and os.environ.get("RESTIR_BENCH_BOTH", "1") != "0":
-            out = both_hosts(args, out)     # the driver never passes --native: time that host too (child process) and report the faster verified one
+            out = both_hosts(args, out)     # the driver never passes --native: time that host too (child process, bounded by the time left) and report it beside this one
+        if world > 1:
+            out["wall_s"] = round(_time_mod.time() - _T_START, 1)   # this process, start to line (scene generation, BVH build, band planning, timed region, gate, second host)
         print(json.dumps(out), flush=True)
         if world > 1 and out.get("tiled_equals_untiled") is False:
             raise SystemExit(3)             # a number for a wrong image is not a result
@@ -682,11 +701,12 @@ def verify_native(args, abi, m, r, bands, scene, pose, st, W, H, orbit):
 
 def both_hosts(args, rccl_line):
     """rank 0, after the RCCL host's run and the end of its process group: the native host (one process, hipMemcpyPeerAsync pulls, no host sync per stage) on the
-    same devices in a CHILD process (this one has RCCL and N idle peers' contexts around), both results in one line — `value` is the faster host whose tiled ==
-    untiled gate passed."""
+    same devices in a CHILD process (this one has RCCL and N idle peers' contexts around), both results in one line — `value` stays the RCCL host's (the host the driver launched) as long as its tiled == untiled
+    gate passed; `faster_host` names the faster verified one."""
     import subprocess
     keep = ["--gpus", str(args.gpus), "--native", "--steps", str(args.steps), "--warmup", str(args.warmup), "--config", str(args.config), "--scene-footprint", args.scene_footprint,
-            "--scale", str(args.scale), "--verify-frames", str(args.verify_frames)]
+            "--scale", str(args.scale), "--verify-frames", str(args.verify_frames), "--band-rounds", str(args.band_rounds), "--diffuse-rounds", str(args.diffuse_rounds),
+            "--period-rounds", str(args.period_rounds)]
     keep += (["--moving-camera"] if args.moving_camera else []) + (["--equal-bands"] if args.equal_bands else [])
     keep += (["--width", str(args.width)] if args.width else []) + (["--height", str(args.height)] if args.height else [])
     keep += (["--devices", args.devices] if getattr(args, "devices", "") else [])
@@ -695,7 +715,11 @@ def both_hosts(args, rccl_line):
     nat, err = None, None
     try:
         time.sleep(2.0)     # the other ranks are leaving: let their contexts go before the native host times anything
-        p = subprocess.run([sys.executable, os.path.abspath(__file__)] + keep, env=env, capture_output=True, text=True, timeout=1500)
+        # bounded by what is left of the driver's limit for the whole command (1 800 s, measured from this process's start), with a margin for the line itself
+        budget = float(os.environ.get("RESTIR_BENCH_WALL_LIMIT", "1500")) - (_time_mod.time() - _T_START)
+        if budget < 90:
+            raise TimeoutError(f"second host skipped: {budget:.0f} s left of the command's wall budget")
+        p = subprocess.run([sys.executable, os.path.abspath(__file__)] + keep, env=env, capture_output=True, text=True, timeout=budget)
         lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
         if lines:
             nat = json.loads(lines[-1])
@@ -710,12 +734,13 @@ def both_hosts(args, rccl_line):
     hosts = {"rccl": summary(rccl_line), "native": summary(nat)}
     if err:
         hosts["native_error"] = err
+    # `value` is tied to ONE named host — the one-process-per-GPU RCCL host the driver launched — so that the headline does not switch implementation between runs
+    # (advisor finding of round 5); the native host's numbers stand beside it under `hosts`, and `faster_host` names the faster verified one.  Only when the RCCL line has
+    # no verified value does the native one take its place (the line says so: `host`).
     ok = {k: d for k, d in (("rccl", rccl_line), ("native", nat)) if d is not None and d.get("value") and d.get("tiled_equals_untiled") is not False}
-    if not ok:
-        out = dict(rccl_line); out["host"] = "rccl"
-    else:
-        name = max(ok, key=lambda k: ok[k]["value"])
-        out = dict(ok[name]); out["host"] = name
+    name = "rccl" if ("rccl" in ok or not ok) else "native"
+    out = dict(ok.get(name, rccl_line)); out["host"] = name
+    out["faster_host"] = max(ok, key=lambda k: ok[k]["value"]) if ok else None
     out["hosts"] = hosts
     out["rccl_ranks"] = rccl_line.get("rccl_ranks"); out["rccl"] = rccl_line.get("rccl", "ok")
     out.setdefault("peer_access", rccl_line.get("peer_access"))
@@ -827,6 +852,8 @@ def native_world(args, abi, host, Renderer, torch, extra=None):
     if distinct < n:
         out["note"] = f"{n} ranks on {distinct} device(s): a functional check of the native host, NOT a benchmark result"
     out["host"] = "native"
+    out["stream_layout"] = dict(m.stream_layout(), note="every rank renders on its context's streams: main created at rt_mgpu_create, filter then indirect stream on the rank's first "
+                                                        "frame in flight; rank 0 adds a copy stream for the gather (csrc/mgpu.cpp ensurePipeStreams)")
     out["peer_access_runtime"] = peer_matrix(torch, torch.cuda.device_count())
     if extra:
         out.update(extra)
@@ -862,6 +889,7 @@ def native_world(args, abi, host, Renderer, torch, extra=None):
         except Exception as e:   # noqa: BLE001
             ver = {"workload": {"equal": False, "error": repr(e)}}
     attach_verdict(out, ver)
+    out["wall_s"] = round(_time_mod.time() - _T_START, 1)
     print(json.dumps(out), flush=True)
     m.destroy(); r.destroy()
     if out.get("tiled_equals_untiled") is False:
@@ -1031,6 +1059,73 @@ def emulate_world(args, abi, host, scene, env, st, desc, single, W, H, device):
         mm = out["xgmi_model"]["modelled_ms"]
         out["xgmi_model"]["on_frame_path_ms"] = round(mm["history"] + mm["filter"] + mm["moved"], 4)
         out["slowest_rank_period_with_modelled_xgmi_ms"] = round(float(max(periods)) + out["xgmi_model"]["on_frame_path_ms"], 4)
+    out["stream_layout_in_process"] = m.stream_layout()
+    m.destroy()
+    if args.solo_fresh > 0 and not args.no_period and "rank_period_ms" in out and len(out["rank_period_ms"]) == n:
+        out["solo_fresh"] = solo_fresh(args, n, cur, out["rank_period_ms"])
+    print(json.dumps(out), flush=True)
+    return None
+
+
+def solo_fresh(args, n, part, periods):
+    """the K slowest ranks of the in-process period pass, each measured again in a fresh child process (emulate_child): same partition, same frames, but the process holds the
+    N contexts' main streams and ONLY that rank's filter / indirect stream (+ rank 0's copy stream) — the in-process figure was taken with every earlier rank's streams alive"""
+    import subprocess
+    order = sorted(range(n), key=lambda q: -periods[q])[:args.solo_fresh]
+    res = []
+    for q in order:
+        cmd = [sys.executable, os.path.abspath(__file__), "--emulate-world", str(n), "--config", str(args.config), "--scene-footprint", args.scene_footprint, "--scale", str(args.scale),
+               "--steps", str(args.steps), "--warmup", str(args.warmup), "--emulate-child", f"{q}:" + ",".join(str(int(b)) for b in part)]
+        cmd += (["--moving-camera"] if args.moving_camera else []) + (["--width", str(args.width)] if args.width else []) + (["--height", str(args.height)] if args.height else [])
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+            d = json.loads(lines[-1]) if lines else {"error": f"exit {p.returncode}: {(p.stderr or '').strip()[-300:]}"}
+        except Exception as e:   # noqa: BLE001
+            d = {"error": repr(e)}
+        d["rank"] = q; d["period_in_process_ms"] = periods[q]
+        res.append(d)
+    return res
+
+
+def emulate_child(args, abi, host, scene, env, st, desc, single, W, H, device):
+    """--emulate-child rank:bands — one rank's period in a process of its own (see solo_fresh)"""
+    from restir_amd.renderer import MultiGpuRenderer
+    single.destroy()                                    # (its one stream was created first and stays counted: `library_streams_created`)
+    n = args.emulate_world
+    q, bands = args.emulate_child.split(":")
+    q, part = int(q), [int(x) for x in bands.split(",")]
+    orbit = args.moving_camera or CONFIGS[args.config].get("orbit", False)
+    eye0, center0, up0, fov0 = scene.cameraPose()
+    m = MultiGpuRenderer().setup([device] * n)
+    m.load_scene(desc); m.update(W, H)
+    m.set_bands(part); m.set_serialize(False); m.set_pipeline(True)     # (an explicit partition implies "freeze")
+    if os.environ.get("RESTIR_EMULATE_GATHER") == "0":
+        m.set_gather(False)
+    scene.updateCamera(W, H)
+    f = 0
+
+    def frame():
+        nonlocal f
+        st.time = 1000 + f
+        if orbit:
+            a = np.deg2rad(0.5 * (f + 1))
+            rot = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], dtype=np.float32)
+            scene.setCamera(center0 + rot @ (eye0 - center0), center0, up0, fov0)
+        scene.updateCamera(W, H)
+        m.set_camera(scene.getCamera()); m.run(st, f)
+        f += 1
+    m.set_solo(q)
+    for _ in range(max(20, args.warmup)):
+        frame()
+    per = []
+    for _rep in range(2):
+        m.sync(); t0 = time.perf_counter()
+        k = max(60, args.steps)
+        for _ in range(k):
+            frame()
+        m.sync(); per.append((time.perf_counter() - t0) / k * 1e3)
+    out = {"period_fresh_process_ms": round(min(per), 4), "passes_ms": [round(x, 4) for x in per], "stream_layout": m.stream_layout(), "mgpu_prio": os.environ.get("RESTIR_MGPU_PRIO", "default")}
     print(json.dumps(out), flush=True)
     m.destroy()
     return None

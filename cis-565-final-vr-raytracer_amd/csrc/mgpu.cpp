@@ -48,7 +48,13 @@
 #include <vector>
 #include "../../include/rt_abi.h"
 
+// rt_create with explicit stream levels (csrc/rt_api.cpp; internal, not part of the C ABI)
+int rtCreateWithLevels(rt_ctx** out, int device, const int* levels);
+
 namespace {
+
+// default levels of a rank's main / indirect / filter stream (RESTIR_MGPU_PRIO overrides): rt_mgpu_create
+constexpr int MGPU_PRIO_DEFAULT[3] = {1, 0, 0};
 
 // full-res rows of last-frame history around the band: adaptive (rt_mgpu::histHalo) — HIST_HALO_MIN while no temporal lookup leaves band + halo, doubled
 // (up to HIST_HALO_MAX) for the frames after one did, halved again after HIST_HALO_CALM frames without; a lookup outside is always caught (exact fallback)
@@ -140,6 +146,7 @@ struct rt_mgpu {
   int balanceFrames = 0;               // frames balanced since the partition was last reset
   bool haveHistory = false, balance = true, serialize = false, gatherResults = true, pipeline = true;
   int solo = -1;
+  int levels[3] = {0, 0, 0};           // priority levels of every rank's main / indirect / filter stream (rt_mgpu_create)
   bool corruptHalo = false;            // test hook (RESTIR_TEST_CORRUPT_HALO=1): the first bytes of every pulled noisy-direct-colour halo are overwritten, so the
                                        // bench's tiled == untiled gate must report a mismatch (tests/test_gpu_bench_cli.py).  Never set outside tests.
   std::vector<uint8_t> peerOk;         // [puller rank * n + owner rank]: direct peer access from the puller's device to the owner's is enabled (rt_mgpu_create)
@@ -394,10 +401,19 @@ void waitAll(rt_mgpu& M, Rank& R, hipStream_t strm, int kind, int64_t seq, bool 
     MG_HIP(hipStreamWaitEvent(strm, Q.evp[kind][seq % RING], 0), "hipStreamWaitEvent");
   }
 }
+// the rank's indirect and filter stream (the context's, created here in its order: rt_get_streams), the display rank's copy stream — on the rank's first frame in flight
+void ensurePipeStreams(rt_mgpu& M, Rank& R)
+{
+  if(R.sInd && R.sSide && (R.id != 0 || R.sCopy)) return;
+  void* ind = nullptr; void* side = nullptr;
+  MG_CHECK(rt_get_streams(R.ctx, nullptr, &ind, &side), "rt_get_streams");
+  R.sInd = static_cast<hipStream_t>(ind); R.sSide = static_cast<hipStream_t>(side);
+  if(R.id == 0 && !R.sCopy) MG_HIP(hipStreamCreateWithFlags(&R.sCopy, hipStreamNonBlocking), "hipStreamCreate");   // the display rank's gather; the others have no use for a fourth hardware queue
+}
 void syncRank(rt_mgpu& M, Rank& R)
 {
-  MG_HIP(hipStreamSynchronize(R.stream), "sync"); MG_HIP(hipStreamSynchronize(R.sInd), "sync");
-  MG_HIP(hipStreamSynchronize(R.sSide), "sync"); if(R.sCopy) MG_HIP(hipStreamSynchronize(R.sCopy), "sync");
+  MG_HIP(hipStreamSynchronize(R.stream), "sync"); if(R.sInd) MG_HIP(hipStreamSynchronize(R.sInd), "sync");
+  if(R.sSide) MG_HIP(hipStreamSynchronize(R.sSide), "sync"); if(R.sCopy) MG_HIP(hipStreamSynchronize(R.sCopy), "sync");
 }
 void harvestTiming(Rank& R, int64_t seq)
 {
@@ -614,6 +630,8 @@ void framePipelined(rt_mgpu& M, Rank& R, const FrameCmd& c)
     for(auto& a : R.issued) a.store(s, std::memory_order_release);
     return;
   }
+  ensurePipeStreams(M, R);
+  if(R.rc != RT_OK) return;
   if(R.aIssued != s) pipeDirect(M, R, c);
   // second half of frame f-1, issued while direct(f) runs (the ids of the rotating buffers name frame f's: finishPrev undoes that for a re-run only)
   finishPrev(M, R, R.rotatedFor);
@@ -811,12 +829,13 @@ void rebalance(rt_mgpu* M)
 void destroyRank(Rank& R)
 {
   (void)hipSetDevice(R.dev);
-  if(R.ctx) rt_destroy(R.ctx);
+  if(R.ctx) rt_destroy(R.ctx);   // (takes the rank's main / indirect / filter streams with it: they are the context's — round 6)
   for(auto& e : R.ev) if(e) (void)hipEventDestroy(e);
   for(auto& k : R.evp) for(auto& e : k) if(e) (void)hipEventDestroy(e);
   for(auto& k : R.tm) for(auto& e : k) if(e) (void)hipEventDestroy(e);
   for(auto& k : R.tl) for(auto& e : k) if(e) (void)hipEventDestroy(e);
-  for(hipStream_t s : {R.stream, R.sInd, R.sSide, R.sCopy}) if(s) (void)hipStreamDestroy(s);
+  if(R.sCopy) (void)hipStreamDestroy(R.sCopy);
+  R.stream = R.sInd = R.sSide = R.sCopy = nullptr;
   R.ctx = nullptr;
 }
 
@@ -864,20 +883,21 @@ int rt_mgpu_create(rt_mgpu** out, int numRanks, const int* devices)
   for(int r = 0; r < numRanks; r++) {
     Rank& R = M->ranks[size_t(r)];
     R.id = r; R.dev = devices ? devices[r] : r;
-    int rc = rt_create(&R.ctx, R.dev);
+    // Round 6: a rank's three streams are its CONTEXT's streams (rt_get_streams): the main stream rt_create makes, and — created on the rank's first frame in flight
+    // (ensurePipeStreams), filter stream first, then the indirect stream, nothing in between — the two others, i.e. the creation order and the levels the single-GPU
+    // schedule was tuned on.  Before, every rank created three more streams next to its context's unused one, all of them up front: with N ranks emulated on one device
+    // (bench.py --emulate-world) 8 x 4-5 streams were alive while ONE rank was being timed "alone", and a stream's worth depends on how many the process created before
+    // it (profiles/r05_prio_by_config_ab.txt §2).  Levels: RESTIR_MGPU_PRIO = three characters over {-, 0, +} for the main / indirect / filter stream; the default was
+    // re-measured per rank in fresh processes on the real scene (profiles/r06_mgpu_streams_ab.txt; round 3 had chosen "main high" on the lite scene under the old layout).
+    int levels[3] = {MGPU_PRIO_DEFAULT[0], MGPU_PRIO_DEFAULT[1], MGPU_PRIO_DEFAULT[2]};
+    if(const char* e = getenv("RESTIR_MGPU_PRIO")) if(strlen(e) == 3 && strspn(e, "-0+") == 3) for(int i = 0; i < 3; i++) levels[i] = e[i] == '+' ? 1 : (e[i] == '-' ? -1 : 0);
+    for(int i = 0; i < 3; i++) M->levels[i] = levels[i];
+    int rc = rtCreateWithLevels(&R.ctx, R.dev, levels);
     if(rc != RT_OK) return bail(rc);
     (void)hipSetDevice(R.dev);
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    // stream priorities (0 none, 1 indirect stream high, 2 main stream high: the one used).  Measured per-rank periods of the 8-way 1080p
-    // benchmark frame (profiles/r03_mgpu_period_ab.txt): slowest rank 1.91 / 1.80 / 1.63 ms for 0 / 1 / 2 — the direct stage of frame f+1 is what the
-    // next frame of EVERY rank waits for
-    const int prio = 2;
-    const bool can = hi < lo;
-    bool ok = (can && prio == 2 ? hipStreamCreateWithPriority(&R.stream, hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking)) == hipSuccess;
-    ok = ok && (can && prio == 1 ? hipStreamCreateWithPriority(&R.sInd, hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(&R.sInd, hipStreamNonBlocking)) == hipSuccess;
-    ok = ok && hipStreamCreateWithFlags(&R.sSide, hipStreamNonBlocking) == hipSuccess;
-    if(r == 0) ok = ok && hipStreamCreateWithFlags(&R.sCopy, hipStreamNonBlocking) == hipSuccess;   // the display rank's gather; the others have no use for a fourth hardware queue
+    void* mainStream = nullptr;
+    bool ok = rt_get_streams(R.ctx, &mainStream, nullptr, nullptr) == RT_OK && mainStream;
+    R.stream = static_cast<hipStream_t>(mainStream);
     for(auto& e : R.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     for(auto& k : R.evp) for(auto& e : k) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     for(auto& k : R.tm) for(auto& e : k) ok = ok && hipEventCreate(&e) == hipSuccess;
@@ -1069,6 +1089,19 @@ const char* rt_mgpu_last_error(rt_mgpu* M) { return (M && !M->err.empty()) ? M->
 
 // What the links did for the latest complete frame of the frames-in-flight schedule: the four pull groups of every rank, event-timed on the stream that
 // carried them, with their bytes; plus the device of every rank and whether the puller has direct peer access to the owner (xGMI on an MI355X node).
+int rt_mgpu_get_stream_layout(rt_mgpu* M, int* created, int* index, int levels[3])
+{
+  if(!M) return RT_ERR_INVALID_ARG;
+  for(int r = 0; r < M->n; r++) {
+    int idx[3] = {-1, -1, -1};
+    const int rc = rt_get_stream_layout(M->ranks[size_t(r)].ctx, created, idx);
+    if(rc != RT_OK) return rc;
+    if(index) for(int k = 0; k < 3; k++) index[3 * r + k] = idx[k];
+  }
+  if(levels) { levels[0] = M->levels[0]; (void)rt_get_stream_priorities(M->ranks[0].ctx, &levels[1], &levels[2], nullptr, nullptr); }
+  return RT_OK;
+}
+
 int rt_mgpu_get_link_stats(rt_mgpu* M, rt_mgpu_link_stats* out)
 {
   if(!M || !out) return RT_ERR_INVALID_ARG;

@@ -36,10 +36,14 @@ struct rt_ctx {
   // the process lands on the 1st one's queue): 3.38 -> 3.71 ms per frame, found by two back-to-back bench lines in round 5.
   hipStream_t indStreams[3] = {nullptr, nullptr, nullptr}, sideStreams[3] = {nullptr, nullptr, nullptr};   // index = level + 1
   std::vector<hipStream_t> padStreams;   // idle streams of the creation-order probe (RESTIR_STREAM_PAD)
-  int prio[3] = {0, 1, 0};   // priority level of the main / indirect / filter stream (-1 low, 0 normal, +1 high): prioSpec() at rt_create, rt_set_stream_priorities, rt_tune_stream_priorities
+  int prio[3] = {0, 1, 0};   // priority level of the main / indirect / filter stream (-1 low, 0 normal, +1 high): prioSpec() at rt_create, rt_set_stream_priorities, the rule
   bool prioFromEnv = false;  // RESTIR_PRIO was set (A/B scripts stay in control)
-  bool prioDecided = false;  // the levels are final (environment, rt_set_stream_priorities, or the rule applied to the first frame's stage times)
-  float filterShare = -1.f;  // filters / (direct + indirect) of the first frame, stages run alone (the rule's input); -1: not measured
+  bool prioExplicit = false; // rt_set_stream_priorities was called: the rule stays out of it, also after rt_resize / a new scene
+  bool prioDecided = false;  // the levels are final (environment, rt_set_stream_priorities, or the rule applied to the probe frames' stage times)
+  float filterShare = -1.f;  // filters / (direct + indirect) of the LAST probe frame, stages run alone (the rule's input); -1: not measured
+  int probeFrames = 0;       // probe frames rendered so far for the pending decision (PRIO_PROBE_FRAMES of them: warm caches, warm history)
+  int denoiseSeen = -1;      // RtxState.denoise of the frames the decision was taken on: a toggle re-opens it (without the filters the share is compose alone)
+  int mainIdx = -1, indIdx[3] = {-1, -1, -1}, sideIdx[3] = {-1, -1, -1};   // creation index (process-wide, g_streamsCreated) of every stream above: rt_get_stream_layout
   void* dSky = nullptr;      // SkyPre (csrc/sky.h), valid while sunAndSky.in_use == 1
   void* dPick = nullptr;     // rt_pick_result written by k_pick
   rt_sun_and_sky sunAndSky{};
@@ -261,7 +265,15 @@ static void prioSpec(int level[3])   // (read at every rt_create: a host may cha
 }
 static hipError_t createStreamLevel(hipStream_t* s, int which, int level);
 static hipError_t createStream(hipStream_t* s, int which, bool high) { return createStreamLevel(s, which, high ? 1 : 0); }
+static std::atomic<int> g_streamsCreated{0};   // HIP streams this library has created in the process so far (a stream's worth depends on its place in that order)
+static hipError_t createStreamLevelRaw(hipStream_t* s, int which, int level);
 static hipError_t createStreamLevel(hipStream_t* s, int which, int level)
+{
+  const hipError_t e = createStreamLevelRaw(s, which, level);
+  if(e == hipSuccess) g_streamsCreated.fetch_add(1);
+  return e;
+}
+static hipError_t createStreamLevelRaw(hipStream_t* s, int which, int level)
 {
   const bool high = level > 0;
   int lo, hi;
@@ -289,6 +301,7 @@ template <class T> static int upload(rt_ctx* c, std::vector<void*>& pool, const 
 }
 static void freePool(std::vector<void*>& pool) { for(void* p : pool) (void)hipFree(p); pool.clear(); }
 static int ensureStackOverflow(rt_ctx* c);
+static void reopenPriorityDecision(rt_ctx* c);
 static int stackLdsEnv() { static const int v = getenv("RESTIR_STACK_LDS") ? std::max(2, atoi(getenv("RESTIR_STACK_LDS"))) : 0; return v; }
 static int stackLdsMin() { return stackLdsEnv() ? stackLdsEnv() : 6; }   // the shortest LDS stack any schedule uses: sizes the overflow areas
 
@@ -316,7 +329,14 @@ uint32_t rt_abi_version(void) { return (RT_ABI_VERSION_MAJOR << 16) | RT_ABI_VER
 
 const char* rt_last_error(rt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_createErr.c_str(); }
 
-int rt_create(rt_ctx** out, int device)
+}  // extern "C"
+// rt_create with explicit stream levels (main / indirect / filter; nullptr = RESTIR_PRIO or the defaults): csrc/mgpu.cpp gives every rank's context the levels of its
+// schedule so that the rank's streams are the CONTEXT's streams, created in the order the single-GPU schedule was tuned for (round 6) — not part of the C ABI.
+int rtCreateWithLevels(rt_ctx** out, int device, const int* levels);
+extern "C" {
+int rt_create(rt_ctx** out, int device) { return rtCreateWithLevels(out, device, nullptr); }
+}
+int rtCreateWithLevels(rt_ctx** out, int device, const int* levels)
 {
   if(!out) { g_createErr = "rt_create: out is NULL"; return RT_ERR_INVALID_ARG; }
   *out = nullptr;
@@ -330,8 +350,10 @@ int rt_create(rt_ctx** out, int device)
   c->device = device;
   {
     prioSpec(c->prio); c->prioFromEnv = getenv("RESTIR_PRIO") != nullptr; c->prioDecided = c->prioFromEnv;
+    if(levels) { for(int i = 0; i < 3; i++) c->prio[i] = std::max(-1, std::min(1, levels[i])); c->prioDecided = c->prioExplicit = true; }
     bool ok = createStreamLevel(&c->ownStream, 0, c->prio[0]) == hipSuccess;
     if(!ok) { g_createErr = "rt_create: hipStreamCreate failed"; rt_destroy(c); return RT_ERR_HIP; }
+    c->mainIdx = g_streamsCreated.load() - 1;
     c->stream = c->ownStream;
     for(int i = 0; i < 4; i++) {
       ok = ok && hipEventCreateWithFlags(&c->evD[i], hipEventDisableTiming) == hipSuccess;
@@ -348,6 +370,8 @@ int rt_create(rt_ctx** out, int device)
   *out = c;
   return RT_OK;
 }
+
+extern "C" {
 
 int rt_destroy(rt_ctx* c)
 {
@@ -485,6 +509,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
   }
   RT_HIP(c, hipDeviceSynchronize());
   c->haveScene = true;
+  reopenPriorityDecision(c);   // (the context is drained: syncAll above / hipDeviceSynchronize below)
   return RT_OK;
 }
 
@@ -620,6 +645,7 @@ int rt_build_accel(rt_ctx* c)
   c->numRefs = bo.tris.size(); c->spatialSplits = size_t(bo.spatialSplits); c->sahNodeSteps = bo.sahNodeSteps; c->sahTriSteps = bo.sahTriSteps;
   RT_HIP(c, hipDeviceSynchronize());
   c->haveAccel = true;
+  reopenPriorityDecision(c);
   return ensureStackOverflow(c);
 }
 
@@ -629,6 +655,7 @@ int rt_resize(rt_ctx* c, int w, int h)
   if(w <= 0 || h <= 0 || w > 32767 || h > 32767) return fail(c, RT_ERR_INVALID_ARG, "rt_resize: size must be in 1..32767 (RG16_SINT motion vectors)");
   RT_HIP(c, hipSetDevice(c->device));
   RT_HIP(c, syncAll(c));
+  reopenPriorityDecision(c);
   for(void*& p : c->indA) { if(p && p != c->bufs[RT_BUF_DENOISE_IND_A]) (void)hipFree(p); p = nullptr; }
   for(int i = 0; i < RT_BUF_COUNT; i++) { if(c->bufs[i]) (void)hipFree(c->bufs[i]); c->bufs[i] = nullptr; c->bufBytes[i] = 0; }
   if(c->spareG) { (void)hipFree(c->spareG); c->spareG = nullptr; }
@@ -723,10 +750,23 @@ static hipError_t ensureOverlapStreams(rt_ctx* c)
   static int padA = -1, padB = 0, padL = 0;
   if(padA < 0) { padA = 0; if(const char* pe = getenv("RESTIR_STREAM_PAD")) (void)sscanf(pe, "%d,%d,%d", &padA, &padB, &padL); }
   auto pad = [&](int n) { for(int i = 0; i < n; i++) { hipStream_t d = nullptr; (void)createStreamLevel(&d, 2, padL); c->padStreams.push_back(d); } };
-  if(!side) { pad(padA); e = createStreamLevel(&side, 2, c->prio[2]); }
-  if(e == hipSuccess && !ind) { pad(padB); e = createStreamLevel(&ind, 1, c->prio[1]); }
+  if(!side) { pad(padA); e = createStreamLevel(&side, 2, c->prio[2]); if(e == hipSuccess) c->sideIdx[c->prio[2] + 1] = g_streamsCreated.load() - 1; }
+  if(e == hipSuccess && !ind) { pad(padB); e = createStreamLevel(&ind, 1, c->prio[1]); if(e == hipSuccess) c->indIdx[c->prio[1] + 1] = g_streamsCreated.load() - 1; }
   c->sideStream = side; c->indStream = ind;
   return e;
+}
+
+// The rule of rt_render_frame's probe frames (see there).  RESTIR_PRIO_PROBE = number of probe frames (default 3; 1 = round 5's first-frame decision).
+static constexpr float PRIO_FILTER_SHARE = 0.14f;
+static int prioProbeFrames() { static const int n = getenv("RESTIR_PRIO_PROBE") ? std::max(1, atoi(getenv("RESTIR_PRIO_PROBE"))) : 3; return n; }
+// what the decision was taken on has changed (target size, scene, tree, denoise toggle): the next frames probe again.  The streams of the old levels stay alive, idle
+// (one per role and level, never destroyed: see rt_ctx::indStreams); the caller has drained the context.
+static void reopenPriorityDecision(rt_ctx* c)
+{
+  if(c->prioExplicit || c->prioFromEnv) return;
+  c->prioDecided = false; c->filterShare = -1.f; c->probeFrames = 0; c->denoiseSeen = -1;
+  c->prio[1] = 1; c->prio[2] = 0;
+  c->indStream = c->sideStream = nullptr;
 }
 
 static DevFrame makeFrame(rt_ctx* c, int frames)
@@ -804,11 +844,15 @@ int rt_render_frame(rt_ctx* c, const rt_state* st, int frames)
     for(int i = 0; i < rt_ctx::MAX_EV; i++) RT_HIP(c, hipEventCreate(&E.ev[i]));
     c->evSets.push_back(E);
   }
-  // The FIRST frame of a frames-in-flight context runs every stage alone on the main stream, is timed, and decides the priorities of the two other streams BEFORE they
-  // are created (below): filter stream high as well when the filter chain is a sizeable part of the frame's work.  Measured (profiles/r05_prio_by_config_ab.txt, every
-  // setting in a fresh process): filters / (direct + indirect) = 0.16 (real exterior scene: indirect-high alone is best), 0.22 (lite: both high -1.8 %), 0.48 (config 5:
-  // -6.4 %), 0.50 (config 3: -8.2 %).  The decision has to come first: a stream's place in the process's creation order changes what the schedule gets out of it (a
-  // setting introduced after another one's streams exist ran 15-45 % slower than in a fresh process), so settings cannot be compared in place.
+  // The first PRIO_PROBE_FRAMES frames of a frames-in-flight context ("probe frames") run every stage alone on the main stream and are timed; the LAST of them — warm
+  // caches, warm history, the steady state's ray lengths — decides the priorities of the two other streams BEFORE they are created (below): filter stream high as
+  // well when the filter chain is a sizeable part of the frame's work.  Round 5 decided on frame 0 alone (cold history: first-frame shares 0.12 real exterior scene /
+  // 0.16 lite / 0.25 config 3 / 0.34 config 5 against a threshold of 0.14 — the real scene sat 10 % from the edge); the warm shares and the margins are in
+  // profiles/r06_prio_rule.txt.  The decision has to precede the streams: a stream's place in the process's creation order changes what the schedule gets out of it (a
+  // setting introduced after another one's streams exist ran 15-45 % slower than in a fresh process, profiles/r05_prio_by_config_ab.txt), so settings cannot be
+  // compared in place.  A new target size, a new scene / tree or a denoise toggle re-opens the decision (reopenPriorityDecision); an explicit
+  // rt_set_stream_priorities / RESTIR_PRIO closes it for good.
+  if(c->prioDecided && !c->prioExplicit && !c->prioFromEnv && c->denoiseSeen >= 0 && (st->denoise > 0) != (c->denoiseSeen > 0)) { RT_HIP(c, syncAll(c)); reopenPriorityDecision(c); }
   const bool decide = c->overlap >= 2 && !c->prioDecided && c->spareG && c->spareMotion;
   if(decide) { RT_HIP(c, syncAll(c)); harvestTimings(c); }
   const double tracedBefore = c->accStage[RT_STAGE_DIRECT] + c->accStage[RT_STAGE_INDIRECT];
@@ -910,9 +954,12 @@ int rt_render_frame(rt_ctx* c, const rt_state* st, int frames)
     const double traced = (c->accStage[RT_STAGE_DIRECT] + c->accStage[RT_STAGE_INDIRECT]) - tracedBefore;
     const double filt = (c->accStage[RT_STAGE_DENOISE_DIRECT] + c->accStage[RT_STAGE_DENOISE_INDIRECT] + c->accStage[RT_STAGE_COMPOSE]) - filterBefore;
     c->filterShare = traced > 0.0 ? float(filt / traced) : -1.f;
-    c->prio[1] = 1; c->prio[2] = (c->filterShare >= 0.14f) ? 1 : 0;
-    c->prioDecided = true;
-    c->indStream = c->sideStream = nullptr;   // (created with these levels by the next frame: filter stream first, then the indirect stream)
+    c->denoiseSeen = st->denoise > 0 ? 1 : 0;
+    if(++c->probeFrames >= prioProbeFrames()) {
+      c->prio[1] = 1; c->prio[2] = (c->filterShare >= PRIO_FILTER_SHARE) ? 1 : 0;
+      c->prioDecided = true;
+      c->indStream = c->sideStream = nullptr;   // (created with these levels by the next frame: filter stream first, then the indirect stream)
+    }
   }
   return RT_OK;
 }
@@ -1123,15 +1170,15 @@ int rt_set_stream_priorities(rt_ctx* c, int indirectLevel, int filterLevel)
   if(!c || indirectLevel < -1 || indirectLevel > 1 || filterLevel < -1 || filterLevel > 1) return RT_ERR_INVALID_ARG;
   RT_HIP(c, hipSetDevice(c->device));
   RT_HIP(c, syncAll(c));
-  c->prioDecided = true;   // an explicit choice: the first-frame rule stays out of it
+  c->prioDecided = c->prioExplicit = true;   // an explicit choice: the probe-frame rule stays out of it, also after rt_resize / a new scene
   if(c->prio[1] == indirectLevel && c->prio[2] == filterLevel) return RT_OK;
   c->prio[1] = indirectLevel; c->prio[2] = filterLevel;
   c->indStream = c->sideStream = nullptr;   // (selected — and created, once per level — on first use: ensureOverlapStreams; streams of other levels stay alive, idle)
   return RT_OK;
 }
 
-/* The levels in use and the measurement behind them: filterShare = filters / (direct + indirect) of the first frame with every stage alone (-1: no frame yet, or the
- * levels were set explicitly / by RESTIR_PRIO); decided = 0 while the first frame has not been rendered. */
+/* The levels in use and the measurement behind them: filterShare = filters / (direct + indirect) of the last probe frame, every stage alone (-1: no frame yet, or the
+ * levels were set explicitly / by RESTIR_PRIO); decided = 0 while the probe frames have not all been rendered. */
 int rt_get_stream_priorities(rt_ctx* c, int* indirectLevel, int* filterLevel, float* filterShare, int* decided)
 {
   if(!c) return RT_ERR_INVALID_ARG;
@@ -1139,6 +1186,36 @@ int rt_get_stream_priorities(rt_ctx* c, int* indirectLevel, int* filterLevel, fl
   if(filterLevel) *filterLevel = c->prio[2];
   if(filterShare) *filterShare = c->filterShare;
   if(decided) *decided = c->prioDecided ? 1 : 0;
+  return RT_OK;
+}
+
+/* The context's three streams of the frames-in-flight schedule, for a host that issues the stages itself (rt_run_stage + rt_set_stream: restir_amd/tiled.py,
+ * csrc/mgpu.cpp).  Creates the filter and the indirect stream if they do not exist yet — with the current levels, in the order the schedule was tuned for (filter
+ * stream first, then the indirect stream, nothing in between) — so that such a host runs on the SAME stream layout as rt_render_frame instead of on streams from
+ * another pool created whenever (round-5 finding: a stream's place in the process's creation order is worth 15-75 % of a frame).  Call it before anything else in the
+ * process creates streams (torch's pool, RCCL's communicator).  The handles stay owned by the context. */
+int rt_get_streams(rt_ctx* c, void** mainStream, void** indirectStream, void** filterStream)
+{
+  if(!c) return RT_ERR_INVALID_ARG;
+  RT_HIP(c, hipSetDevice(c->device));
+  if(indirectStream || filterStream) {   // (asking for the main stream alone creates nothing: csrc/mgpu.cpp creates a rank's other two on its first frame in flight)
+    RT_HIP(c, ensureOverlapStreams(c));
+    c->prioDecided = true;   // the levels these streams were created with stand: a later rt_render_frame does not probe and switch
+  }
+  if(mainStream) *mainStream = c->ownStream;
+  if(indirectStream) *indirectStream = c->indStream;
+  if(filterStream) *filterStream = c->sideStream;
+  return RT_OK;
+}
+
+/* Where this context's streams sit in the process's creation order: created = HIP streams this LIBRARY has created in the process so far (all contexts; streams made by
+ * the host — torch's pool, RCCL — are not visible to it), index[0..2] = creation index of the main / indirect / filter stream in use (-1: not created yet).  bench.py
+ * prints it with every N > 1 line (`stream_layout`). */
+int rt_get_stream_layout(rt_ctx* c, int* created, int index[3])
+{
+  if(!c) return RT_ERR_INVALID_ARG;
+  if(created) *created = g_streamsCreated.load();
+  if(index) { index[0] = c->mainIdx; index[1] = c->indStream ? c->indIdx[c->prio[1] + 1] : -1; index[2] = c->sideStream ? c->sideIdx[c->prio[2] + 1] : -1; }
   return RT_OK;
 }
 

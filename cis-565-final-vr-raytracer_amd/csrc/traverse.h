@@ -63,7 +63,7 @@ RT_DEV bool wrapIsMask(int w, int h, int wrapS, int wrapT) { return (((w & (w - 
 RT_DEV bool waveNone(bool c) { return __builtin_amdgcn_ballot_w64(c) == 0ull; }
 RT_DEV f4 texelBGRA(const DevTexture& t, int x, int y)
 {
-  uint32_t p = *reinterpret_cast<const uint32_t*>(t.bgra + (size_t(y) * t.w + x) * 4);
+  uint32_t p = gLoadU32(t.bgra + (size_t(y) * t.w + x) * 4);   // (t.bgra was loaded from the texture table: generic to the compiler)
   return mk4(unorm8ToFloat((p >> 16) & 0xffu), unorm8ToFloat((p >> 8) & 0xffu), unorm8ToFloat(p & 0xffu), unorm8ToFloat(p >> 24));
 }
 RT_DEV f4 sampleTexture(const DevScene& S, int id, f2 uv)
@@ -92,7 +92,7 @@ RT_DEV f4 sampleTexture(const DevScene& S, int id, f2 uv)
 }
 RT_DEV f4 envTexel(const DevScene& S, int x, int y)
 {
-  const float4 p = *reinterpret_cast<const float4*>(S.env + (size_t(y) * S.envW + x) * 4);
+  const float4 p = gLoadF4(S.env + (size_t(y) * S.envW + x) * 4);
   return mk4(p.x, p.y, p.z, p.w);
 }
 // environmentTexture: linear, U repeat, V clamp-to-edge (hdr_sampling.cpp:69-77)
@@ -135,7 +135,7 @@ struct AlphaFetch { const uint8_t* p00; const uint8_t* p10; const uint8_t* p01; 
 RT_DEV AlphaRegs alphaLoad(const DevScene& S, uint32_t alphaIdx)
 {
   const uint4* rp = reinterpret_cast<const uint4*>(S.alphaRec + alphaIdx);
-  AlphaRegs A; A.r0 = rp[0]; A.r1 = rp[1]; A.r2 = rp[2]; A.r3 = rp[3];
+  AlphaRegs A; A.r0 = gLoadU4(rp); A.r1 = gLoadU4(rp + 1); A.r2 = gLoadU4(rp + 2); A.r3 = gLoadU4(rp + 3);
   return A;
 }
 // texel addresses of the fetch; without a texture every address is `safe` (a readable dummy) so that callers may load unconditionally
@@ -199,8 +199,9 @@ RT_DEV bool hitTestAlpha(const DevScene& S, uint32_t alphaIdx, uint32_t gid, flo
   const AlphaRegs A = alphaLoad(S, alphaIdx);
   const AlphaFetch F = alphaAddr(A, u, v, reinterpret_cast<const uint8_t*>(S.alphaRec));
   uint8_t a00 = 0, a10 = 0, a01 = 0, a11 = 0;
-  if(F.kind == 1) a00 = *F.p00;
-  else if(F.kind == 2) { a00 = *F.p00; a10 = *F.p10; a01 = *F.p01; a11 = *F.p11; }
+  // (the texel addresses derive from AlphaRec::bgra, a pointer loaded from memory)
+  if(F.kind == 1) a00 = gLoadU8(F.p00);
+  else if(F.kind == 2) { a00 = gLoadU8(F.p00); a10 = gLoadU8(F.p10); a01 = gLoadU8(F.p01); a11 = gLoadU8(F.p11); }
   return alphaFinish(A, F, a00, a10, a01, a11, gid, raySeed);
 }
 
@@ -300,21 +301,25 @@ RT_DEV bool travInit(Trav& T, f3 o, f3 d, float tmax, uint32_t raySeed)
 // ray of this tree can need in HBM, one small area per thread of the launch.  The short LDS stack is what lets LDS-staged filter kernels run beside
 // the traversal kernels of the neighbouring frames in flight (profiles/r02_short_stack_ab.txt; a ring of the TOP entries in LDS was measured too:
 // it needs a power-of-two size, and 4 KB per wave loses more to LDS pressure than the rarer HBM accesses gain).
-RT_DEV uint2& stackOverflowSlot(const DevScene& S, int sp)
+// Round 6: the two homes of a stack entry are accessed through TYPED pointers (ldsLoadU2 / gLoadU2, dev_math.h) on two explicit paths.  Written as
+// `cond ? stack[..] : ovf[..]` the compiler merged both into one generic pointer and every pop became flat_load_dwordx2 + s_waitcnt vmcnt(0) lgkmcnt(0) —
+// a wait that also drains whatever node / triangle fetch is in flight; now the common pop is ds_read_b64 + lgkmcnt only (scripts/isa_census.py,
+// profiles/r06_addrspace_ab.txt).
+RT_DEV uint2* stackOverflowSlot(const DevScene& S, int sp)
 {
   const size_t thread = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  return S.stackOvf[thread * size_t(S.stackTotal - S.stackEntries) + size_t(sp - S.stackEntries)];
+  return S.stackOvf + (thread * size_t(S.stackTotal - S.stackEntries) + size_t(sp - S.stackEntries));
 }
 RT_DEV uint2 stackPop(const DevScene& S, Trav& T, uint2* stack)
 {
   --T.sp;
-  if(T.sp < S.stackEntries) return stack[T.sp * 64];
-  return stackOverflowSlot(S, T.sp);
+  if(__builtin_expect(T.sp < S.stackEntries, 1)) return ldsLoadU2(stack + T.sp * 64);
+  return gLoadU2(stackOverflowSlot(S, T.sp));
 }
 RT_DEV void stackPush(const DevScene& S, Trav& T, uint2* stack, uint2 g)
 {
-  if(T.sp < S.stackEntries) stack[(T.sp++) * 64] = g;
-  else if(T.sp < S.stackTotal) { stackOverflowSlot(S, T.sp) = g; T.sp++; }   // (deeper than the tree: cannot happen, rt_build_accel sizes stackTotal)
+  if(__builtin_expect(T.sp < S.stackEntries, 1)) ldsStoreU2(stack + (T.sp++) * 64, g);
+  else if(T.sp < S.stackTotal) { gStoreU2(stackOverflowSlot(S, T.sp), g); T.sp++; }   // (deeper than the tree: cannot happen, rt_build_accel sizes stackTotal)
 }
 
 // Node step (precondition: no pending triangles, travHasNodes).  `stack` = this lane's LDS column (stride 64 entries).
@@ -337,7 +342,7 @@ RT_DEV uint32_t travNodeSelect(const DevScene& S, Trav& T, uint2* stack)
 RT_DEV NodeRegs nodeLoad(const DevScene& S, uint32_t index)
 {
   const uint4* np = reinterpret_cast<const uint4*>(S.nodes + index);
-  NodeRegs N; N.n0 = np[0]; N.n1 = np[1]; N.n2 = np[2]; N.n3 = np[3]; N.n4 = np[4];
+  NodeRegs N; N.n0 = gLoadU4(np); N.n1 = gLoadU4(np + 1); N.n2 = gLoadU4(np + 2); N.n3 = gLoadU4(np + 3); N.n4 = gLoadU4(np + 4);
   return N;
 }
 RT_DEV void travNodeTest(Trav& T, const NodeRegs& N)
@@ -391,7 +396,7 @@ struct TriRegs { uint4 a, b, c, om; };
 RT_DEV TriRegs triLoad(const DevScene& S, uint32_t triIndex)
 {
   const uint4* tp = reinterpret_cast<const uint4*>(S.tris + triIndex);
-  TriRegs Q; Q.a = tp[0]; Q.b = tp[1]; Q.c = tp[2]; Q.om = tp[3];
+  TriRegs Q; Q.a = gLoadU4(tp); Q.b = gLoadU4(tp + 1); Q.c = gLoadU4(tp + 2); Q.om = gLoadU4(tp + 3);
   return Q;
 }
 // everything but the texture fetch: 0 = rejected, 1 = accepted, 2 = accepted iff HitTest on the triangle's AlphaRec (alphaIdx) accepts
@@ -754,8 +759,8 @@ template <int CTRL> RT_DEV void candMinStep(WideCand& c)
 RT_DEV void groupMinCand(WideCand& c) { candMinStep<RT_DPP_XOR1>(c); candMinStep<RT_DPP_XOR2>(c); candMinStep<RT_DPP_HALF_MIRROR>(c); }
 
 // the ray's stack: one 8-byte column per ray, stride WIDE_RAYS entries (every lane of the group reads the same address; lane 0 of the group writes)
-RT_DEV uint2 stackPopW(Trav& T, const uint2* stack) { --T.sp; return stack[T.sp * WIDE_RAYS]; }
-RT_DEV void stackPushW(Trav& T, uint2* stack, uint2 g, int j) { if(j == 0) stack[T.sp * WIDE_RAYS] = g; T.sp++; }
+RT_DEV uint2 stackPopW(Trav& T, const uint2* stack) { --T.sp; return ldsLoadU2(stack + T.sp * WIDE_RAYS); }
+RT_DEV void stackPushW(Trav& T, uint2* stack, uint2 g, int j) { if(j == 0) ldsStoreU2(stack + T.sp * WIDE_RAYS, g); T.sp++; }
 RT_DEV uint32_t travNodeSelectW(Trav& T, uint2* stack, int j)
 {
   uint2 ngroup = T.ngroup;
@@ -824,7 +829,7 @@ RT_DEV void travTriW(const DevScene& S, Trav& T, int j, TravCounters& tc)
     const uint32_t ti = T.tgroup.x + uint32_t(mine);
     const TriRegs Q = triLoad(S, ti);
     const uint4* ap = reinterpret_cast<const uint4*>(S.alphaByTri + ti);   // fetched with the record, whether needed or not: no second dependent access
-    AlphaRegs A; A.r0 = ap[0]; A.r1 = ap[1]; A.r2 = ap[2]; A.r3 = ap[3];
+    AlphaRegs A; A.r0 = gLoadU4(ap); A.r1 = gLoadU4(ap + 1); A.r2 = gLoadU4(ap + 2); A.r3 = gLoadU4(ap + 3);
     RT_PH(0)   // record + AlphaRec arrive
     const int s = triCandidateGeom(S, Q, T.o, T.d, ANY, T.tmax, T.hit.t, T.hit.gid, T.seed, t, u, v, gid, alphaIdx, tc);
     ok = s == 1;
@@ -833,8 +838,8 @@ RT_DEV void travTriW(const DevScene& S, Trav& T, int j, TravCounters& tc)
       const AlphaFetch Fh = alphaAddr(A, u, v, reinterpret_cast<const uint8_t*>(S.alphaRec));
       RT_PH(2) // texel addresses
       uint8_t a00 = 0, a10 = 0, a01 = 0, a11 = 0;
-      if(Fh.kind == 1) a00 = *Fh.p00;
-      else if(Fh.kind == 2) { a00 = *Fh.p00; a10 = *Fh.p10; a01 = *Fh.p01; a11 = *Fh.p11; }
+      if(Fh.kind == 1) a00 = gLoadU8(Fh.p00);
+      else if(Fh.kind == 2) { a00 = gLoadU8(Fh.p00); a10 = gLoadU8(Fh.p10); a01 = gLoadU8(Fh.p01); a11 = gLoadU8(Fh.p11); }
       RT_PH(3) // texels arrive
       ok = alphaFinish(A, Fh, a00, a10, a01, a11, gid, T.seed);
       RT_PH(4) // filter + draw

@@ -15,9 +15,9 @@ _lib = None
 # every symbol include/rt_abi.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_build_accel", "rt_resize", "rt_set_camera",
                "rt_render_frame", "rt_run_stage", "rt_readback", "rt_upload_history", "rt_buffer_bytes", "rt_device_ptr",
-               "rt_set_counting", "rt_get_counters", "rt_sync", "rt_last_error", "rt_abi_version", "rt_set_traversal", "rt_set_history_rows", "rt_history_miss", "rt_set_overlap", "rt_tonemap", "rt_set_sun_and_sky", "rt_pick", "rt_trace_rays", "rt_history_miss_stage", "rt_rotate_buffers", "rt_select_frame", "rt_measure_valu_peak", "rt_set_stream_priorities", "rt_get_stream_priorities",
+               "rt_set_counting", "rt_get_counters", "rt_sync", "rt_last_error", "rt_abi_version", "rt_set_traversal", "rt_set_history_rows", "rt_history_miss", "rt_set_overlap", "rt_tonemap", "rt_set_sun_and_sky", "rt_pick", "rt_trace_rays", "rt_history_miss_stage", "rt_rotate_buffers", "rt_select_frame", "rt_measure_valu_peak", "rt_set_stream_priorities", "rt_get_stream_priorities", "rt_get_streams", "rt_get_stream_layout",
                "rt_mgpu_create", "rt_mgpu_destroy", "rt_mgpu_upload_scene", "rt_mgpu_resize", "rt_mgpu_set_camera", "rt_mgpu_render_frame", "rt_mgpu_readback",
-               "rt_mgpu_sync", "rt_mgpu_set_balance", "rt_mgpu_set_serialize", "rt_mgpu_set_pipeline", "rt_mgpu_set_gather", "rt_mgpu_set_solo", "rt_mgpu_set_bands", "rt_mgpu_get_stats", "rt_mgpu_get_link_stats", "rt_mgpu_last_error", "rt_mgpu_plan_bands"]
+               "rt_mgpu_sync", "rt_mgpu_set_balance", "rt_mgpu_set_serialize", "rt_mgpu_set_pipeline", "rt_mgpu_set_gather", "rt_mgpu_set_solo", "rt_mgpu_set_bands", "rt_mgpu_get_stats", "rt_mgpu_get_link_stats", "rt_mgpu_get_stream_layout", "rt_mgpu_last_error", "rt_mgpu_plan_bands"]
 
 
 def hip_lib():
@@ -84,6 +84,9 @@ def hip_lib():
         L.rt_mgpu_plan_bands.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.rt_set_stream_priorities.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.rt_get_stream_priorities.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rt_get_streams.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        L.rt_get_stream_layout.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int * 3)]
+        L.rt_mgpu_get_stream_layout.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
         L.rt_accel_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
         L.rt_accel_quality.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _lib = L
@@ -256,10 +259,23 @@ class Renderer:
         self._chk(hip_lib().rt_set_stream_priorities(self._h, int(indirect_level), int(filter_level)), "rt_set_stream_priorities")
 
     def stream_priorities(self):
-        """{"chosen": [indirect, filter], "filter_share": filters / (direct + indirect) of the first frame or None, "decided": bool} (rt_get_stream_priorities)"""
+        """{"chosen": [indirect, filter], "filter_share": filters / (direct + indirect) of the last probe frame or None, "decided": bool} (rt_get_stream_priorities)"""
         a, b, sh, d = C.c_int(), C.c_int(), C.c_float(), C.c_int()
         self._chk(hip_lib().rt_get_stream_priorities(self._h, C.byref(a), C.byref(b), C.byref(sh), C.byref(d)), "rt_get_stream_priorities")
         return {"chosen": [a.value, b.value], "filter_share": (round(sh.value, 4) if sh.value >= 0 else None), "decided": bool(d.value)}
+
+    def streams(self):
+        """{"main", "ind", "side"}: the context's three hipStream_t handles of the frames-in-flight schedule (rt_get_streams; created on first call — filter stream, then
+        indirect stream — with the current levels).  A host that issues the stages itself runs on these (restir_amd/tiled.py) instead of on streams of its own."""
+        m, i, f = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._chk(hip_lib().rt_get_streams(self._h, C.byref(m), C.byref(i), C.byref(f)), "rt_get_streams")
+        return {"main": m.value, "ind": i.value, "side": f.value}
+
+    def stream_layout(self):
+        """{"library_streams_created": n, "creation_index": {"main": i, "ind": j, "side": k}} (rt_get_stream_layout; -1 = not created)"""
+        n, idx = C.c_int(), (C.c_int * 3)()
+        self._chk(hip_lib().rt_get_stream_layout(self._h, C.byref(n), C.byref(idx)), "rt_get_stream_layout")
+        return {"library_streams_created": n.value, "creation_index": {"main": idx[0], "ind": idx[1], "side": idx[2]}}
 
     def accel_stats(self):
         n, t, d = C.c_uint64(), C.c_uint64(), C.c_int()
@@ -341,6 +357,13 @@ class MultiGpuRenderer:
         s = MgpuStats()
         self._chk(hip_lib().rt_mgpu_get_stats(self._h, C.byref(s)), "rt_mgpu_get_stats")
         return s
+    def stream_layout(self):
+        """per rank: creation index of its main / indirect / filter stream in the process (-1 = not created yet), + the levels (rt_mgpu_get_stream_layout)"""
+        n = self.world
+        created, idx, lv = C.c_int(), (C.c_int * (3 * n))(), (C.c_int * 3)()
+        self._chk(hip_lib().rt_mgpu_get_stream_layout(self._h, C.byref(created), idx, lv), "rt_mgpu_get_stream_layout")
+        return {"library_streams_created": created.value, "levels_main_ind_side": [lv[0], lv[1], lv[2]],
+                "creation_index": [{"main": idx[3 * r], "ind": idx[3 * r + 1], "side": idx[3 * r + 2]} for r in range(n)]}
     def link_stats(self):
         s = MgpuLinkStats()
         self._chk(hip_lib().rt_mgpu_get_link_stats(self._h, C.byref(s)), "rt_mgpu_get_link_stats")

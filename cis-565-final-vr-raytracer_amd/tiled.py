@@ -801,14 +801,23 @@ class RendererTensors:
         self.r.rotate_buffers(frames)
         for buf in (abi.BUF_GBUFFER0, abi.BUF_GBUFFER1, abi.BUF_MOTION):
             self._cache.pop(buf, None)
+    @staticmethod
+    def create_streams(renderer):
+        """The rank's three streams = the CONTEXT's (rt_get_streams, ABI 2.3): created on the first call, filter stream first, then the indirect stream, with the levels of
+        RESTIR_TILED_PRIO (streams that get high priority: any of `ind`, `side`; default `ind`).  Round 5 found that a stream's worth depends on how many streams the
+        process created before it; until round 6 this host took three streams from torch's pool (32 per priority class, created on first use — after RCCL's).  Call before
+        torch.distributed.init_process_group.  Measured (per-rank emulation, N = 2 / 8, round 3): none 2.94 / 2.14 ms, "ind" 2.59 / 1.88, "ind,side" 2.60 / 1.90 — the
+        indirect stage carries the critical path (one multi-bounce tile), its waves should not queue behind the next frame's direct stage."""
+        import os
+        prio = os.environ.get("RESTIR_TILED_PRIO", "ind").split(",")
+        if renderer.stream_layout()["creation_index"]["ind"] < 0:
+            renderer.set_stream_priorities(1 if "ind" in prio else 0, 1 if "side" in prio else 0)
+        return renderer.streams()
     def stream(self, name):
         """Context: kernels (rt_set_stream) and collectives (torch current stream) issued inside go to the named stream."""
         if self._streams is None:
-            import os
-            prio = os.environ.get("RESTIR_TILED_PRIO", "ind")   # streams that get high priority.  Measured (per-rank emulation, N = 2 / 8):
-            # none 2.94 / 2.14 ms, "ind" 2.59 / 1.88, "ind,side" 2.60 / 1.90, "main" 2.54 / 2.06 — the indirect stage carries the
-            # critical path (one multi-bounce tile), its waves should not queue behind the next frame's direct stage
-            self._streams = {n: self.torch.cuda.Stream(priority=-1 if n in prio.split(",") else 0) for n in ("main", "ind", "side")}
+            ptrs = RendererTensors.create_streams(self.r)
+            self._streams = {n: self.torch.cuda.ExternalStream(ptrs[n]) for n in ("main", "ind", "side")}
         backend, s = self, self._streams[name]
         class _Ctx:
             def __enter__(self_):

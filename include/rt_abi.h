@@ -419,14 +419,23 @@ int rt_set_sun_and_sky(rt_ctx* ctx, const rt_sun_and_sky* ss);
 int rt_set_overlap(rt_ctx* ctx, int mode);
 /* Priorities of the indirect-stage stream and the filter stream of mode 2 (levels: -1 low, 0 normal, +1 high).  The reference submits its dispatches to ONE queue
  * (src/renderer.cpp:154-206) and has no such choice; here three streams share the chip and the fastest setting depends on the workload
- * (profiles/r05_prio_by_config_ab.txt).  Unset (no call, no RESTIR_PRIO), the context decides at its FIRST mode-2 frame: that frame runs every stage alone on the main
- * stream, is timed, and the filter stream becomes high next to the indirect stream when filters / (direct + indirect) >= 0.14; the two streams are created afterwards.
- * An explicit call is best made before the first frame: a stream created after others exist may share a hardware queue with them.  Results are identical under every
- * setting.  Drains the context. */
+ * (profiles/r05_prio_by_config_ab.txt).  Unset (no call, no RESTIR_PRIO), the context decides on its first three mode-2 frames ("probe frames": every stage alone on
+ * the main stream, timed): the filter stream becomes high next to the indirect stream when filters / (direct + indirect) of the LAST probe frame — warm caches, warm
+ * history — is >= 0.14; the two streams are created afterwards.  rt_resize, a new scene / tree and a denoise toggle re-open that decision (round 6; round 5 decided once,
+ * on the cold first frame).  An explicit call is best made before the first frame: a stream created after others exist may share a hardware queue with them; it
+ * stands for the context's lifetime.  Results are identical under every setting.  Drains the context. */
 int rt_set_stream_priorities(rt_ctx* ctx, int indirectLevel, int filterLevel);
-/* The levels in use; filterShare = the first frame's filters / (direct + indirect) (-1: not measured: no frame yet, or the levels were given); decided = 0 before the
- * first frame of a context that decides for itself.  Any pointer may be NULL. */
+/* The levels in use; filterShare = the last probe frame's filters / (direct + indirect) (-1: not measured: no frame yet, or the levels were given); decided = 0 while a
+ * context that decides for itself is still probing.  Any pointer may be NULL. */
 int rt_get_stream_priorities(rt_ctx* ctx, int* indirectLevel, int* filterLevel, float* filterShare, int* decided);
+/* The context's three streams of the frames-in-flight schedule (hipStream_t; owned by the context), for a host that issues the stages itself through rt_run_stage +
+ * rt_set_stream (restir_amd/tiled.py wraps them in torch.cuda.ExternalStream; csrc/mgpu.cpp uses them per rank).  The reference has ONE queue (src/renderer.cpp:154-206);
+ * here a host that brought its own streams (torch's pool of 32, created after RCCL's) ran on a stream layout the schedule was never measured on.  Creates the filter,
+ * then the indirect stream with the current levels if they do not exist (only when one of the two is asked for: with both NULL nothing is created); call before anything
+ * else in the process creates streams.  Any pointer may be NULL. */
+int rt_get_streams(rt_ctx* ctx, void** mainStream, void** indirectStream, void** filterStream);
+/* created = HIP streams this library has created in the process so far; index[0..2] = creation index of this context's main / indirect / filter stream (-1: none yet). */
+int rt_get_stream_layout(rt_ctx* ctx, int* created, int index[3]);
 /* ------------------------------------------------------------------------------------------------------------------
  * Multi-GPU context (csrc/mgpu.cpp): the row-tiled frame of BASELINE.json / SURVEY.md §8(e) for a host that owns all the
  * GPUs of the node from ONE process — "multi-GPU ctx internally drives 8 streams" (§8b threading row).  One worker thread,
@@ -487,6 +496,9 @@ typedef struct {
   uint64_t pullBytes[RT_MGPU_MAX_RANKS][4];
 } rt_mgpu_link_stats;
 int rt_mgpu_get_link_stats(rt_mgpu* m, rt_mgpu_link_stats* out);
+/* rt_get_stream_layout of every rank's context: created = streams the library has created in the process; index[3 * rank + {0, 1, 2}] = creation index of that rank's
+ * main / indirect / filter stream (-1: not created yet — a rank's two extra streams are created on its first frame in flight); levels[3] = their priority levels. */
+int rt_mgpu_get_stream_layout(rt_mgpu* m, int* created, int* index, int levels[3]);
 /* The partition rule on its own (pure host arithmetic): boundaries (numRanks + 1 rows, multiples of 16) that equalise the summed cost of the
  * 16-row stripes; with prevBands a boundary moves at most maxMoveStripes stripes (< 0: unlimited); every rank keeps >= one stripe. */
 int rt_mgpu_plan_bands(int height, int numRanks, const float* stripeCost, const int* prevBands, int maxMoveStripes, int* outBands);
@@ -501,10 +513,10 @@ int rt_measure_valu_peak(rt_ctx* ctx, int variant, int wavesPerSimd, double* wav
 int rt_sync(rt_ctx* ctx);
 /* Last error message of this ctx (or of rt_create when ctx == NULL). Never NULL. */
 const char* rt_last_error(rt_ctx* ctx);
-/* ABI version: (major<<16)|minor.  2.2 (round 5): + rt_set_stream_priorities, rt_get_stream_priorities.  2.1 (round 4): + rt_mgpu_get_link_stats.  2.0 (round 3): rt_set_pipeline -> rt_set_traversal; RT_STAGE_DIRECT levels 1 / 2 are rejected outside the
+/* ABI version: (major<<16)|minor.  2.3 (round 6): + rt_get_streams, rt_get_stream_layout, rt_mgpu_get_stream_layout; the priority rule probes three frames and re-opens on resize / scene / denoise.  2.2 (round 5): + rt_set_stream_priorities, rt_get_stream_priorities.  2.1 (round 4): + rt_mgpu_get_link_stats.  2.0 (round 3): rt_set_pipeline -> rt_set_traversal; RT_STAGE_DIRECT levels 1 / 2 are rejected outside the
  * spatial modes; 1.1 would have been round 2's additions (rt_mgpu_*, rt_measure_valu_peak, the `level` halves of RT_STAGE_DIRECT). */
 #define RT_ABI_VERSION_MAJOR 2u
-#define RT_ABI_VERSION_MINOR 2u
+#define RT_ABI_VERSION_MINOR 3u
 uint32_t rt_abi_version(void);
 
 #ifdef __cplusplus

@@ -1,5 +1,7 @@
 """bench.py's N > 1 bookkeeping that no one-GPU box can execute end to end (round-4 verdict, item 2): the default `--gpus N` run reports BOTH hosts in one line — the
-RCCL host it was launched as and the native host (child process) — with `value` from the faster host whose tiled == untiled gate passed.  The child is faked here; the
+RCCL host it was launched as and the native host (child process).  Since round 6 `value` stays with ONE named host — the RCCL host the driver launched — while its gate
+passes (the headline does not switch implementation between runs), `faster_host` names the faster verified one, the child gets every partition-planning flag and only the
+time that is left of the command's wall budget.  The child is faked here; the
 gate itself runs over gloo in tests/test_tiled_gloo.py and on the GPU in tests/test_gpu_bench_cli.py."""
 import json
 import os
@@ -15,7 +17,8 @@ import bench  # noqa: E402
 
 
 def _args():
-    return types.SimpleNamespace(gpus=8, steps=20, warmup=5, config=4, scene_footprint="real", scale=1.0, verify_frames=3, moving_camera=False, equal_bands=False, width=0, height=0, devices="")
+    return types.SimpleNamespace(gpus=8, steps=20, warmup=5, config=4, scene_footprint="real", scale=1.0, verify_frames=3, moving_camera=False, equal_bands=False, width=0, height=0, devices="",
+                                 band_rounds=5, diffuse_rounds=7, period_rounds=4)
 
 
 def _line(value, ok=True, **kw):
@@ -37,22 +40,31 @@ def _fake_child(monkeypatch, stdout="", returncode=0, stderr="", raises=None):
     return calls
 
 
-def test_faster_verified_host_becomes_the_value(monkeypatch):
+def test_value_stays_with_the_launched_host_and_the_faster_one_is_named(monkeypatch):
     calls = _fake_child(monkeypatch, stdout="noise\n" + json.dumps(_line(2600.0, host="native", links={"x": 1})) + "\n")
     monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("WORLD_SIZE", "8"); monkeypatch.setenv("MASTER_PORT", "1234")
     out = bench.both_hosts(_args(), _line(2100.0, rccl_ranks=8, rccl="ok", peer_access=[[1]]))
-    assert out["host"] == "native" and out["value"] == 2600.0 and out["links"] == {"x": 1}
+    assert out["host"] == "rccl" and out["value"] == 2100.0 and out["faster_host"] == "native"
     assert out["hosts"]["rccl"]["value"] == 2100.0 and out["hosts"]["native"]["value"] == 2600.0 and out["hosts_all_verified"] is True
     assert out["rccl_ranks"] == 8 and out["rccl"] == "ok" and out["tiled_equals_untiled"] is True
     cmd, kw = calls[0]
     assert "--native" in cmd and cmd[cmd.index("--gpus") + 1] == "8" and cmd[cmd.index("--steps") + 1] == "20" and cmd[cmd.index("--scene-footprint") + 1] == "real"
+    assert cmd[cmd.index("--band-rounds") + 1] == "5" and cmd[cmd.index("--diffuse-rounds") + 1] == "7"       # (dropped until round 6: the child planned another partition)
+    assert 0 < kw["timeout"] <= 1500                                                      # bounded by what is left of the command's wall budget
     assert not any(k in kw["env"] for k in ("RANK", "WORLD_SIZE", "MASTER_PORT"))      # the child is ONE process: no launcher environment
+
+
+def test_second_host_is_skipped_when_the_wall_budget_is_spent(monkeypatch):
+    calls = _fake_child(monkeypatch, stdout=json.dumps(_line(2600.0, host="native")))
+    monkeypatch.setenv("RESTIR_BENCH_WALL_LIMIT", "30")
+    out = bench.both_hosts(_args(), _line(2100.0, rccl_ranks=8))
+    assert calls == [] and out["host"] == "rccl" and out["value"] == 2100.0 and "second host skipped" in out["hosts"]["native_error"]
 
 
 def test_rccl_stays_when_it_is_faster_or_the_child_fails(monkeypatch):
     _fake_child(monkeypatch, stdout=json.dumps(_line(1500.0, host="native")))
     out = bench.both_hosts(_args(), _line(2100.0, rccl_ranks=8))
-    assert out["host"] == "rccl" and out["value"] == 2100.0 and out["hosts"]["native"]["value"] == 1500.0
+    assert out["host"] == "rccl" and out["value"] == 2100.0 and out["hosts"]["native"]["value"] == 1500.0 and out["faster_host"] == "rccl"
     _fake_child(monkeypatch, stdout="", returncode=1, stderr="hipErrorNoDevice")
     out = bench.both_hosts(_args(), _line(2100.0, rccl_ranks=8))
     assert out["host"] == "rccl" and out["hosts"]["native"] is None and "hipErrorNoDevice" in out["hosts"]["native_error"] and out["hosts_all_verified"] is False
