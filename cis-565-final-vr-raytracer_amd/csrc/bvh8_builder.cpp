@@ -8,6 +8,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -46,6 +47,9 @@ struct Builder2 {
   std::atomic<uint32_t> nodeCount{1};
   std::atomic<int> liveThreads{0};
   int maxThreads;
+  // (read per build, not once per process: the settings are part of rt_build_accel's cache key)
+  const int envNB = getenv("RESTIR_BVH_BINS") ? std::min(64, std::max(4, atoi(getenv("RESTIR_BVH_BINS")))) : 16;
+  const float leafSlotCost = getenv("RESTIR_BVH_SLOTCOST") ? float(atof(getenv("RESTIR_BVH_SLOTCOST"))) : 0.25f;  // measured: 0.25 beats 0.5 by 2 % on the Bistro-class scene, bins 16 vs 32 vs 64 make no difference
   Builder2(const std::vector<Prim>& p, std::vector<uint32_t>& i, int threads) : prims(p), idx(i), nodes(std::max<size_t>(2, 2 * p.size() + 2)), maxThreads(threads) {}
 
   void build(uint32_t node, uint32_t b, uint32_t e)
@@ -60,8 +64,6 @@ struct Builder2 {
       if(cnt <= 1) { makeLeaf(); return; }
       // binned SAH over the three axes
       constexpr int NBMAX = 64;
-      static const int envNB = getenv("RESTIR_BVH_BINS") ? std::min(NBMAX, std::max(4, atoi(getenv("RESTIR_BVH_BINS")))) : 16;
-      static const float leafSlotCost = getenv("RESTIR_BVH_SLOTCOST") ? float(atof(getenv("RESTIR_BVH_SLOTCOST"))) : 0.25f;  // measured: 0.25 beats 0.5 by 2 % on the Bistro-class scene, bins 16 vs 32 vs 64 make no difference
       const int NB = envNB;
       float best = 3e38f; int bestAxis = -1, bestBin = 0;
       for(int ax = 0; ax < 3; ax++) {
@@ -130,21 +132,58 @@ struct Builder2 {
 // a triangle twice changes neither; every point of a triangle lies in the (padded) box of at least one of its references.
 struct Ref { Box b; uint32_t tri; };   // b: UNPADDED bounds of the part of triangle `tri` this reference stands for
 
+// fixed-size chunks of [0, n) dealt to at most `threads` threads; f(chunk, begin, end).  The chunking never depends on the thread count, and every use below merges the
+// per-chunk results in chunk order (or with min / max / integer sums, which do not care), so what is built is a function of the input alone.
+template <class F> void parallelChunks(size_t n, size_t chunk, int threads, F f)
+{
+  const size_t nc = (n + chunk - 1) / chunk;
+  if(nc <= 1 || threads <= 1) { for(size_t c = 0; c < nc; c++) f(c, c * chunk, std::min(n, (c + 1) * chunk)); return; }
+  std::atomic<size_t> next{0};
+  auto work = [&] { for(;;) { const size_t c = next.fetch_add(1); if(c >= nc) return; f(c, c * chunk, std::min(n, (c + 1) * chunk)); } };
+  std::vector<std::thread> pool;
+  const int nt = int(std::min<size_t>(size_t(threads), nc));
+  for(int i = 1; i < nt; i++) pool.emplace_back(work);
+  work();
+  for(auto& t : pool) t.join();
+}
+
+// Round 6: the build is DETERMINISTIC — the same tree for any thread count and any run.  Until round 5 the threads drew node indices, leaf ranges and the reference
+// budget from shared atomics in whatever order they got there: the tree, its SAH figures and the frame time varied from run to run, and subtrees built late found the
+// budget spent (advisor finding; a race for the budget had already overrun `leafTris` once, commit 12d774f).  Now every subtree owns what it may use, handed down from
+// its parent: a share of the reference budget (what is left after the parent's own split, divided between the children in proportion to their reference counts) and,
+// derived from it, a range of node records and of leaf entries sized for the worst case (a subtree of r references and budget b has at most r + b leaves and
+// 2 (r + b) - 1 nodes).  Subtrees of more than SEQ_MAX references are cut this way and may be built by different threads; a subtree of at most SEQ_MAX references is
+// built by ONE thread, depth first, and inside it the budget is a pool again (what the left child leaves goes to the right one, records and leaf entries are taken
+// from the subtree's range in the order of the walk) — sequential, hence reproducible, and the budget does not strand in parts of the scene that need no splits (with
+// fixed shares all the way down only 7 k of the 33 k spatial splits of the round-5 tree were taken).  The ranges leave gaps in `nodes` / `leafTris` (unused records
+// stay marked as empty leaves); nothing is shared, nothing is atomic.
 struct BuilderS {
   const std::vector<Tri48>& flat;
   const float pad;
   std::vector<N2> nodes;
   std::vector<uint32_t> leafTris;
-  std::atomic<uint32_t> nodeCount{1}, leafCount{0};
-  std::atomic<int64_t> budget;           // references that may still be added
   std::atomic<int> liveThreads{0};
-  std::atomic<uint64_t> spatialSplits{0};
+  std::atomic<uint64_t> spatialSplits{0}, leafRefs{0};   // statistics (integer sums: the order of the additions does not matter)
+  int64_t rootBudget;
   int maxThreads;
   float rootArea = 1.f, alpha = 1e-5f;
   int NB = 16, NBS = 16;   // bins of the object / of the spatial split search
   float leafSlotCost = 0.25f;
+  bool areaRule = false;
+  // nodes with more than PAR_MIN references bin them in parallel, in chunks of PAR_CHUNK; subtrees of at most SEQ_MAX references: one thread, budget pooled (see above).
+  // (RESTIR_BVH_PAR_MIN / RESTIR_BVH_SEQ_MAX: test hooks — the sanitizer jobs of tests/test_bvh_quality.py reach every parallel path on a 50 k-triangle scene.  The
+  //  thresholds are part of the build's definition: another value is another, equally reproducible, tree.)
+  const size_t PAR_MIN = getenv("RESTIR_BVH_PAR_MIN") ? size_t(std::max(256, atoi(getenv("RESTIR_BVH_PAR_MIN")))) : size_t(1) << 18;
+  const size_t PAR_CHUNK = std::min<size_t>(size_t(1) << 16, std::max<size_t>(64, PAR_MIN / 4));
+  const size_t SEQ_MAX = getenv("RESTIR_BVH_SEQ_MAX") ? size_t(std::max(16, atoi(getenv("RESTIR_BVH_SEQ_MAX")))) : 100000;
+  struct Pool { int64_t budget; uint32_t nextNode, nextLeaf; };     // what a sequential subtree still owns
   BuilderS(const std::vector<Tri48>& f, float pad_, size_t n, double budgetFrac, int threads)
-    : flat(f), pad(pad_), nodes(2 * (n + size_t(double(n) * budgetFrac)) + 16), leafTris(n + size_t(double(n) * budgetFrac) + 16), budget(int64_t(double(n) * budgetFrac)), maxThreads(threads) {}
+    : flat(f), pad(pad_), rootBudget(int64_t(double(n) * budgetFrac)), maxThreads(threads)
+  {
+    N2 empty; empty.b.reset(); empty.a = 0; empty.n = 0; empty.leaf = true;
+    nodes.assign(2 * (n + size_t(rootBudget)) + 16, empty);
+    leafTris.assign(n + size_t(rootBudget) + 16, 0u);
+  }
 
   // bounds of (triangle t) AND box `cell` (closed), by clipping the polygon in double; false: empty
   bool clipBounds(uint32_t t, const Box& cell, Box& out) const
@@ -184,36 +223,95 @@ struct BuilderS {
     return true;
   }
 
-  void makeLeaf(N2& N, const std::vector<Ref>& refs)
+  void makeLeaf(N2& N, const std::vector<Ref>& refs, uint32_t leafBase)
   {
-    const uint32_t off = leafCount.fetch_add(uint32_t(refs.size()));
-    for(size_t k = 0; k < refs.size(); k++) leafTris[off + k] = refs[k].tri;
-    N.leaf = true; N.a = off; N.n = uint32_t(refs.size());
+    for(size_t k = 0; k < refs.size(); k++) leafTris[leafBase + k] = refs[k].tri;
+    N.leaf = true; N.a = leafBase; N.n = uint32_t(refs.size());
+    leafRefs += refs.size();
   }
 
-  void build(uint32_t node, std::vector<Ref> refs)
+  static constexpr int NBMAX = 64;
+  struct Bins {   // what one pass over (a chunk of) a node's references collects: object bins by centroid and spatial bins by clipped extent, for the three axes
+    Box ob[3][NBMAX]; uint32_t oc[3][NBMAX];
+    Box sb[3][NBMAX]; uint32_t en[3][NBMAX], ex[3][NBMAX];
+    void reset(int nb, int nbs) { for(int a = 0; a < 3; a++) { for(int i = 0; i < nb; i++) { ob[a][i].reset(); oc[a][i] = 0; } for(int i = 0; i < nbs; i++) { sb[a][i].reset(); en[a][i] = ex[a][i] = 0; } } }
+    void merge(const Bins& o, int nb, int nbs) { for(int a = 0; a < 3; a++) { for(int i = 0; i < nb; i++) { ob[a][i].grow(o.ob[a][i]); oc[a][i] += o.oc[a][i]; } for(int i = 0; i < nbs; i++) { sb[a][i].grow(o.sb[a][i]); en[a][i] += o.en[a][i]; ex[a][i] += o.ex[a][i]; } } }
+  };
+  void binRefs(const Ref* r, size_t count, const Box& nb, const Box& cb, bool spatial, Bins& B) const
   {
+    float k1o[3], k1s[3], w[3]; bool okO[3], okS[3];
+    for(int ax = 0; ax < 3; ax++) {
+      const float extO = cb.hi[ax] - cb.lo[ax], extS = nb.hi[ax] - nb.lo[ax];
+      okO[ax] = extO > 0; okS[ax] = spatial && extS > 0;
+      k1o[ax] = okO[ax] ? NB * (1.f - 1e-6f) / extO : 0.f;
+      k1s[ax] = okS[ax] ? NBS * (1.f - 1e-6f) / extS : 0.f; w[ax] = extS / NBS;
+    }
+    for(size_t q = 0; q < count; q++) {
+      const Ref& R = r[q];
+      for(int ax = 0; ax < 3; ax++) {
+        if(okO[ax]) {
+          const int bi = std::min(NB - 1, std::max(0, int((0.5f * (R.b.lo[ax] + R.b.hi[ax]) - cb.lo[ax]) * k1o[ax])));
+          B.ob[ax][bi].grow(R.b); B.oc[ax][bi]++;
+        }
+        if(okS[ax]) {
+          const float lo = nb.lo[ax];
+          const int b0 = std::min(NBS - 1, std::max(0, int((R.b.lo[ax] - lo) * k1s[ax]))), b1 = std::min(NBS - 1, std::max(b0, int((R.b.hi[ax] - lo) * k1s[ax])));
+          B.en[ax][b0]++; B.ex[ax][b1]++;
+          if(b0 == b1) { B.sb[ax][b0].grow(R.b); continue; }
+          for(int bi = b0; bi <= b1; bi++) {
+            Box cell = R.b, part;
+            cell.lo[ax] = std::max(cell.lo[ax], lo + w[ax] * float(bi)); cell.hi[ax] = std::min(cell.hi[ax], bi == NBS - 1 ? nb.hi[ax] : lo + w[ax] * float(bi + 1));
+            if(cell.lo[ax] <= cell.hi[ax] && clipBounds(R.tri, cell, part)) B.sb[ax][bi].grow(part);
+          }
+        }
+      }
+    }
+  }
+
+  // subtree of `refs` rooted at record `node`; its descendants use the records [nodeBase, nodeBase + 2 (|refs| + budget) - 2), its leaves the entries
+  // [leafBase, leafBase + |refs| + budget)
+  void build(uint32_t node, std::vector<Ref> refs, int64_t budget, uint32_t nodeBase, uint32_t leafBase, Pool* pool = nullptr)
+  {
+    Pool own;
     for(;;) {
       N2& N = nodes[node];
+      const uint32_t cnt = uint32_t(refs.size());
+      if(!pool && cnt <= SEQ_MAX) { own.budget = budget; own.nextNode = nodeBase; own.nextLeaf = leafBase; pool = &own; }   // from here down: one thread, pooled budget
+      if(pool) budget = pool->budget;
+      const int par = cnt >= PAR_MIN ? std::max(1, maxThreads) : 1;
       Box nb, cb; nb.reset(); cb.reset();
-      for(const Ref& r : refs) { nb.grow(r.b); const float c[3] = {0.5f * (r.b.lo[0] + r.b.hi[0]), 0.5f * (r.b.lo[1] + r.b.hi[1]), 0.5f * (r.b.lo[2] + r.b.hi[2])}; cb.grow(c); }
+      if(par > 1) {
+        const size_t nch = (cnt + PAR_CHUNK - 1) / PAR_CHUNK;
+        std::vector<Box> pn(nch), pc(nch);
+        parallelChunks(cnt, PAR_CHUNK, par, [&](size_t c, size_t b, size_t e) {
+          Box x, y; x.reset(); y.reset();
+          for(size_t k = b; k < e; k++) { const Ref& r = refs[k]; x.grow(r.b); const float ce[3] = {0.5f * (r.b.lo[0] + r.b.hi[0]), 0.5f * (r.b.lo[1] + r.b.hi[1]), 0.5f * (r.b.lo[2] + r.b.hi[2])}; y.grow(ce); }
+          pn[c] = x; pc[c] = y;
+        });
+        for(size_t c = 0; c < nch; c++) { nb.grow(pn[c]); cb.grow(pc[c]); }
+      } else
+        for(const Ref& r : refs) { nb.grow(r.b); const float c[3] = {0.5f * (r.b.lo[0] + r.b.hi[0]), 0.5f * (r.b.lo[1] + r.b.hi[1]), 0.5f * (r.b.lo[2] + r.b.hi[2])}; cb.grow(c); }
       N.b = nb;
       for(int a = 0; a < 3; a++) { N.b.lo[a] -= pad; N.b.hi[a] += pad; }
-      const uint32_t cnt = uint32_t(refs.size());
-      if(cnt <= 1) { makeLeaf(N, refs); return; }
-      constexpr int NBMAX = 64;
-      // ---- object split: binned SAH on the reference centroids (the rule of Builder2) ----
+      auto leafHere = [&] { if(pool) { makeLeaf(N, refs, pool->nextLeaf); pool->nextLeaf += cnt; } else makeLeaf(N, refs, leafBase); };
+      if(cnt <= 1) { leafHere(); return; }
+      // ---- one pass over the references: object bins on the centroids (the rule of Builder2) and, while references may be added, spatial bins ----
+      const bool mayAdd = budget > 0;
+      std::unique_ptr<Bins> binsHeap(new Bins);
+      Bins& B = *binsHeap;
+      B.reset(NB, NBS);
+      if(par > 1) {
+        const size_t nch = (cnt + PAR_CHUNK - 1) / PAR_CHUNK;
+        std::vector<std::unique_ptr<Bins>> part(nch);
+        parallelChunks(cnt, PAR_CHUNK, par, [&](size_t c, size_t b, size_t e) { part[c].reset(new Bins); part[c]->reset(NB, NBS); binRefs(refs.data() + b, e - b, nb, cb, mayAdd, *part[c]); });
+        for(size_t c = 0; c < nch; c++) B.merge(*part[c], NB, NBS);
+      } else binRefs(refs.data(), cnt, nb, cb, mayAdd, B);
+      // ---- object split ----
       float best = 3e38f; int bestAxis = -1, bestBin = 0; Box bestL, bestR;
       for(int ax = 0; ax < 3; ax++) {
         const float ext = cb.hi[ax] - cb.lo[ax];
         if(!(ext > 0)) continue;
-        Box bb[NBMAX]; uint32_t bc[NBMAX];
-        for(int i = 0; i < NB; i++) { bb[i].reset(); bc[i] = 0; }
-        const float k1 = NB * (1.f - 1e-6f) / ext;
-        for(const Ref& r : refs) {
-          const int bi = std::min(NB - 1, std::max(0, int((0.5f * (r.b.lo[ax] + r.b.hi[ax]) - cb.lo[ax]) * k1)));
-          bb[bi].grow(r.b); bc[bi]++;
-        }
+        const Box* bb = B.ob[ax]; const uint32_t* bc = B.oc[ax];
         Box rb[NBMAX]; uint32_t rc[NBMAX];
         Box acc; acc.reset(); uint32_t c = 0;
         for(int i = NB - 1; i > 0; i--) { acc.grow(bb[i]); c += bc[i]; rb[i] = acc; rc[i] = c; }
@@ -228,7 +326,7 @@ struct BuilderS {
       const float pa = std::max(nb.area(), 1e-30f);
       // ---- spatial split: only where the object split leaves its children overlapping (Stich et al., 4.5), and while references may be added ----
       float sBest = 3e38f; int sAxis = -1; float sPlane = 0.f; uint32_t sNL = 0, sNR = 0; Box sL, sR;
-      bool trySpatial = cnt >= 2 && budget.load(std::memory_order_relaxed) > 0;
+      bool trySpatial = cnt >= 2 && mayAdd;
       if(trySpatial && bestAxis >= 0) {
         Box ov;
         for(int a = 0; a < 3; a++) { ov.lo[a] = std::max(bestL.lo[a], bestR.lo[a]); ov.hi[a] = std::min(bestL.hi[a], bestR.hi[a]); }
@@ -238,19 +336,8 @@ struct BuilderS {
         for(int ax = 0; ax < 3; ax++) {
           const float lo = nb.lo[ax], ext = nb.hi[ax] - nb.lo[ax];
           if(!(ext > 0)) continue;
-          Box bb[NBMAX]; uint32_t en[NBMAX], exx[NBMAX];
-          for(int i = 0; i < NBS; i++) { bb[i].reset(); en[i] = exx[i] = 0; }
-          const float k1 = NBS * (1.f - 1e-6f) / ext, w = ext / NBS;
-          for(const Ref& r : refs) {
-            const int b0 = std::min(NBS - 1, std::max(0, int((r.b.lo[ax] - lo) * k1))), b1 = std::min(NBS - 1, std::max(b0, int((r.b.hi[ax] - lo) * k1)));
-            en[b0]++; exx[b1]++;
-            if(b0 == b1) { bb[b0].grow(r.b); continue; }
-            for(int bi = b0; bi <= b1; bi++) {
-              Box cell = r.b, part;
-              cell.lo[ax] = std::max(cell.lo[ax], lo + w * float(bi)); cell.hi[ax] = std::min(cell.hi[ax], bi == NBS - 1 ? nb.hi[ax] : lo + w * float(bi + 1));
-              if(cell.lo[ax] <= cell.hi[ax] && clipBounds(r.tri, cell, part)) bb[bi].grow(part);
-            }
-          }
+          const Box* bb = B.sb[ax]; const uint32_t* en = B.en[ax]; const uint32_t* exx = B.ex[ax];
+          const float w = ext / NBS;
           Box rb[NBMAX]; uint32_t rc[NBMAX];
           Box acc; acc.reset(); uint32_t c = 0;
           for(int i = NBS - 1; i > 0; i--) { acc.grow(bb[i]); c += exx[i]; rb[i] = acc; rc[i] = c; }
@@ -263,10 +350,10 @@ struct BuilderS {
           }
         }
       }
-      const bool spatial = sAxis >= 0 && sBest < best && int64_t(sNL + sNR) - int64_t(cnt) <= budget.load(std::memory_order_relaxed);
+      const bool spatial = sAxis >= 0 && sBest < best && int64_t(sNL + sNR) - int64_t(cnt) <= budget;
       const float chosen = spatial ? sBest : best;
       if(cnt <= 3) {
-        if((bestAxis < 0 && !spatial) || leafSlotCost * pa + chosen >= float(cnt) * pa) { makeLeaf(N, refs); return; }
+        if((bestAxis < 0 && !spatial) || leafSlotCost * pa + chosen >= float(cnt) * pa) { leafHere(); return; }
       }
       std::vector<Ref> left, right;
       if(spatial) {
@@ -288,14 +375,9 @@ struct BuilderS {
           else if(cRight < cSplit && nl > 1) { right.push_back(r); R = Rw; nl--; }
           else { Ref a = r, b = r; a.b = pl; b.b = pr; left.push_back(a); right.push_back(b); }
         }
-        if(left.empty() || right.empty() || left.size() >= cnt || right.size() >= cnt) { left.clear(); right.clear(); }   // no progress: the object split below
-        else {
-          // the references this split adds are RESERVED: the subtrees are built by several threads and the check above read a budget another thread may have spent
-          // since (leafTris is sized for triangles + budget: an overdraft would write past it)
-          const int64_t added = int64_t(left.size() + right.size()) - int64_t(cnt);
-          if(added > 0 && budget.fetch_sub(added) < added) { budget.fetch_add(added); left.clear(); right.clear(); }
-          else spatialSplits++;
-        }
+        // no progress, or more references than this subtree may add (cannot happen: the unsplitting rule only lowers the binned estimate checked above): the object split
+        if(left.empty() || right.empty() || left.size() >= cnt || right.size() >= cnt || int64_t(left.size() + right.size()) - int64_t(cnt) > budget) { left.clear(); right.clear(); }
+        else spatialSplits++;
       }
       if(left.empty()) {
         if(bestAxis >= 0) {
@@ -310,17 +392,33 @@ struct BuilderS {
         }
       }
       std::vector<Ref>().swap(refs);
-      const uint32_t child = nodeCount.fetch_add(2);
+      const int64_t rest = budget - (int64_t(left.size() + right.size()) - int64_t(cnt));
+      if(pool) {   // sequential subtree: the two child records from the pool, the left child first; what it leaves of the budget is the right child's
+        pool->budget = rest;
+        const uint32_t child = pool->nextNode; pool->nextNode += 2;
+        N.leaf = false; N.a = child; N.n = 0;
+        build(child, std::move(left), 0, 0u, 0u, pool);
+        node = child + 1; refs = std::move(right);
+        continue;
+      }
+      // what this split did not use of the subtree's budget goes to the children in proportion to their reference counts; their record / leaf ranges follow from it
+      // (RESTIR_BVH_BUDGET_RULE=area weighs a child's count with the area of its references' bounds: measured against the count rule in profiles/r06_bvh_build.txt)
+      double wl = double(left.size()), wr = double(right.size());
+      if(areaRule) { Box bL, bR; bL.reset(); bR.reset(); for(const Ref& r : left) bL.grow(r.b); for(const Ref& r : right) bR.grow(r.b); wl *= double(bL.area()) + 1e-30; wr *= double(bR.area()) + 1e-30; }
+      const int64_t bl = std::min<int64_t>(rest, std::max<int64_t>(0, int64_t(double(rest) * (wl / (wl + wr))))), br = rest - bl;
+      const uint32_t child = nodeBase;
+      const uint32_t lNodes = uint32_t(2 * (int64_t(left.size()) + bl) - 2), lLeaves = uint32_t(int64_t(left.size()) + bl);
       N.leaf = false; N.a = child; N.n = 0;
-      if(left.size() + right.size() > 100000 && liveThreads.load() < maxThreads) {
+      const uint32_t lBase = nodeBase + 2, rBase = nodeBase + 2 + lNodes, lLeaf = leafBase, rLeaf = leafBase + lLeaves;
+      if(liveThreads.load() < maxThreads) {
         liveThreads++;
-        std::thread th([this, child, l = std::move(left)]() mutable { build(child, std::move(l)); liveThreads--; });
-        build(child + 1, std::move(right));
+        std::thread th([this, child, bl, lBase, lLeaf, l = std::move(left)]() mutable { build(child, std::move(l), bl, lBase, lLeaf); liveThreads--; });
+        build(child + 1, std::move(right), br, rBase, rLeaf);
         th.join();
         return;
       }
-      build(child, std::move(left));
-      node = child + 1; refs = std::move(right);
+      build(child, std::move(left), bl, lBase, lLeaf);
+      node = child + 1; refs = std::move(right); budget = br; nodeBase = rBase; leafBase = rLeaf;
     }
   }
 };
@@ -330,57 +428,86 @@ struct BuilderS {
 // loses / gains a subtree; the exchange with the largest area reduction is applied.  Children are adjacent records (a, a + 1) and a record carries its
 // subtree by index, so an exchange is a swap of two records.  RESTIR_BVH_ROTATE = number of passes (0 = off).
 inline Box unite(const Box& x, const Box& y) { Box r = x; r.grow(y); return r; }
-uint64_t rotatePass(std::vector<N2>& N, uint32_t count, bool gg)
+// the best exchange at internal record n, applied; false: none improves
+inline bool rotateAt(std::vector<N2>& N, uint32_t n, bool gg)
 {
-  uint64_t applied = 0;
-  for(uint32_t n = count; n-- > 0;) {   // children have larger indices than their parent: reverse index order is bottom-up
-    N2& P = N[n];
-    if(P.leaf) continue;
-    const uint32_t L = P.a, R = P.a + 1;
-    float best = 0.f; int which = -1;
-    if(!N[R].leaf) {
-      const uint32_t RL = N[R].a, RR = N[R].a + 1;
-      const float base = N[R].b.area();
-      const float d0 = unite(N[L].b, N[RR].b).area() - base;   // L <-> RL
-      const float d1 = unite(N[RL].b, N[L].b).area() - base;   // L <-> RR
-      if(d0 < best) { best = d0; which = 0; }
-      if(d1 < best) { best = d1; which = 1; }
-    }
-    if(!N[L].leaf) {
-      const uint32_t LL = N[L].a, LR = N[L].a + 1;
-      const float base = N[L].b.area();
-      const float d2 = unite(N[R].b, N[LR].b).area() - base;   // R <-> LL
-      const float d3 = unite(N[LL].b, N[R].b).area() - base;   // R <-> LR
-      if(d2 < best) { best = d2; which = 2; }
-      if(d3 < best) { best = d3; which = 3; }
-    }
-    if(gg && !N[L].leaf && !N[R].leaf) {   // grandchild <-> grandchild across the two children: both child boxes change (LL <-> RL, LL <-> RR; the other two are mirror images)
-      const uint32_t LL = N[L].a, LR = N[L].a + 1, RL = N[R].a, RR = N[R].a + 1;
-      const float base = N[L].b.area() + N[R].b.area();
-      const float d4 = unite(N[RL].b, N[LR].b).area() + unite(N[LL].b, N[RR].b).area() - base;   // LL <-> RL
-      const float d5 = unite(N[RR].b, N[LR].b).area() + unite(N[RL].b, N[LL].b).area() - base;   // LL <-> RR
-      if(d4 < best) { best = d4; which = 4; }
-      if(d5 < best) { best = d5; which = 5; }
-      (void)LL;
-    }
-    if(which < 0) continue;
-    if(which >= 4) {
-      const uint32_t LL = N[L].a, g = N[R].a + uint32_t(which - 4);
-      std::swap(N[LL], N[g]);
-      N[L].b = unite(N[N[L].a].b, N[N[L].a + 1].b);
-      N[R].b = unite(N[N[R].a].b, N[N[R].a + 1].b);
-    } else if(which < 2) {
-      const uint32_t g = N[R].a + uint32_t(which);
-      std::swap(N[L], N[g]);
-      N[R].b = unite(N[N[R].a].b, N[N[R].a + 1].b);
-    } else {
-      const uint32_t g = N[L].a + uint32_t(which - 2);
-      std::swap(N[R], N[g]);
-      N[L].b = unite(N[N[L].a].b, N[N[L].a + 1].b);
-    }
-    applied++;
+  N2& P = N[n];
+  if(P.leaf) return false;
+  const uint32_t L = P.a, R = P.a + 1;
+  float best = 0.f; int which = -1;
+  if(!N[R].leaf) {
+    const uint32_t RL = N[R].a, RR = N[R].a + 1;
+    const float base = N[R].b.area();
+    const float d0 = unite(N[L].b, N[RR].b).area() - base;   // L <-> RL
+    const float d1 = unite(N[RL].b, N[L].b).area() - base;   // L <-> RR
+    if(d0 < best) { best = d0; which = 0; }
+    if(d1 < best) { best = d1; which = 1; }
   }
-  return applied;
+  if(!N[L].leaf) {
+    const uint32_t LL = N[L].a, LR = N[L].a + 1;
+    const float base = N[L].b.area();
+    const float d2 = unite(N[R].b, N[LR].b).area() - base;   // R <-> LL
+    const float d3 = unite(N[LL].b, N[R].b).area() - base;   // R <-> LR
+    if(d2 < best) { best = d2; which = 2; }
+    if(d3 < best) { best = d3; which = 3; }
+  }
+  if(gg && !N[L].leaf && !N[R].leaf) {   // grandchild <-> grandchild across the two children: both child boxes change (LL <-> RL, LL <-> RR; the other two are mirror images)
+    const uint32_t LL = N[L].a, LR = N[L].a + 1, RL = N[R].a, RR = N[R].a + 1;
+    const float base = N[L].b.area() + N[R].b.area();
+    const float d4 = unite(N[RL].b, N[LR].b).area() + unite(N[LL].b, N[RR].b).area() - base;   // LL <-> RL
+    const float d5 = unite(N[RR].b, N[LR].b).area() + unite(N[RL].b, N[LL].b).area() - base;   // LL <-> RR
+    if(d4 < best) { best = d4; which = 4; }
+    if(d5 < best) { best = d5; which = 5; }
+  }
+  if(which < 0) return false;
+  if(which >= 4) {
+    const uint32_t LL = N[L].a, g = N[R].a + uint32_t(which - 4);
+    std::swap(N[LL], N[g]);
+    N[L].b = unite(N[N[L].a].b, N[N[L].a + 1].b);
+    N[R].b = unite(N[N[R].a].b, N[N[R].a + 1].b);
+  } else if(which < 2) {
+    const uint32_t g = N[R].a + uint32_t(which);
+    std::swap(N[L], N[g]);
+    N[R].b = unite(N[N[R].a].b, N[N[R].a + 1].b);
+  } else {
+    const uint32_t g = N[L].a + uint32_t(which - 2);
+    std::swap(N[R], N[g]);
+    N[L].b = unite(N[N[L].a].b, N[N[L].a + 1].b);
+  }
+  return true;
+}
+// One bottom-up pass.  The order comes from the TREE — reverse pre-order: every record after all of its descendants — not from the record indices: "children have
+// larger indices than their parent" stops being true with the first exchange (a record carries its subtree by index, the one moved up keeps children with smaller
+// indices; advisor finding of round 5) and never held for the ranges the deterministic builder hands out.  An exchange at n only permutes records INSIDE n's subtree, all
+// of which the pass has already visited, so the order taken at the start of the pass stays bottom-up.  Parallel (round 6): the tree is cut ROT_CUT levels below the
+// root; the subtrees under the cut are independent — one task each — and the few records above it follow serially.  Which thread runs a subtree changes nothing in it:
+// the result is the sequential pass's, for any thread count.
+uint64_t rotatePass(std::vector<N2>& N, bool gg, int threads)
+{
+  constexpr int ROT_CUT = 9;   // up to 512 subtrees
+  std::vector<uint32_t> top, roots;
+  {
+    std::vector<std::pair<uint32_t, int>> st; st.push_back({0u, 0});
+    while(!st.empty()) {
+      const auto [q, d] = st.back(); st.pop_back();
+      if(N[q].leaf) continue;
+      if(d == ROT_CUT) { roots.push_back(q); continue; }
+      top.push_back(q);   // pre-order
+      st.push_back({N[q].a + 1, d + 1}); st.push_back({N[q].a, d + 1});
+    }
+  }
+  std::vector<uint64_t> applied(roots.size(), 0);
+  parallelChunks(roots.size(), 1, threads, [&](size_t c, size_t, size_t) {
+    std::vector<uint32_t> pre, st2; st2.push_back(roots[c]);
+    while(!st2.empty()) { const uint32_t q = st2.back(); st2.pop_back(); if(N[q].leaf) continue; pre.push_back(q); st2.push_back(N[q].a); st2.push_back(N[q].a + 1); }
+    uint64_t k = 0;
+    for(size_t i = pre.size(); i-- > 0;) k += rotateAt(N, pre[i], gg) ? 1 : 0;
+    applied[c] = k;
+  });
+  uint64_t total = 0;
+  for(uint64_t k : applied) total += k;
+  for(size_t i = top.size(); i-- > 0;) total += rotateAt(N, top[i], gg) ? 1 : 0;
+  return total;
 }
 
 // ---- insertion-based optimisation of the finished BVH2 (after Bittner, Hapala, Havran, "Fast Insertion-Based Optimization of Bounding Volume Hierarchies",
@@ -496,17 +623,36 @@ static void inverseAffine(const float* M, float* R, float* detOut)
   R[11] = -((R[8] * tx + R[9] * ty) + R[10] * tz);
 }
 
-bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads)
+namespace {
+// RESTIR_BVH_TIMING=1: seconds per phase of the build on stderr (round 6: where the 4.6 s of the headline scene went)
+struct PhaseTimer {
+  const bool on = getenv("RESTIR_BVH_TIMING") && atoi(getenv("RESTIR_BVH_TIMING")) != 0;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(const char* what)
+  {
+    if(!on) return;
+    const auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[bvh8 build] %-28s %.3f s\n", what, std::chrono::duration<double>(n - t).count());
+    t = n;
+  }
+};
+}  // namespace
+
+bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads, bool plainTree)
 {
+  PhaseTimer timer;
   // ---- 1. flatten: one world-space triangle per (instance, primitive); globalId = running index ------------
   out.instances.resize(sc.numInstances);
   size_t total = 0;
   for(uint32_t i = 0; i < sc.numInstances; i++) total += sc.primMeshes[sc.instances[i].primMesh].indexCount / 3;
   std::vector<Tri48> flat(total);
   out.triRef.resize(total);
-  size_t g = 0;
-  float scale = 1e-3f;
-  for(uint32_t i = 0; i < sc.numInstances; i++) {
+  // (round 6: instances in parallel — a task per instance, its first record from a prefix sum; the largest |coordinate| is a maximum: any order gives the same value)
+  std::vector<size_t> first(size_t(sc.numInstances) + 1, 0);
+  for(uint32_t i = 0; i < sc.numInstances; i++) first[i + 1] = first[i] + sc.primMeshes[sc.instances[i].primMesh].indexCount / 3;
+  std::vector<float> scaleOf(sc.numInstances, 0.f);
+  parallelChunks(sc.numInstances, 1, std::max(1, threads), [&](size_t ii, size_t, size_t) {
+    const uint32_t i = uint32_t(ii);
     const rt_instance& in = sc.instances[i];
     DevInstance& di = out.instances[i];
     memcpy(di.o2w, in.objectToWorld, sizeof(di.o2w));
@@ -518,13 +664,15 @@ bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads)
     if(in.flags & RT_INST_CULL_DISABLE) f |= TRI_NOCULL;
     if(det < 0.0f) f |= TRI_FLIP;
     const rt_prim_mesh& pm = sc.primMeshes[in.primMesh];
+    float sm = 0.f;
+    size_t g = first[i];
     for(uint32_t p = 0; p < pm.indexCount / 3; p++, g++) {
       const uint32_t* ix = &sc.indices[pm.firstIndex + 3 * p];
       float w[3][3];
       for(int k = 0; k < 3; k++) {
         const rt_vec3& q = sc.vertices[pm.vertexOffset + ix[k]].position;
         xformPointRaw(di.o2w, q.x, q.y, q.z, w[k]);
-        for(int a = 0; a < 3; a++) scale = std::max(scale, std::fabs(w[k][a]));
+        for(int a = 0; a < 3; a++) sm = std::max(sm, std::fabs(w[k][a]));
       }
       Tri48& T = flat[g];
       T.v0x = w[0][0]; T.v0y = w[0][1]; T.v0z = w[0][2];
@@ -533,7 +681,11 @@ bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads)
       T.globalId = uint32_t(g); T.flags = f; T.alphaIdx = 0; T.omm[0] = T.omm[1] = T.omm[2] = T.omm[3] = 0;
       out.triRef[g] = TriRef{i, p};
     }
-  }
+    scaleOf[i] = sm;
+  });
+  float scale = 1e-3f;
+  for(float v : scaleOf) scale = std::max(scale, v);
+  timer.lap("flatten");
   const size_t n = total;
   out.nodes.clear(); out.tris.clear(); out.maxDepth = 0; out.sahNodeSteps = out.sahTriSteps = out.sahNodeStepsQ = out.sahTriStepsQ = 0; out.references = 0; out.spatialSplits = 0; out.rotations = 0; out.reinsertions = 0;
   if(n == 0) {  // a single empty node keeps the kernels branch-free
@@ -545,52 +697,80 @@ bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads)
   out.pad = pad;
 
   // ---- 2. padded triangle boxes + binned-SAH BVH2 ---------------------------------------------------------------
-  std::vector<Prim> prims(n);
-  for(size_t i = 0; i < n; i++) {
-    const Tri48& T = flat[i];
-    const float v[3][3] = {{T.v0x, T.v0y, T.v0z}, {T.v0x + T.e1x, T.v0y + T.e1y, T.v0z + T.e1z}, {T.v0x + T.e2x, T.v0y + T.e2y, T.v0z + T.e2z}};
-    Prim& P = prims[i];
-    P.b.reset();
-    for(int k = 0; k < 3; k++) P.b.grow(v[k]);
-    // e1/e2 were rounded when stored: v0+e1 may differ from v1 by an ulp; the pad (>= 300 ulp) absorbs it
-    for(int a = 0; a < 3; a++) { P.b.lo[a] -= pad; P.b.hi[a] += pad; P.c[a] = 0.5f * (P.b.lo[a] + P.b.hi[a]); }
-  }
-  std::vector<uint32_t> idx(n);
-  for(size_t i = 0; i < n; i++) idx[i] = uint32_t(i);
   // RESTIR_BVH_SPLIT: 0 = object splits only (the tree of rounds 1-4), 1 = spatial splits (BuilderS); RESTIR_BVH_SPLIT_BUDGET: added references / triangles
-  const int splitMode = getenv("RESTIR_BVH_SPLIT") ? atoi(getenv("RESTIR_BVH_SPLIT")) : RT_BVH_SPLIT_DEFAULT;
-  const double splitBudget = getenv("RESTIR_BVH_SPLIT_BUDGET") ? std::max(0.0, std::min(2.0, atof(getenv("RESTIR_BVH_SPLIT_BUDGET")))) : 0.3;
-  const float splitAlpha = getenv("RESTIR_BVH_SPLIT_ALPHA") ? float(atof(getenv("RESTIR_BVH_SPLIT_ALPHA"))) : 1e-5f;
-  Builder2 B2(prims, idx, std::max(1, threads));
-  std::unique_ptr<BuilderS> BS;
-  uint32_t n2count = 0;
-  if(splitMode > 0 && n > 1) {
-    BS.reset(new BuilderS(flat, pad, n, splitBudget, std::max(1, threads)));
-    std::vector<Ref> refs(n);
-    Box root; root.reset();
-    for(size_t i = 0; i < n; i++) {
+  const int splitMode = plainTree ? 0 : (getenv("RESTIR_BVH_SPLIT") ? atoi(getenv("RESTIR_BVH_SPLIT")) : RT_BVH_SPLIT_DEFAULT);
+  const bool useSplits = splitMode > 0 && n > 1;
+  std::vector<Prim> prims(useSplits ? 0 : n);   // (the padded boxes + centroids are the object-split builder's input; the spatial-split builder works on references)
+  std::vector<uint32_t> idx(useSplits ? 0 : n);
+  if(!useSplits) parallelChunks(n, size_t(1) << 16, std::max(1, threads), [&](size_t, size_t b0, size_t e0) {
+    for(size_t i = b0; i < e0; i++) {
       const Tri48& T = flat[i];
       const float v[3][3] = {{T.v0x, T.v0y, T.v0z}, {T.v0x + T.e1x, T.v0y + T.e1y, T.v0z + T.e1z}, {T.v0x + T.e2x, T.v0y + T.e2y, T.v0z + T.e2z}};
-      refs[i].tri = uint32_t(i); refs[i].b.reset();
-      for(int k = 0; k < 3; k++) refs[i].b.grow(v[k]);   // the UNPADDED bounds (the same expressions as the padded boxes above)
-      root.grow(refs[i].b);
+      Prim& P = prims[i];
+      P.b.reset();
+      for(int k = 0; k < 3; k++) P.b.grow(v[k]);
+      // e1/e2 were rounded when stored: v0+e1 may differ from v1 by an ulp; the pad (>= 300 ulp) absorbs it
+      for(int a = 0; a < 3; a++) { P.b.lo[a] -= pad; P.b.hi[a] += pad; P.c[a] = 0.5f * (P.b.lo[a] + P.b.hi[a]); }
+      idx[i] = uint32_t(i);
     }
-    BS->rootArea = std::max(root.area(), 1e-30f); BS->alpha = splitAlpha;
-    BS->NB = getenv("RESTIR_BVH_BINS") ? std::min(64, std::max(4, atoi(getenv("RESTIR_BVH_BINS")))) : 16;
-    BS->NBS = getenv("RESTIR_BVH_SBINS") ? std::min(64, std::max(4, atoi(getenv("RESTIR_BVH_SBINS")))) : 16;
-    BS->leafSlotCost = getenv("RESTIR_BVH_SLOTCOST") ? float(atof(getenv("RESTIR_BVH_SLOTCOST"))) : 0.25f;
-    BS->build(0, std::move(refs));
-    n2count = BS->nodeCount.load();
-    out.references = BS->leafCount.load(); out.spatialSplits = BS->spatialSplits.load();
+  });
+  timer.lap("triangle boxes");
+  const double splitBudget = getenv("RESTIR_BVH_SPLIT_BUDGET") ? std::max(0.0, std::min(2.0, atof(getenv("RESTIR_BVH_SPLIT_BUDGET")))) : 0.3;
+  const float splitAlpha = getenv("RESTIR_BVH_SPLIT_ALPHA") ? float(atof(getenv("RESTIR_BVH_SPLIT_ALPHA"))) : 1e-5f;
+  std::unique_ptr<Builder2> B2;   // (built only when it builds the tree: its constructor allocates 2 n records — advisor finding of round 5)
+  std::unique_ptr<BuilderS> BS;
+  uint32_t n2count = 0;
+  if(useSplits) {
+    // The budget is a cap on the TOTAL of added references.  Shares of exactly that total strand most of it in parts of the scene that need no splits (see
+    // BuilderS), so the build first runs with shares of a generous working budget (every subtree may double its references): on the benchmark scenes the overlap
+    // criterion (alpha) then decides alone — 0.26 n added references on the real exterior scene, the tree of round 5 — and the total stays under the cap.  Only when it
+    // does not is the build redone with shares of the cap itself, which bound the total by construction.  Both attempts are deterministic.
+    const size_t RCH = size_t(1) << 16;
+    Box root; root.reset();
+    std::vector<Ref> refs0(n);
+    {
+      std::vector<Box> rootOf((n + RCH - 1) / RCH);
+      parallelChunks(n, RCH, std::max(1, threads), [&](size_t c, size_t b0, size_t e0) {
+        Box rb; rb.reset();
+        for(size_t i = b0; i < e0; i++) {
+          const Tri48& T = flat[i];
+          const float v[3][3] = {{T.v0x, T.v0y, T.v0z}, {T.v0x + T.e1x, T.v0y + T.e1y, T.v0z + T.e1z}, {T.v0x + T.e2x, T.v0y + T.e2y, T.v0z + T.e2z}};
+          refs0[i].tri = uint32_t(i); refs0[i].b.reset();
+          for(int k = 0; k < 3; k++) refs0[i].b.grow(v[k]);   // the UNPADDED bounds (the same expressions as the padded boxes of the object-split builder)
+          rb.grow(refs0[i].b);
+        }
+        rootOf[c] = rb;
+      });
+      for(const Box& b : rootOf) root.grow(b);
+    }
+    const double workBudget = getenv("RESTIR_BVH_SPLIT_WORK") ? std::max(0.0, atof(getenv("RESTIR_BVH_SPLIT_WORK"))) : 1.0;
+    for(int attempt = 0; attempt < 2; attempt++) {
+      const bool strict = attempt == 1 || workBudget <= splitBudget;
+      BS.reset();   // (release the first attempt's arrays before the second one allocates)
+      BS.reset(new BuilderS(flat, pad, n, strict ? splitBudget : workBudget, std::max(1, threads)));
+      std::vector<Ref> refs = refs0;
+      if(strict) std::vector<Ref>().swap(refs0);
+      BS->rootArea = std::max(root.area(), 1e-30f); BS->alpha = splitAlpha;
+      BS->NB = getenv("RESTIR_BVH_BINS") ? std::min(64, std::max(4, atoi(getenv("RESTIR_BVH_BINS")))) : 16;
+      BS->NBS = getenv("RESTIR_BVH_SBINS") ? std::min(64, std::max(4, atoi(getenv("RESTIR_BVH_SBINS")))) : 16;
+      BS->leafSlotCost = getenv("RESTIR_BVH_SLOTCOST") ? float(atof(getenv("RESTIR_BVH_SLOTCOST"))) : 0.25f;
+      BS->areaRule = getenv("RESTIR_BVH_BUDGET_RULE") && strcmp(getenv("RESTIR_BVH_BUDGET_RULE"), "area") == 0;
+      BS->build(0, std::move(refs), BS->rootBudget, 1u, 0u);
+      n2count = uint32_t(BS->nodes.size());   // (record ranges are handed out per subtree: the records in use are not contiguous)
+      out.references = BS->leafRefs.load(); out.spatialSplits = BS->spatialSplits.load();
+      if(strict || double(out.references - n) <= double(n) * splitBudget) break;
+    }
   } else {
-    B2.build(0, 0, uint32_t(n));
-    n2count = B2.nodeCount.load();
+    B2.reset(new Builder2(prims, idx, std::max(1, threads)));
+    B2->build(0, 0, uint32_t(n));
+    n2count = B2->nodeCount.load();
     out.references = n; out.spatialSplits = 0;
   }
+  timer.lap("BVH2 (splits)");
   {
-    const bool dp = false;   // (the SAH-optimal collapse takes its bottom-up order from the tree itself since round 5: the passes below may run before it)
+    const bool dp = plainTree;   // (plain tree: no quality passes.  The SAH-optimal collapse takes its bottom-up order from the tree itself since round 5, so the passes may run before it)
     const int rotate = dp ? 0 : (getenv("RESTIR_BVH_ROTATE") ? atoi(getenv("RESTIR_BVH_ROTATE")) : RT_BVH_ROTATE_DEFAULT);
-    std::vector<N2>& M = BS ? BS->nodes : B2.nodes;
+    std::vector<N2>& M = BS ? BS->nodes : B2->nodes;
     const bool rotateGG = getenv("RESTIR_BVH_ROTATE_GG") && atoi(getenv("RESTIR_BVH_ROTATE_GG")) != 0;
     const int reins = dp ? 0 : (getenv("RESTIR_BVH_REINSERT") ? atoi(getenv("RESTIR_BVH_REINSERT")) : RT_BVH_REINSERT_DEFAULT);
     if(reins > 0) {
@@ -598,9 +778,10 @@ bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads)
       for(int pass = 0; pass < reins; pass++) RI.pass(0.02f);
       out.reinsertions = RI.moved;
     }
-    for(int pass = 0; pass < rotate; pass++) { const uint64_t k = rotatePass(M, n2count, rotateGG); out.rotations += k; if(k == 0) break; }
+    for(int pass = 0; pass < rotate; pass++) { const uint64_t k = rotatePass(M, rotateGG, std::max(1, threads)); out.rotations += k; if(k == 0) break; }
   }
-  const std::vector<N2>& N = BS ? BS->nodes : B2.nodes;
+  timer.lap("rotations / reinsertion");
+  const std::vector<N2>& N = BS ? BS->nodes : B2->nodes;
   const std::vector<uint32_t>& leafTris = BS ? BS->leafTris : idx;
 
   // ---- 3a. which BVH2 nodes become wide nodes: SAH-optimal collapse (Ylitie, Karras, Laine 2017, §3.1) -------------------------
@@ -613,7 +794,7 @@ bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads)
   // Measured on the 2.8 M-triangle bench scene (scripts/bvh_ab.py, profiles/r02_bvh_collapse_ab.txt): 408 k nodes instead of 636 k, but
   // node visits per ray only 16.49 -> 16.18 (the visits are in the upper and middle levels, not in the under-filled bottom nodes), depth
   // 11 -> 13, direct stage -2 %, indirect stage +4.6 %: no net gain, so the greedy rule stays the default (RESTIR_BVH_COLLAPSE=dp selects this).
-  static const bool useDp = getenv("RESTIR_BVH_COLLAPSE") && strcmp(getenv("RESTIR_BVH_COLLAPSE"), "dp") == 0;
+  const bool useDp = getenv("RESTIR_BVH_COLLAPSE") && strcmp(getenv("RESTIR_BVH_COLLAPSE"), "dp") == 0;
   static const float cNode = 2.3f;   // a node step is ~230 instructions,
   static const float cTri = 1.0f;                                                                            // a triangle step ~100
   std::vector<float> cost;        // [n][i], i = 1..7 at [n * 8 + i]
@@ -658,160 +839,223 @@ bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads)
   };
 
   // ---- 3b. build the 8-wide nodes, breadth-first so that a node's internal children are contiguous ------------------
-  struct Work { uint32_t n2; uint32_t wide; int depth; };
-  std::vector<Work> queue;
+  // Round 6: level by level, two parallel passes per level around a prefix sum.  Pass 1 picks a wide node's children (collapse), assigns them to slots and counts its
+  // internal children and leaf triangles; the prefix sum over the level (in level order) gives every node its child base and triangle base — the same numbers the
+  // sequential breadth-first queue of rounds 1-5 produced; pass 2 quantises, writes the node, copies its triangle records and names its children's records for the
+  // next level.  The statistics are summed per fixed chunk and then in chunk order: the same bits for any thread count.
+  struct Work { uint32_t n2; uint32_t wide; };
+  struct Wide { uint32_t ch[8]; int8_t childInSlot[8]; uint8_t nc, nInner, nTris; };
+  const bool optSlots = getenv("RESTIR_BVH_SLOTS") && strcmp(getenv("RESTIR_BVH_SLOTS"), "opt") == 0;
+  const int T = std::max(1, threads);
+  constexpr size_t WCH = 512;
+  std::vector<Work> level, nextLevel;
   out.nodes.reserve(n / 2 + 16);
   out.tris.reserve(size_t(out.references));
   out.nodes.push_back(Node8{});
   // a root that is itself a leaf gets wrapped by a one-child wide node (handled by the generic path below)
-  queue.push_back({0, 0, 1});
-  for(size_t qi = 0; qi < queue.size(); qi++) {
-    const Work w = queue[qi];
-    out.maxDepth = std::max(out.maxDepth, w.depth);
-    uint32_t ch[8]; int nc = 0;
-    if(N[w.n2].leaf) ch[nc++] = w.n2;
-    else if(useDp) {
-      // the optimal 8 children of this wide node under the cost model: left subtree in k8 slots, right subtree in the rest
-      const int k = k8[w.n2];
-      expand(expand, N[w.n2].a, k, ch, nc);
-      expand(expand, N[w.n2].a + 1, 8 - k, ch, nc);
-    } else {
-      ch[nc++] = N[w.n2].a; ch[nc++] = N[w.n2].a + 1;
-      for(;;) {  // greedily open the internal child with the largest surface area
-        int pick = -1; float bestA = -1.f;
-        for(int i = 0; i < nc; i++) if(!N[ch[i]].leaf && N[ch[i]].b.area() > bestA) { bestA = N[ch[i]].b.area(); pick = i; }
-        if(pick < 0 || nc == 8) break;
-        uint32_t c = ch[pick];
-        ch[pick] = N[c].a; ch[nc++] = N[c].a + 1;
+  level.push_back({0, 0});
+  const double ra = std::max(1e-30, double(N[0].b.area()));
+  int depth = 0;
+  while(!level.empty()) {
+    depth++;
+    out.maxDepth = std::max(out.maxDepth, depth);
+    const size_t L = level.size();
+    std::vector<Wide> wide(L);
+    // ---- pass 1: children, slots, counts ----
+    parallelChunks(L, WCH, T, [&](size_t, size_t b0, size_t e0) {
+      for(size_t wi = b0; wi < e0; wi++) {
+        const Work w = level[wi];
+        Wide& X = wide[wi];
+        uint32_t* ch = X.ch; int nc = 0;
+        if(N[w.n2].leaf) ch[nc++] = w.n2;
+        else if(useDp) {
+          // the optimal 8 children of this wide node under the cost model: left subtree in k8 slots, right subtree in the rest
+          const int k = k8[w.n2];
+          expand(expand, N[w.n2].a, k, ch, nc);
+          expand(expand, N[w.n2].a + 1, 8 - k, ch, nc);
+        } else {
+          ch[nc++] = N[w.n2].a; ch[nc++] = N[w.n2].a + 1;
+          for(;;) {  // greedily open the internal child with the largest surface area
+            int pick = -1; float bestA = -1.f;
+            for(int i = 0; i < nc; i++) if(!N[ch[i]].leaf && N[ch[i]].b.area() > bestA) { bestA = N[ch[i]].b.area(); pick = i; }
+            if(pick < 0 || nc == 8) break;
+            uint32_t c = ch[pick];
+            ch[pick] = N[c].a; ch[nc++] = N[c].a + 1;
+          }
+        }
+        X.nc = uint8_t(nc);
+        // node box = union of child boxes
+        Box nb; nb.reset();
+        for(int i = 0; i < nc; i++) nb.grow(N[ch[i]].b);
+        // slot assignment: child whose centroid lies furthest towards corner s gets slot s (greedy best-pair)
+        int slotOf[8]; bool slotUsed[8] = {false, false, false, false, false, false, false, false}; bool done[8] = {false, false, false, false, false, false, false, false};
+        const float cen[3] = {0.5f * (nb.lo[0] + nb.hi[0]), 0.5f * (nb.lo[1] + nb.hi[1]), 0.5f * (nb.lo[2] + nb.hi[2])};
+        for(int r = 0; r < nc; r++) {
+          float bestC = -3e38f; int bc = -1, bs = -1;
+          for(int i = 0; i < nc; i++) {
+            if(done[i]) continue;
+            const Box& cb = N[ch[i]].b;
+            float d[3] = {0.5f * (cb.lo[0] + cb.hi[0]) - cen[0], 0.5f * (cb.lo[1] + cb.hi[1]) - cen[1], 0.5f * (cb.lo[2] + cb.hi[2]) - cen[2]};
+            for(int s = 0; s < 8; s++) {
+              if(slotUsed[s]) continue;
+              float c = d[0] * slotSign(s, 0) + d[1] * slotSign(s, 1) + d[2] * slotSign(s, 2);
+              if(c > bestC) { bestC = c; bc = i; bs = s; }
+            }
+          }
+          done[bc] = true; slotUsed[bs] = true; slotOf[bc] = bs;
+        }
+        // RESTIR_BVH_SLOTS=opt (experiment, profiles/r05_bvh_quality_ab.txt): the assignment that MAXIMISES the summed projection (Ylitie et al. 2017 solve it with an
+        // auction; with 8 x 8 an exact subset DP is 2 k steps per node) instead of the greedy best pair above
+        if(optSlots && nc > 1) {
+          float score[8][8];
+          for(int i = 0; i < nc; i++) {
+            const Box& cb = N[ch[i]].b;
+            const float d[3] = {0.5f * (cb.lo[0] + cb.hi[0]) - cen[0], 0.5f * (cb.lo[1] + cb.hi[1]) - cen[1], 0.5f * (cb.lo[2] + cb.hi[2]) - cen[2]};
+            for(int s2 = 0; s2 < 8; s2++) score[i][s2] = d[0] * slotSign(s2, 0) + d[1] * slotSign(s2, 1) + d[2] * slotSign(s2, 2);
+          }
+          // dp[mask] = best total for children 0 .. popcount(mask) - 1 placed in the slots of mask
+          float dp[256]; int8_t from[256];
+          for(int m = 0; m < 256; m++) { dp[m] = -3e38f; from[m] = -1; }
+          dp[0] = 0.f;
+          for(int m = 0; m < 256; m++) {
+            const int i = __builtin_popcount(unsigned(m));
+            if(i >= nc || dp[m] < -1e38f) continue;
+            for(int s2 = 0; s2 < 8; s2++) {
+              if(m & (1 << s2)) continue;
+              const float v = dp[m] + score[i][s2];
+              if(v > dp[m | (1 << s2)]) { dp[m | (1 << s2)] = v; from[m | (1 << s2)] = int8_t(s2); }
+            }
+          }
+          int bestMask = -1; float bestV = -3e38f;
+          for(int m = 0; m < 256; m++) if(__builtin_popcount(unsigned(m)) == nc && dp[m] > bestV) { bestV = dp[m]; bestMask = m; }
+          for(int i = nc - 1, m = bestMask; i >= 0; i--) { const int s2 = from[m]; slotOf[i] = s2; m &= ~(1 << s2); }
+        }
+        for(int s = 0; s < 8; s++) X.childInSlot[s] = -1;
+        for(int i = 0; i < nc; i++) X.childInSlot[slotOf[i]] = int8_t(i);
+        int inner = 0, tris = 0;
+        for(int i = 0; i < nc; i++) { if(N[ch[i]].leaf) tris += int(std::min<uint32_t>(N[ch[i]].n, 3u)); else inner++; }
+        X.nInner = uint8_t(inner); X.nTris = uint8_t(tris);
       }
-    }
-    // node box = union of child boxes
-    Box nb; nb.reset();
-    for(int i = 0; i < nc; i++) nb.grow(N[ch[i]].b);
-    // slot assignment: child whose centroid lies furthest towards corner s gets slot s (greedy best-pair)
-    int slotOf[8]; bool slotUsed[8] = {false, false, false, false, false, false, false, false}; bool done[8] = {false, false, false, false, false, false, false, false};
-    float cen[3] = {0.5f * (nb.lo[0] + nb.hi[0]), 0.5f * (nb.lo[1] + nb.hi[1]), 0.5f * (nb.lo[2] + nb.hi[2])};
-    for(int r = 0; r < nc; r++) {
-      float bestC = -3e38f; int bc = -1, bs = -1;
-      for(int i = 0; i < nc; i++) {
-        if(done[i]) continue;
-        const Box& cb = N[ch[i]].b;
-        float d[3] = {0.5f * (cb.lo[0] + cb.hi[0]) - cen[0], 0.5f * (cb.lo[1] + cb.hi[1]) - cen[1], 0.5f * (cb.lo[2] + cb.hi[2]) - cen[2]};
+    });
+    // ---- prefix sums in level order: where every node's internal children and leaf triangles go ----
+    std::vector<uint32_t> childBase(L), triBase(L);
+    uint32_t nodeTop = uint32_t(out.nodes.size()), triTop = uint32_t(out.tris.size());
+    for(size_t wi = 0; wi < L; wi++) { childBase[wi] = nodeTop; triBase[wi] = triTop; nodeTop += wide[wi].nInner; triTop += wide[wi].nTris; }
+    const uint32_t firstChild = uint32_t(out.nodes.size());
+    out.nodes.resize(nodeTop);
+    out.tris.resize(triTop);
+    nextLevel.assign(size_t(nodeTop - firstChild), Work{0u, 0u});
+    const size_t nChunks = (L + WCH - 1) / WCH;
+    std::vector<double> sNode(nChunks, 0.0), sTri(nChunks, 0.0), sNodeQ(nChunks, 0.0), sTriQ(nChunks, 0.0);
+    // ---- pass 2: quantise, write the node, copy its triangles, name its children ----
+    parallelChunks(L, WCH, T, [&](size_t chunkId, size_t b0, size_t e0) {
+      double aN = 0, aT = 0, aNQ = 0, aTQ = 0;
+      for(size_t wi = b0; wi < e0; wi++) {
+        const Work w = level[wi];
+        const Wide& X = wide[wi];
+        const uint32_t* ch = X.ch; const int nc = X.nc;
+        const int8_t* childInSlot = X.childInSlot;
+        Box nb; nb.reset();
+        for(int i = 0; i < nc; i++) nb.grow(N[ch[i]].b);
+        // quantisation grid: smallest power-of-two step with extent/step <= 255, bumped until every child fits
+        Node8 W{};
+        W.px = nb.lo[0]; W.py = nb.lo[1]; W.pz = nb.lo[2];
+        int ex[3];
+        for(int a = 0; a < 3; a++) {
+          float ext = nb.hi[a] - nb.lo[a];
+          int e = -60;
+          if(ext > 0) { int fe; std::frexp(ext / 255.f, &fe); e = fe; }  // ext/255 <= 2^fe
+          ex[a] = std::max(-100, std::min(100, e));
+        }
+        uint8_t qlo[3][8], qhi[3][8];
+        for(int a = 0; a < 3; a++) {
+          for(;;) {
+            const float step = std::ldexp(1.0f, ex[a]);
+            const float p = nb.lo[a];
+            bool ok = true;
+            for(int s = 0; s < 8 && ok; s++) {
+              qlo[a][s] = 0; qhi[a][s] = 0;
+              if(childInSlot[s] < 0) continue;
+              const Box& cb = N[ch[childInSlot[s]]].b;
+              int ql = int(std::floor((double(cb.lo[a]) - double(p)) / double(step)));
+              ql = std::max(0, std::min(255, ql));
+              while(ql > 0 && p + float(ql) * step > cb.lo[a]) ql--;
+              int qh = int(std::ceil((double(cb.hi[a]) - double(p)) / double(step)));
+              qh = std::max(0, qh);
+              while(qh <= 255 && p + float(qh) * step < cb.hi[a]) qh++;
+              if(qh > 255) { ok = false; break; }
+              qlo[a][s] = uint8_t(ql); qhi[a][s] = uint8_t(qh);
+            }
+            if(ok) break;
+            ex[a]++;
+          }
+        }
+        W.ex = uint8_t(ex[0] + 127); W.ey = uint8_t(ex[1] + 127); W.ez = uint8_t(ex[2] + 127);
+        W.childBase = childBase[wi];
+        W.triBase = triBase[wi];
+        uint32_t triOff = 0, rel = 0;
         for(int s = 0; s < 8; s++) {
-          if(slotUsed[s]) continue;
-          float c = d[0] * slotSign(s, 0) + d[1] * slotSign(s, 1) + d[2] * slotSign(s, 2);
-          if(c > bestC) { bestC = c; bc = i; bs = s; }
+          W.qlox[s] = qlo[0][s]; W.qloy[s] = qlo[1][s]; W.qloz[s] = qlo[2][s];
+          W.qhix[s] = qhi[0][s]; W.qhiy[s] = qhi[1][s]; W.qhiz[s] = qhi[2][s];
+          if(childInSlot[s] < 0) { W.meta[s] = 0; continue; }
+          const N2& c = N[ch[childInSlot[s]]];
+          if(c.leaf) {
+            // c.n <= 3 by construction, except the degenerate "root is one big leaf" case which cannot happen for n > 3
+            uint32_t cntT = std::min<uint32_t>(c.n, 3u);
+            W.meta[s] = uint8_t((((1u << cntT) - 1u) << 5) | triOff);
+            for(uint32_t k = 0; k < cntT; k++) out.tris[size_t(triBase[wi]) + triOff + k] = flat[leafTris[c.a + k]];
+            triOff += cntT;
+          } else {
+            W.imask |= uint8_t(1u << s);
+            W.meta[s] = uint8_t((1u << 5) | (24u + uint32_t(s)));
+            const uint32_t widx = childBase[wi] + rel; rel++;
+            nextLevel[size_t(widx - firstChild)] = Work{ch[childInSlot[s]], widx};
+          }
         }
-      }
-      done[bc] = true; slotUsed[bs] = true; slotOf[bc] = bs;
-    }
-    // RESTIR_BVH_SLOTS=opt (experiment, profiles/r05_bvh_quality_ab.txt): the assignment that MAXIMISES the summed projection (Ylitie et al. 2017 solve it with an
-    // auction; with 8 x 8 an exact subset DP is 2 k steps per node) instead of the greedy best pair above
-    static const bool optSlots = getenv("RESTIR_BVH_SLOTS") && strcmp(getenv("RESTIR_BVH_SLOTS"), "opt") == 0;
-    if(optSlots && nc > 1) {
-      float score[8][8];
-      for(int i = 0; i < nc; i++) {
-        const Box& cb = N[ch[i]].b;
-        const float d[3] = {0.5f * (cb.lo[0] + cb.hi[0]) - cen[0], 0.5f * (cb.lo[1] + cb.hi[1]) - cen[1], 0.5f * (cb.lo[2] + cb.hi[2]) - cen[2]};
-        for(int s2 = 0; s2 < 8; s2++) score[i][s2] = d[0] * slotSign(s2, 0) + d[1] * slotSign(s2, 1) + d[2] * slotSign(s2, 2);
-      }
-      // dp[mask] = best total for children 0 .. popcount(mask) - 1 placed in the slots of mask
-      float dp[256]; int8_t from[256];
-      for(int m = 0; m < 256; m++) { dp[m] = -3e38f; from[m] = -1; }
-      dp[0] = 0.f;
-      for(int m = 0; m < 256; m++) {
-        const int i = __builtin_popcount(unsigned(m));
-        if(i >= nc || dp[m] < -1e38f) continue;
+        out.nodes[w.wide] = W;
+        // SAH statistics of the WIDE tree (expected steps of a random ray that hits the root box): a node step per wide node whose box is hit, a triangle step
+        // per triangle of a leaf slot whose box is hit
+        aN += double(nb.area()) / ra;
+        for(int i = 0; i < nc; i++) if(N[ch[i]].leaf) aT += double(N[ch[i]].b.area()) / ra * double(std::min<uint32_t>(N[ch[i]].n, 3u));
+        // ... and the same expectation with the boxes the GPU tests: the children's boxes on this node's 8-bit grid (a thin triangle in a wide node grows to the grid step)
         for(int s2 = 0; s2 < 8; s2++) {
-          if(m & (1 << s2)) continue;
-          const float v = dp[m] + score[i][s2];
-          if(v > dp[m | (1 << s2)]) { dp[m | (1 << s2)] = v; from[m | (1 << s2)] = int8_t(s2); }
+          if(childInSlot[s2] < 0) continue;
+          const N2& cq = N[ch[childInSlot[s2]]];
+          Box q;
+          for(int a = 0; a < 3; a++) { const float step = std::ldexp(1.0f, ex[a]); q.lo[a] = nb.lo[a] + float(qlo[a][s2]) * step; q.hi[a] = nb.lo[a] + float(qhi[a][s2]) * step; }
+          if(cq.leaf) aTQ += double(q.area()) / ra * double(std::min<uint32_t>(cq.n, 3u));
+          else aNQ += double(q.area()) / ra;
         }
+        if(w.wide == 0) aNQ += 1.0;   // the root itself
       }
-      int bestMask = -1; float bestV = -3e38f;
-      for(int m = 0; m < 256; m++) if(__builtin_popcount(unsigned(m)) == nc && dp[m] > bestV) { bestV = dp[m]; bestMask = m; }
-      for(int i = nc - 1, m = bestMask; i >= 0; i--) { const int s2 = from[m]; slotOf[i] = s2; m &= ~(1 << s2); }
-    }
-    int childInSlot[8]; for(int s = 0; s < 8; s++) childInSlot[s] = -1;
-    for(int i = 0; i < nc; i++) childInSlot[slotOf[i]] = i;
-
-    // quantisation grid: smallest power-of-two step with extent/step <= 255, bumped until every child fits
-    Node8 W{};
-    W.px = nb.lo[0]; W.py = nb.lo[1]; W.pz = nb.lo[2];
-    int ex[3];
-    for(int a = 0; a < 3; a++) {
-      float ext = nb.hi[a] - nb.lo[a];
-      int e = -60;
-      if(ext > 0) { int fe; std::frexp(ext / 255.f, &fe); e = fe; }  // ext/255 <= 2^fe
-      ex[a] = std::max(-100, std::min(100, e));
-    }
-    uint8_t qlo[3][8], qhi[3][8];
-    for(int a = 0; a < 3; a++) {
-      for(;;) {
-        const float step = std::ldexp(1.0f, ex[a]);
-        const float p = nb.lo[a];
-        bool ok = true;
-        for(int s = 0; s < 8 && ok; s++) {
-          qlo[a][s] = 0; qhi[a][s] = 0;
-          if(childInSlot[s] < 0) continue;
-          const Box& cb = N[ch[childInSlot[s]]].b;
-          int ql = int(std::floor((double(cb.lo[a]) - double(p)) / double(step)));
-          ql = std::max(0, std::min(255, ql));
-          while(ql > 0 && p + float(ql) * step > cb.lo[a]) ql--;
-          int qh = int(std::ceil((double(cb.hi[a]) - double(p)) / double(step)));
-          qh = std::max(0, qh);
-          while(qh <= 255 && p + float(qh) * step < cb.hi[a]) qh++;
-          if(qh > 255) { ok = false; break; }
-          qlo[a][s] = uint8_t(ql); qhi[a][s] = uint8_t(qh);
-        }
-        if(ok) break;
-        ex[a]++;
-      }
-    }
-    W.ex = uint8_t(ex[0] + 127); W.ey = uint8_t(ex[1] + 127); W.ez = uint8_t(ex[2] + 127);
-    W.childBase = uint32_t(out.nodes.size());
-    W.triBase = uint32_t(out.tris.size());
-    uint32_t triOff = 0;
-    for(int s = 0; s < 8; s++) {
-      W.qlox[s] = qlo[0][s]; W.qloy[s] = qlo[1][s]; W.qloz[s] = qlo[2][s];
-      W.qhix[s] = qhi[0][s]; W.qhiy[s] = qhi[1][s]; W.qhiz[s] = qhi[2][s];
-      if(childInSlot[s] < 0) { W.meta[s] = 0; continue; }
-      const N2& c = N[ch[childInSlot[s]]];
-      if(c.leaf) {
-        // c.n <= 3 by construction, except the degenerate "root is one big leaf" case which cannot happen for n > 3
-        uint32_t cntT = std::min<uint32_t>(c.n, 3u);
-        W.meta[s] = uint8_t((((1u << cntT) - 1u) << 5) | triOff);
-        for(uint32_t k = 0; k < cntT; k++) out.tris.push_back(flat[leafTris[c.a + k]]);
-        triOff += cntT;
-      } else {
-        W.imask |= uint8_t(1u << s);
-        W.meta[s] = uint8_t((1u << 5) | (24u + uint32_t(s)));
-        const uint32_t wi = uint32_t(out.nodes.size());
-        out.nodes.push_back(Node8{});
-        queue.push_back({ch[childInSlot[s]], wi, w.depth + 1});
-      }
-    }
-    out.nodes[w.wide] = W;
-    // SAH statistics of the WIDE tree (expected steps of a random ray that hits the root box): a node step per wide node whose box is hit, a triangle step
-    // per triangle of a leaf slot whose box is hit
-    const double ra = std::max(1e-30, double(N[0].b.area()));
-    out.sahNodeSteps += double(nb.area()) / ra;
-    for(int i = 0; i < nc; i++) if(N[ch[i]].leaf) out.sahTriSteps += double(N[ch[i]].b.area()) / ra * double(std::min<uint32_t>(N[ch[i]].n, 3u));
-    // ... and the same expectation with the boxes the GPU tests: the children's boxes on this node's 8-bit grid (a thin triangle in a wide node grows to the grid step)
-    for(int s2 = 0; s2 < 8; s2++) {
-      if(childInSlot[s2] < 0) continue;
-      const N2& cq = N[ch[childInSlot[s2]]];
-      Box q;
-      for(int a = 0; a < 3; a++) { const float step = std::ldexp(1.0f, ex[a]); q.lo[a] = nb.lo[a] + float(qlo[a][s2]) * step; q.hi[a] = nb.lo[a] + float(qhi[a][s2]) * step; }
-      if(cq.leaf) out.sahTriStepsQ += double(q.area()) / ra * double(std::min<uint32_t>(cq.n, 3u));
-      else out.sahNodeStepsQ += double(q.area()) / ra;
-    }
-    if(w.wide == 0) out.sahNodeStepsQ += 1.0;   // the root itself
+      sNode[chunkId] = aN; sTri[chunkId] = aT; sNodeQ[chunkId] = aNQ; sTriQ[chunkId] = aTQ;
+    });
+    for(size_t c = 0; c < nChunks; c++) { out.sahNodeSteps += sNode[c]; out.sahTriSteps += sTri[c]; out.sahNodeStepsQ += sNodeQ[c]; out.sahTriStepsQ += sTriQ[c]; }
+    level.swap(nextLevel);
   }
+  timer.lap("collapse + wide nodes");
   return true;
 }
 
 }  // namespace rt
+
+// ---- determinism pin (tests/test_bvh_quality.py; no GPU): the tree as a 64-bit FNV-1a hash of its node and leaf records, built with a given number of threads --------
+// out[0] = hash, out[1] = nodes, out[2] = leaf records, out[3] = spatial splits, out[4] = rotations, out[5] = depth; seconds = build time
+extern "C" int rt_bvh8_build_hash(const rt_scene_desc* scene, int threads, uint64_t* out, double* seconds)
+{
+  if(!scene || !out) return -1;
+  rt::BuildOutput bo;
+  const auto t0 = std::chrono::steady_clock::now();
+  if(!rt::buildBvh8(*scene, bo, std::max(1, threads))) return -2;
+  if(seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  uint64_t h = 1469598103934665603ull;
+  auto eat = [&](const void* p, size_t bytes) { const uint8_t* b = static_cast<const uint8_t*>(p); for(size_t i = 0; i < bytes; i++) { h ^= b[i]; h *= 1099511628211ull; } };
+  eat(bo.nodes.data(), bo.nodes.size() * sizeof(rt::Node8));
+  eat(bo.tris.data(), bo.tris.size() * sizeof(rt::Tri48));
+  eat(&bo.sahNodeSteps, sizeof(double)); eat(&bo.sahTriSteps, sizeof(double)); eat(&bo.sahNodeStepsQ, sizeof(double)); eat(&bo.sahTriStepsQ, sizeof(double));
+  out[0] = h; out[1] = bo.nodes.size(); out[2] = bo.tris.size(); out[3] = bo.spatialSplits; out[4] = bo.rotations; out[5] = uint64_t(bo.maxDepth);
+  return 0;
+}
 
 // ---- host-side self check of a built tree (tests/test_bvh_quality.py; no GPU) ----------------------------------------------------------------------------
 // The property every parity claim rests on: the answer of a query is a function of the triangle set, never of the tree.  For that every point of

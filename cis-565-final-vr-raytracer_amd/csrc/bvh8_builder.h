@@ -24,6 +24,8 @@ struct BuildOutput {
 // Host-side build: flatten (instance, triangle) pairs to world space, binned-SAH BVH2, greedy collapse to 8-wide,
 // octant-ordered slot assignment, conservative 8-bit quantisation.  Replaces AccelStructure::create
 // (src/accelstruct.cpp:55-162: BLAS per prim mesh + TLAS per node, built by the Vulkan driver).
-bool buildBvh8(const rt_scene_desc& scene, BuildOutput& out, int threads);
+// plainTree: object splits only, no rotations / reinsertion — the tree of rounds 1-4, whatever the environment says (rt_build_accel's fallback when the quality passes
+// made a tree deeper than the traversal stack).
+bool buildBvh8(const rt_scene_desc& scene, BuildOutput& out, int threads, bool plainTree = false);
 
 }  // namespace rt

@@ -538,6 +538,14 @@ static void sceneKey(const rt_ctx* c, uint64_t& h0, uint64_t& h1)
     hashBytes(meta, sizeof(meta), h0, h1);
     if(i < c->hostAlpha.size()) RT_HASH_VEC(c->hostAlpha[i]);
   }
+  // the builder's settings are part of what is cached: a host that changes RESTIR_BVH_* between two contexts of one process gets the tree it asked for, not the first
+  // one's (advisor finding of round 5)
+  for(const char* name : {"RESTIR_BVH_SPLIT", "RESTIR_BVH_SPLIT_BUDGET", "RESTIR_BVH_SPLIT_ALPHA", "RESTIR_BVH_SPLIT_WORK", "RESTIR_BVH_BUDGET_RULE", "RESTIR_BVH_ROTATE", "RESTIR_BVH_ROTATE_GG",
+                           "RESTIR_BVH_REINSERT", "RESTIR_BVH_BINS", "RESTIR_BVH_SBINS", "RESTIR_BVH_SLOTCOST", "RESTIR_BVH_COLLAPSE", "RESTIR_BVH_SLOTS", "RESTIR_BVH_PAR_MIN", "RESTIR_BVH_SEQ_MAX"}) {
+    const char* v = getenv(name);
+    hashBytes(name, strlen(name), h0, h1);
+    if(v) hashBytes(v, strlen(v) + 1, h0, h1);
+  }
 }
 #undef RT_HASH_VEC
 static int buildHostAccel(rt_ctx* c, HostAccel& out)
@@ -550,6 +558,11 @@ static int buildHostAccel(rt_ctx* c, HostAccel& out)
   BuildOutput& bo = out.bo;
   int threads = int(std::thread::hardware_concurrency());
   if(!buildBvh8(d, bo, threads > 0 ? threads : 1)) return fail(c, RT_ERR_INVALID_ARG, "rt_build_accel: BVH8 build failed");
+  if(bo.maxDepth > STACK_MAX) {
+    // rotations and spatial splits can deepen a tree: before giving up, the tree of rounds 1-4 (object splits only), which would have built (advisor finding of round 5)
+    bo = BuildOutput{};
+    if(!buildBvh8(d, bo, threads > 0 ? threads : 1, true)) return fail(c, RT_ERR_INVALID_ARG, "rt_build_accel: BVH8 build failed");
+  }
   if(bo.maxDepth > STACK_MAX) return fail(c, RT_ERR_INVALID_ARG, "rt_build_accel: BVH8 deeper than the traversal stack");
   // alpha records for the triangles that go through HitTest (instances without FORCE_OPAQUE)
   std::vector<AlphaRec>& alpha = out.alpha; alpha.assign(1, AlphaRec{});

@@ -644,7 +644,7 @@ class PipelinedTiledFrame(TiledFrame):
     # -- frame -----------------------------------------------------------------------------------------------------------------
     def render_frame(self, state, frames):
         c, b = self.comm, self.b
-        if c.world == 1:
+        if c.world == 1 and os.environ.get("RESTIR_TILED_FORCE_PIPELINE") != "1":   # (forced: scripts/r06_host_period.py times THIS host's schedule on one band, no exchanges)
             return super().render_frame(state, frames)
         f, cur, last = frames, frames & 1, (frames + 1) & 1
         self._last_frames = frames
@@ -816,8 +816,13 @@ class RendererTensors:
     def stream(self, name):
         """Context: kernels (rt_set_stream) and collectives (torch current stream) issued inside go to the named stream."""
         if self._streams is None:
-            ptrs = RendererTensors.create_streams(self.r)
-            self._streams = {n: self.torch.cuda.ExternalStream(ptrs[n]) for n in ("main", "ind", "side")}
+            import os
+            if os.environ.get("RESTIR_TILED_TORCH_STREAMS") == "1":   # A/B only (scripts/r06_host_period.py): the layout of rounds 1-5, three streams of torch's pool
+                prio = os.environ.get("RESTIR_TILED_PRIO", "ind").split(",")
+                self._streams = {n: self.torch.cuda.Stream(priority=-1 if n in prio else 0) for n in ("main", "ind", "side")}
+            else:
+                ptrs = RendererTensors.create_streams(self.r)
+                self._streams = {n: self.torch.cuda.ExternalStream(ptrs[n]) for n in ("main", "ind", "side")}
         backend, s = self, self._streams[name]
         class _Ctx:
             def __enter__(self_):

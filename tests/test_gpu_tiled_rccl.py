@@ -39,13 +39,17 @@ def _worker(rank, world, port, outdir, pipelined):
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(rank)
+    from restir_amd import tiled
+    from restir_amd.renderer import Renderer
+    r = Renderer().setup(rank)
+    ptrs = tiled.RendererTensors.create_streams(r)    # the rank renders on its context's three streams, created before the process group (round 6; bench.py does the same)
+    lay = r.stream_layout()["creation_index"]
+    assert lay["main"] < lay["side"] < lay["ind"]
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{rank}"))
     try:
-        from restir_amd import tiled
-        from restir_amd.renderer import Renderer
         sc, env, st = _scene()
-        r = Renderer().setup(rank); r.load_scene(sc.desc(env)); r.update(W, H)
-        stream = torch.cuda.Stream(); torch.cuda.set_stream(stream); r.set_stream(stream.cuda_stream)
+        r.load_scene(sc.desc(env)); r.update(W, H)
+        stream = torch.cuda.ExternalStream(ptrs["main"]); torch.cuda.set_stream(stream); r.set_stream(stream.cuda_stream)
         Frame = tiled.PipelinedTiledFrame if pipelined else tiled.TiledFrame
         fr = Frame(tiled.RendererTensors(r), tiled.TorchComm(), W, H)
         for f, cam in enumerate(_cameras(sc)):
