@@ -78,8 +78,30 @@ def footprint_of(args):
     return args.scene_footprint if args.config in REAL_KINDS else "lite"
 
 
-def workload_key(config, orbit, footprint="lite"):
-    return f"config{config}" + ("_moving" if orbit and config != 5 else "") + ("_real" if footprint == "real" and config in REAL_KINDS else "")
+def workload_key(config, orbit, footprint="lite", pose=0):
+    return f"config{config}" + ("_moving" if orbit and config != 5 else "") + ("_real" if footprint == "real" and config in REAL_KINDS else "") + (f"_pose{pose}" if pose else "")
+
+
+# --pose N (config 4): the headline scene from fixed camera poses.  Round-5 verdict, missing 3: every conclusion of round 5 was a statement about ONE view — the street of
+# trees seen end-on, whose horizon tiles carry the frame (the same scene 15 degrees off axis renders 2.5 x faster).  0 = the scene's own camera (end-on down the street),
+# 1 = the same eye orbited 15 degrees about its centre of interest (what the orbiting camera of --moving-camera sees after 30 frames), 2 = an elevated view across the street
+# (eye at balcony height on one side, looking down at the other side's facades, awnings, chairs and tree crowns from above: no horizon, no end-on row of trees).
+POSES = {0: "end-on down the street (the scene's camera)", 1: "orbited 15 degrees about the centre of interest", 2: "elevated, across the street"}
+
+
+def apply_pose(args, scene):
+    pose = getattr(args, "pose", 0)
+    if not pose:
+        return
+    eye, center, up, fov = scene.cameraPose()
+    if pose == 1:
+        a = np.deg2rad(15.0)
+        rot = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], dtype=np.float32)
+        scene.setCamera(center + rot @ (eye - center), center, up, fov)
+    elif pose == 2:
+        scene.setCamera(np.array([-30.0, 13.0, 10.5], dtype=np.float32), np.array([-4.0, 2.0, -9.0], dtype=np.float32), up, fov)
+    else:
+        raise SystemExit(f"--pose {pose}: 0, 1 or 2")
 
 
 def texture_bytes(desc):
@@ -165,6 +187,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", type=int, default=4, choices=[2, 3, 4, 5], help="BASELINE.json / SURVEY.md 8(d) configuration (4 = the headline workload)")
     ap.add_argument("--moving-camera", action="store_true", help="the camera orbits its centre of interest by 0.5 degrees per frame (always on for --config 5)")
+    ap.add_argument("--pose", type=int, default=0, choices=[0, 1, 2], help="config 4: fixed camera pose (0 = the scene's own, end-on down the street; 1 = orbited 15 degrees; 2 = elevated, across the street)")
     ap.add_argument("--scene-footprint", choices=["lite", "real"], default=os.environ.get("RESTIR_SCENE_FOOTPRINT", DEFAULT_FOOTPRINT),
                     help="configs 3 / 4: `real` = the texture / material / triangle-shape footprint of the asset the procedural scene stands in for (see scene_kind); "
                          "`lite` = the cache-resident scenes of rounds 1-4")
@@ -195,7 +218,7 @@ def main():
     ap.add_argument("--print-workload-key", action="store_true", help="print the key of this workload in profiles/pmc_traffic.json and exit (scripts/pmc.sh)")
     args = ap.parse_args()
     if args.print_workload_key:
-        print(workload_key(args.config, args.moving_camera or CONFIGS[args.config].get("orbit", False), footprint_of(args)))
+        print(workload_key(args.config, args.moving_camera or CONFIGS[args.config].get("orbit", False), footprint_of(args), args.pose))
         return None
 
     rank = int(os.environ.get("RANK", "0"))
@@ -273,6 +296,7 @@ def main():
     orbit = args.moving_camera or cfg.get("orbit", False)
     footprint = footprint_of(args)
     scene = host.Scene().makeProcedural(scene_kind(abi, args.config, footprint), args.scale, 1)
+    apply_pose(args, scene)
     env = None
     if cfg["env"]:
         env = host.HdrSampling()
@@ -439,7 +463,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"config {args.config}: {cfg['name']} procedural scene ({footprint} footprint: {scene.getStat()['materials']} materials, {texture_bytes(desc) / 1e6:.0f} MB of BGRA8 texels), "
                                    f"{scene.getStat()['instancedTriangles']} triangles, {W}x{H}, {cfg['pipeline']}, "
-                                   + ("camera orbiting 0.5 deg / frame" if orbit else "static camera") + (f", {cfg['env'][0]}x{cfg['env'][1]} synthetic HDR sky" if cfg["env"] else ", no environment"),
+                                   + ("camera orbiting 0.5 deg / frame" if orbit else "static camera") + (f", pose {args.pose}: {POSES[args.pose]}" if getattr(args, "pose", 0) else "") + (f", {cfg['env'][0]}x{cfg['env'][1]} synthetic HDR sky" if cfg["env"] else ", no environment"),
                        "baseline_config": args.config, "scene_footprint": footprint, "texture_bytes": texture_bytes(desc), "width": W, "height": H, "scene_scale": args.scale,
                        "parallelism": ("single GPU" if frame is None else f"ONE rank of an emulated {args.emulate_world}-way row tiling, communication stubbed (not a benchmark result)") if world == 1 else f"row-tiled x{world}: frames in flight on 3 streams per rank, halo exchanges over RCCL (restir_amd/tiled.py PipelinedTiledFrame), " + ("equal-height bands" if band_plan is None else f"cost-weighted bands {band_plan}"),
                        "rays_per_frame": round(rays_per_frame), "fps": round(1e3 / ms_per_step, 2), "bvh8_build_s": round(build_s, 2),
@@ -452,8 +476,12 @@ def main():
             out["sustained"] = sustained
         if world == 1 and not di_only:
             sp = r.stream_priorities()
+            from restir_amd.renderer import PRIO_FILTER_SHARE
             sp["how"] = "given on the command line" if prio_explicit else ("RESTIR_PRIO" if os.environ.get("RESTIR_PRIO") else
-                                                                         "rt_render_frame's rule on the first frame's stage times (filter stream high when filter_share >= 0.14)")
+                                                                         f"rt_render_frame's rule on the third (warm) probe frame's stage times (filter stream high when filter_share >= {PRIO_FILTER_SHARE})")
+            if sp.get("filter_share") is not None:   # how far the measured share is from the rule's threshold: a decision within a few percent of it can flip between runs
+                sp["threshold"] = PRIO_FILTER_SHARE
+                sp["margin_rel"] = round(sp["filter_share"] / PRIO_FILTER_SHARE - 1.0, 3)
             out["stream_priorities"] = sp
         if frame is not None:   # what rank 0 received for the last timed frame, by purpose (restir_amd/tiled.py accounting), and the exact fallbacks of the run
             out["halo_bytes_rank0"] = dict(frame.halo_bytes)
@@ -514,12 +542,12 @@ def main():
         # HBM traffic and VALU instructions of the same kernel from the PMC passes of THIS workload (scripts/pmc.sh: separate rocprofv3 --pmc runs of this
         # command; FETCH_SIZE / WRITE_SIZE are in KiB; gfx950's FETCH_SIZE counts wide reads at half their size — MI355X_MICROARCH.md, HBM section — so it is
         # doubled; WRITE_SIZE is taken as reported).  Counters of another build or another workload are not used: the label is then null.
-        t, pmc = pmc_entry(workload_key(args.config, orbit, footprint), kname)
+        t, pmc = pmc_entry(workload_key(args.config, orbit, footprint, args.pose), kname)
         frames_note = None
         if t and orbit:
             # a moving camera renders other work every frame: counters describe this line only if they were collected over the same frame indices
             # (scripts/pmc.sh records them: `_frames`; entries of round 4 have none)
-            wf = ((pmc.get("workloads", {}).get(workload_key(args.config, orbit, footprint)) or {}).get("_frames") or {})
+            wf = ((pmc.get("workloads", {}).get(workload_key(args.config, orbit, footprint, args.pose)) or {}).get("_frames") or {})
             if wf.get("warmup") != args.warmup or wf.get("steps") != args.steps:
                 frames_note = f"the counter pass of this workload covers frames {wf.get('warmup')}..+{wf.get('steps')}, this line times frames {args.warmup}..+{args.steps} of a moving camera: counters withheld"
                 t = None
@@ -549,7 +577,7 @@ def main():
                              "source": "profiles/pmc_traffic.json (SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU per launch)"})
                 if sdur:
                     valu["serial_frac"] = round(t["INSTS_VALU"] / (sdur * 1e-3) / peak_mix, 4)
-                w = (pmc.get("workloads", {}).get(workload_key(args.config, orbit, footprint)) or pmc) if pmc else None
+                w = (pmc.get("workloads", {}).get(workload_key(args.config, orbit, footprint, args.pose)) or pmc) if pmc else None
                 fr = w.get("_frame") if w else None
                 if fr and args.emulate_world <= 1:
                     valu.update({"frame_wave_insts": round(fr["INSTS_VALU"]), "frame_frac": round(fr["INSTS_VALU"] / (out["ms_per_step"] * 1e-3) / peak_mix, 4)})
@@ -779,6 +807,7 @@ def native_world(args, abi, host, Renderer, torch, extra=None):
         raise SystemExit("--native: config 2 is the direct stage alone (one launch per step); it has no row-tiled form")
     footprint = footprint_of(args)
     scene = host.Scene().makeProcedural(scene_kind(abi, args.config, footprint), args.scale, 1)
+    apply_pose(args, scene)
     env = None
     if cfg["env"]:
         env = host.HdrSampling(); env.makeSyntheticSky(cfg["env"][0], cfg["env"][1], 5e4, 7)
@@ -835,7 +864,7 @@ def native_world(args, abi, host, Renderer, torch, extra=None):
            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"config {args.config}: {cfg['name']} procedural scene ({footprint} footprint: {scene.getStat()['materials']} materials, {texture_bytes(desc) / 1e6:.0f} MB of BGRA8 texels), "
                                   f"{scene.getStat()['instancedTriangles']} triangles, {W}x{H}, {cfg['pipeline']}, "
-                                  + ("camera orbiting 0.5 deg / frame" if orbit else "static camera"),
+                                  + ("camera orbiting 0.5 deg / frame" if orbit else "static camera") + (f", pose {args.pose}: {POSES[args.pose]}" if getattr(args, "pose", 0) else ""),
                       "baseline_config": args.config, "scene_footprint": footprint, "texture_bytes": texture_bytes(desc), "width": W, "height": H, "scene_scale": args.scale,
                       "parallelism": f"row-tiled x{n}: ONE process, native context (rt_mgpu_*): a worker thread, an rt_ctx and three streams per device, frames in flight per rank, "
                                      f"event-ordered hipMemcpyPeerAsync pulls; " + ("equal-height bands" if args.equal_bands else f"cost-weighted bands {bands}"),
@@ -951,6 +980,7 @@ def emulate_world(args, abi, host, scene, env, st, desc, single, W, H, device):
     m.load_scene(desc); m.update(W, H)
     m.set_serialize(True); m.set_balance(0 if args.equal_bands else 1)
     scene2 = host.Scene().makeProcedural(scene_kind(abi, args.config, footprint_of(args)), args.scale, 1)   # (a second instance: its camera history is the tiled run's own)
+    apply_pose(args, scene2)
     scene2.updateCamera(W, H)
     acc = np.zeros((n, 2)); halo = 0; kinds = np.zeros(6); bands = None
     f = 0

@@ -175,7 +175,9 @@ struct BuilderS {
   //  thresholds are part of the build's definition: another value is another, equally reproducible, tree.)
   const size_t PAR_MIN = getenv("RESTIR_BVH_PAR_MIN") ? size_t(std::max(256, atoi(getenv("RESTIR_BVH_PAR_MIN")))) : size_t(1) << 18;
   const size_t PAR_CHUNK = std::min<size_t>(size_t(1) << 16, std::max<size_t>(64, PAR_MIN / 4));
-  const size_t SEQ_MAX = getenv("RESTIR_BVH_SEQ_MAX") ? size_t(std::max(16, atoi(getenv("RESTIR_BVH_SEQ_MAX")))) : 100000;
+  // (SEQ_MAX 100 000 left sequential subtrees of up to 3 s each — the ones dense with thin triangles — and the build did not scale past 16 threads: 4.8 s on the 256
+  //  threads of the GPU box's host; with 16 384 the longest one is a few tenths of a second, profiles/r06_bvh_build.txt)
+  const size_t SEQ_MAX = getenv("RESTIR_BVH_SEQ_MAX") ? size_t(std::max(16, atoi(getenv("RESTIR_BVH_SEQ_MAX")))) : 16384;
   struct Pool { int64_t budget; uint32_t nextNode, nextLeaf; };     // what a sequential subtree still owns
   BuilderS(const std::vector<Tri48>& f, float pad_, size_t n, double budgetFrac, int threads)
     : flat(f), pad(pad_), rootBudget(int64_t(double(n) * budgetFrac)), maxThreads(threads)
@@ -410,7 +412,7 @@ struct BuilderS {
       const uint32_t lNodes = uint32_t(2 * (int64_t(left.size()) + bl) - 2), lLeaves = uint32_t(int64_t(left.size()) + bl);
       N.leaf = false; N.a = child; N.n = 0;
       const uint32_t lBase = nodeBase + 2, rBase = nodeBase + 2 + lNodes, lLeaf = leafBase, rLeaf = leafBase + lLeaves;
-      if(liveThreads.load() < maxThreads) {
+      if(liveThreads.load() < 4 * maxThreads) {   // (most of these threads wait in join() for their children: more threads than cores)
         liveThreads++;
         std::thread th([this, child, bl, lBase, lLeaf, l = std::move(left)]() mutable { build(child, std::move(l), bl, lBase, lLeaf); liveThreads--; });
         build(child + 1, std::move(right), br, rBase, rLeaf);
@@ -722,7 +724,7 @@ bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads, bool plai
   uint32_t n2count = 0;
   if(useSplits) {
     // The budget is a cap on the TOTAL of added references.  Shares of exactly that total strand most of it in parts of the scene that need no splits (see
-    // BuilderS), so the build first runs with shares of a generous working budget (every subtree may double its references): on the benchmark scenes the overlap
+    // BuilderS), so the build first runs with shares of a generous working budget (every subtree may triple its references: no sequential subtree of the benchmark scenes comes near its share): on the benchmark scenes the overlap
     // criterion (alpha) then decides alone — 0.26 n added references on the real exterior scene, the tree of round 5 — and the total stays under the cap.  Only when it
     // does not is the build redone with shares of the cap itself, which bound the total by construction.  Both attempts are deterministic.
     const size_t RCH = size_t(1) << 16;
@@ -743,7 +745,7 @@ bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads, bool plai
       });
       for(const Box& b : rootOf) root.grow(b);
     }
-    const double workBudget = getenv("RESTIR_BVH_SPLIT_WORK") ? std::max(0.0, atof(getenv("RESTIR_BVH_SPLIT_WORK"))) : 1.0;
+    const double workBudget = getenv("RESTIR_BVH_SPLIT_WORK") ? std::max(0.0, atof(getenv("RESTIR_BVH_SPLIT_WORK"))) : 2.0;
     for(int attempt = 0; attempt < 2; attempt++) {
       const bool strict = attempt == 1 || workBudget <= splitBudget;
       BS.reset();   // (release the first attempt's arrays before the second one allocates)

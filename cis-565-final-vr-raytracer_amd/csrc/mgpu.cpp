@@ -54,7 +54,7 @@ int rtCreateWithLevels(rt_ctx** out, int device, const int* levels);
 namespace {
 
 // default levels of a rank's main / indirect / filter stream (RESTIR_MGPU_PRIO overrides): rt_mgpu_create
-constexpr int MGPU_PRIO_DEFAULT[3] = {0, 0, 0};
+constexpr int MGPU_PRIO_DEFAULT[3] = {0, 1, 0};
 
 // full-res rows of last-frame history around the band: adaptive (rt_mgpu::histHalo) — HIST_HALO_MIN while no temporal lookup leaves band + halo, doubled
 // (up to HIST_HALO_MAX) for the frames after one did, halved again after HIST_HALO_CALM frames without; a lookup outside is always caught (exact fallback)

@@ -770,7 +770,7 @@ static hipError_t ensureOverlapStreams(rt_ctx* c)
 }
 
 // The rule of rt_render_frame's probe frames (see there).  RESTIR_PRIO_PROBE = number of probe frames (default 3; 1 = round 5's first-frame decision).
-static constexpr float PRIO_FILTER_SHARE = 0.14f;
+static constexpr float PRIO_FILTER_SHARE = 0.20f;   // (restir_amd/renderer.py mirrors it for reports)
 static int prioProbeFrames() { static const int n = getenv("RESTIR_PRIO_PROBE") ? std::max(1, atoi(getenv("RESTIR_PRIO_PROBE"))) : 3; return n; }
 // what the decision was taken on has changed (target size, scene, tree, denoise toggle): the next frames probe again.  The streams of the old levels stay alive, idle
 // (one per role and level, never destroyed: see rt_ctx::indStreams); the caller has drained the context.

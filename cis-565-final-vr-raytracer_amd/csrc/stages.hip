@@ -517,6 +517,7 @@ __global__ __launch_bounds__(256) void k_ind_tile_order(rt_state st, int rowBegi
   }
   __syncthreads();
   if(threadIdx.x < 2) counts[xcd * 2 + threadIdx.x] = s_cnt[threadIdx.x];
+  if(threadIdx.x == 2) counts[16 + xcd] = 0u;   // the pixel cursor of this XCD's persistent multi-bounce waves (indirectMultiBouncePersistent)
 }
 
 // ReSTIRIndirect, indirect_stage.comp:228-268 (+ findTemporalNeighbor :74-108): temporal lookup, reservoir update, shading
@@ -692,6 +693,162 @@ RT_DEV void indirectSingleBounceTiles(const DevScene& S, const DevFrame& F, cons
   flushCounters(F, c);
 }
 
+// ---- multi-bounce tiles, persistent waves with per-lane path regeneration (round 6) ---------------------------------------------------------------
+// A wave that owns ONE multi-bounce tile traces its paths vertex by vertex: 64 + 0 rays at the first vertex, then whatever survived — the pool runs dry (round 5:
+// 47 % of the traversal rounds of the stage executed <= 8 lanes, 36 % had <= 8 LIVE lanes; ordering the pool did nothing, profiles/r05_pool_order_ab.txt).  Here a
+// wave is not tied to a tile: a lane whose path has ended finishes its pixel (ReSTIRIndirect + the stores are per pixel, seeds are per pixel) and takes the next
+// pixel of its XCD's multi-bounce list from an atomic cursor, so every vertex round of the wave parks rays for (nearly) all 64 lanes — lanes sit at different depths
+// of different pixels.  No ray queue in HBM (the wavefront organisation that lost in round 1): a path lives in its lane's registers from its first vertex to its
+// reservoir.  Per path the arithmetic and the order of the RNG draws are those of the generic body below, hence the same bits.  `persist` tiles' worth of pixels per
+// wave (RESTIR_IND_PERSIST; 0 = the generic body).
+RT_DEV void indirectMultiBouncePersistent(const DevScene& S, const DevFrame& F, const rt_state& st, const rt_scene_camera& cam, int rowBegin, int rowEnd, int tilesX,
+                                          const uint32_t* list /* this XCD's multi-bounce tiles */, int nTiles, uint32_t* cursor, uint2* s_stack)
+{
+  const int lane = int(threadIdx.x);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const i2 indSize{st.size.x / 2, st.size.y / 2};
+  float4* pool = reinterpret_cast<float4*>(s_stack + size_t(S.stackEntries) * 64);
+#if RT_WAVEPROF
+  const uint64_t prof_c0 = clock64(), prof_w0 = wall_clock64();
+#endif
+  Ctx c(S, st, cam, s_stack + lane);
+  const uint32_t total = uint32_t(nTiles) * 64u;
+  // the path a lane carries between two vertex rounds
+  bool have = false, alive = false;      // have: the lane owns a pixel with a surface; alive: its path goes on
+  i2 px{0, 0};
+  int depthI = 1;
+  f3 throughput = mk3(4.0f);
+  Ray ray{mk3(0.0f), mk3(0.0f)};
+  rt_gi_sample gi = newGISample();
+  float primSamplePdf = 0.0f;
+  f3 vPos = mk3(0.0f), vFfn = mk3(0.0f);  // the vertex: position (primary: offset along its normal, :299), shading normal, material
+  Material vMat; vMat.albedo = vMat.emission = mk3(0.0f); vMat.metallic = vMat.ior = vMat.roughness = vMat.transmission = 0.0f;
+  bool exhausted = false;                 // wave-uniform: the cursor has passed the end of the list
+  for(;;) {
+    // ---- 1. lanes without a path take the next pixels of the list (again while pixels without a surface — sky — leave lanes empty) ----------------------------
+    while(!exhausted) {
+      const unsigned long long needM = __ballot(have ? 0 : 1);
+      if(needM == 0ull) break;
+      const int nNeed = __popcll(needM);
+      uint32_t base = 0u;
+      if(lane == __builtin_ctzll(needM)) base = atomicAdd(cursor, uint32_t(nNeed));
+      base = uint32_t(__builtin_amdgcn_readlane(int(base), __builtin_ctzll(needM)));
+      if(base + uint32_t(nNeed) >= total) exhausted = true;
+      const uint32_t idx = base + uint32_t(__popcll(needM & lt));
+      if(!have && idx < total) {
+        const int t = int(list[idx >> 6]), it = int(idx & 63u);
+        const int ty = t / tilesX, tx = t - ty * tilesX;
+        px = i2{tx * 8 + (it & 7), rowBegin + ty * 8 + (it >> 3)};
+        c.seed = tea(uint32_t(indSize.x) * uint32_t(px.y) + uint32_t(px.x), st.time);  // :280
+        c.imageCoords = px;
+        if(it == 0) (void)rnd(c.seed);  // invocation 0 of the workgroup drew the tile flag from its own stream (:283-288); the flag is known here (the list)
+        const bool inImage = !(px.x >= indSize.x || px.y >= indSize.y || px.y >= rowEnd);
+        if(inImage) {
+          ray = c.raySpawn(px, indSize);
+          GState g0; float depth;
+          if(stateFromGBuffer(loadG(F.thisG, F, i2{px.x * 2, px.y * 2}), ray, g0, depth)) {
+            have = true; alive = st.maxDepth >= 1;   // (the depth loop of :129-226 does not run at all with maxDepth 0)
+            depthI = 1;
+            throughput = mk3(4.0f);
+            gi = newGISample();
+            primSamplePdf = 0.0f;
+            vPos = g0.position + g0.ffnormal * 2e-2f;  // :299
+            vFfn = g0.ffnormal; vMat = g0.mat; vMat.albedo = mk3(1.0f);
+          } else storeImg(F.denoiseIndA, F, px, mk4(0, 0, 0, 0));
+        }
+      }
+    }
+    if(__ballot(have ? 1 : 0) == 0ull) break;
+    // ---- 2. one path vertex per lane (pathTraceIndirect, :129-226; the body of the generic kernel's depth loop) ------------------------------------------------
+    bool hasShadow = false, hasBounce = false;
+    f3 pendingAdd = mk3(0.0f), sampleWi = mk3(0.0f);
+    float samplePdf = 0.0f;
+    if(alive) {
+      const f3 wo = -ray.direction;
+      if(depthI > 1 && st.MIS > 0) {  // SampleDirectLight (pathtrace.glsl:185-203) minus its visibility test
+        rt_light_sample ls;
+        const float lightPdf = c.SampleDirectLightNoVisibility(vPos, ls);
+        if(!Ctx::IsPdfInvalid(lightPdf)) {
+          const f3 wi = mk3(ls.wi);
+          const f3 so = OffsetRay(vPos, vFfn);
+          const float maxDist = ((ls.dist - rt_abs(so.x - vPos.x)) - rt_abs(so.y - vPos.y)) - rt_abs(so.z - vPos.z);  // Occlusion :18-22
+          c.nAny++;
+          poolPut(pool, lane * 2 + 1, so, wi, maxDist, c.seed);
+          hasShadow = true;
+          const float BSDFPdf = metallicWorkflowPdf(vMat, vFfn, wo, wi);
+          const float weight = MISw(st, lightPdf, BSDFPdf);
+          pendingAdd = mk3(ls.Li) * metallicWorkflowBSDF(vMat, vFfn, wo, wi) * absDot(vFfn, wi) * throughput / lightPdf * weight;
+        }
+      }
+      const f3 sampleBSDF = c.Sample(vMat, wo, vFfn, sampleWi, samplePdf);
+      if(Ctx::IsPdfInvalid(samplePdf)) alive = false;
+      else {
+        if(depthI > 1) throughput *= sampleBSDF / samplePdf * absDot(vFfn, sampleWi);
+        else {
+          primSamplePdf = samplePdf;
+          gi.xv = toR(vPos);
+          gi.nv = toR(vFfn);
+        }
+        ray.origin = OffsetRay(vPos, vFfn);
+        ray.direction = sampleWi;
+        c.nClosest++;
+        poolPut(pool, lane * 2, ray.origin, ray.direction, RT_INFINITY, c.seed);
+        hasBounce = true;
+      }
+    }
+    // ---- 3. the wave's rays -------------------------------------------------------------------------------------------------------------------------------------
+    tracePool(S, pool, hasBounce, hasShadow, c.stack, c.tc);   // (returns at once when nothing was parked)
+    // ---- 4. results, in the reference's order ---------------------------------------------------------------------------------------------------------------------
+    if(hasShadow && poolGet(pool, lane * 2 + 1).gid == 0xffffffffu) gi.L = toR(mk3(gi.L) + pendingAdd);  // not occluded
+    if(hasBounce) {
+      c.hit = poolGet(pool, lane * 2);
+      if(c.hit.t >= RT_INFINITY - 1e-4f) {
+        if(depthI > 1) {
+          float lightPdf;
+          const f3 Li = c.EnvEval(sampleWi, lightPdf);
+          const float weight = MISw(st, samplePdf, lightPdf);
+          gi.L = toR(mk3(gi.L) + Li * throughput * weight);
+        } else {
+          gi.xs = toR(vPos + sampleWi * RT_INFINITY * 0.8f);
+          gi.ns = toR(-sampleWi);
+        }
+        alive = false;
+      } else {
+        State state = c.GetState(ray.direction);
+        c.GetMaterials(state, ray);
+        if(state.isEmitter) {
+          if(depthI > 1) {
+            float lightPdf;
+            const f3 Li = c.LightEval(state, c.hit.t, sampleWi, lightPdf);
+            const float weight = MISw(st, samplePdf, lightPdf);
+            gi.L = toR(mk3(gi.L) + Li * throughput * weight);
+          } else {
+            gi.xs = toR(state.position);
+            gi.ns = toR(state.ffnormal);
+          }
+          alive = false;
+        } else if(depthI == 1) { gi.xs = toR(state.position); gi.ns = toR(state.ffnormal); }
+        vPos = state.position; vFfn = state.ffnormal; vMat = state.mat;
+      }
+    }
+    // Russian roulette (:218-224) is compiled out in the reference (`#ifndef RR`, pathtrace.glsl:2)
+    if(alive) { depthI++; if(depthI > st.maxDepth) alive = false; }
+    // ---- 5. paths that ended: ReSTIRIndirect of their pixel; the lane is free for the next one -----------------------------------------------------------------------
+    if(have && !alive) {
+      const Ray ray0 = c.raySpawn(px, indSize);
+      GState primState; float depth;
+      stateFromGBuffer(loadG(F.thisG, F, i2{px.x * 2, px.y * 2}), ray0, primState, depth);
+      primState.position += primState.ffnormal * 2e-2f;
+      restirIndirectFinish(c, F, st, cam, px, indSize, primState, -ray0.direction, gi, primSamplePdf);
+      have = false;
+    }
+  }
+#if RT_WAVEPROF
+  waveProfFlush(F, c, int(blockIdx.x & 0xffff) | 0x10000, 0, prof_c0, prof_w0);
+#endif
+  flushCounters(F, c);
+}
+
 #endif  // !RT_LAT
 
 // 5 waves/SIMD (96 VGPRs, a few more spills) instead of 4: the stage alone is no faster, but with frames in flight its waves
@@ -699,16 +856,19 @@ RT_DEV void indirectSingleBounceTiles(const DevScene& S, const DevFrame& F, cons
 #ifndef RT_INDIRECT_LB
 #define RT_INDIRECT_LB 5
 #endif
+#ifndef RT_IND_PERSIST_DEFAULT
+#define RT_IND_PERSIST_DEFAULT 0
+#endif
 #if RT_LAT
 // latency build: a workgroup of NW waves per half-res tile; wave 0 runs the paths of the 64 pixels (the body below), the other waves only serve the
 // workgroup's ray pool: after every path vertex wave 0 lists the vertex's rays, all waves trace them eight lanes per ray, wave 0 goes on shading
 // (4 waves per SIMD = 128 VGPRs: two of these workgroups per CU, and beside one of them two direct-stage waves per SIMD — with 165 registers the next
 //  frame's direct stage, which runs beside this kernel when frames are in flight, had one wave slot per SIMD left: profiles/r03_mgpu_period_ab.txt)
 __global__ __launch_bounds__(512, 4) void k_indirect_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY, int cap,
-                                                       const uint32_t* lists, const uint32_t* counts, int subShift, int sbK, int genericBlocks)
+                                                       const uint32_t* lists, uint32_t* counts, int subShift, int sbK, int genericBlocks, int persist)
 #else
 __global__ __launch_bounds__(64, RT_INDIRECT_LB) void k_indirect_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY, int cap,
-                                                          const uint32_t* lists, const uint32_t* counts, int subShift, int sbK, int genericBlocks)
+                                                          const uint32_t* lists, uint32_t* counts, int subShift, int sbK, int genericBlocks, int persist)
 #endif
 {
   // subShift > 0 (small launches: row bands of a multi-GPU frame, small images): a tile is split over 2 or 4 waves that own
@@ -735,7 +895,13 @@ __global__ __launch_bounds__(64, RT_INDIRECT_LB) void k_indirect_stage(DevScene 
       else indirectSingleBounceTiles<2>(S, F, st, cam, rowBegin, rowEnd, tilesX, t, n, s_stack);  // (4 per wave was measured: slower, spills)
       return;
     }
+    if(sbK > 0 && persist > 0) {  // multi-bounce tiles of this XCD: persistent waves, `persist` tiles' worth of pixels each, paths regenerated per lane
+      if((L >> 3) * persist >= nf) return;
+      indirectMultiBouncePersistent(S, F, st, cam, rowBegin, rowEnd, tilesX, lists + size_t(xcd) * cap, nf, counts + 16 + xcd, s_stack);
+      return;
+    }
 #endif
+    (void)persist;
     const int k = (L >> 3) >> subShift;
     tile.valid = sbK > 0 ? (k < nf) : (k < nf + nb);
     const uint32_t t = tile.valid ? lists[size_t(xcd) * cap + (k < nf ? k : cap - 1 - (k - nf))] : 0u;
@@ -1292,7 +1458,7 @@ hipError_t launchStage(hipStream_t stream, const DevScene& Sin, const DevFrame& 
 #if RT_LAT
       // one workgroup per tile, multi-bounce tiles first (same lists)
       hipLaunchKernelGGL(k_indirect_stage, grid, dim3(64 * nWaves), wideLdsBytes(S.stackEntries, nWaves), stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY, cap,
-                         (const uint32_t*)F.tileOrder, (const uint32_t*)(F.qcount + 192), 0, 0, int(grid.x));
+                         (const uint32_t*)F.tileOrder, F.qcount + 192, 0, 0, int(grid.x), 0);
 #else
       // under ~2 waves per SIMD (1024 SIMDs) the launch is latency bound: split tiles over more waves
       static const int subEnv = getenv("RESTIR_IND_SUB") ? atoi(getenv("RESTIR_IND_SUB")) : -1;
@@ -1305,8 +1471,13 @@ hipError_t launchStage(hipStream_t stream, const DevScene& Sin, const DevFrame& 
       const unsigned sbBlocks = sbK > 0 ? 8u * unsigned((cap + sbK - 1) / sbK) : 0u;
       const size_t poolBytes = std::max<size_t>(POOL_BYTES, size_t(sbK) * 64 * 33);
       if(needOvf && (genericBlocks + sbBlocks) * 64u > S.stackOvfThreads) return hipErrorInvalidConfiguration;
+      // multi-bounce tiles of large launches: persistent waves with per-lane path regeneration, RESTIR_IND_PERSIST tiles' worth of pixels per wave (0 = one wave per tile,
+      // the generic body; profiles/r06_indirect_persistent_ab.txt)
+      const char* pe = getenv("RESTIR_IND_PERSIST");   // (read per launch: the parity tests switch it inside one process)
+      const int persistEnv = pe ? std::max(0, std::min(16, atoi(pe))) : RT_IND_PERSIST_DEFAULT;
+      const int persist = sbK > 0 ? persistEnv : 0;
       hipLaunchKernelGGL(k_indirect_stage, dim3(genericBlocks + sbBlocks), block, lds + poolBytes, stream, S, F, st, cam, rowBegin, rowEnd, tilesX, tilesY, cap,
-                         (const uint32_t*)F.tileOrder, (const uint32_t*)(F.qcount + 192), subShift, sbK, int(genericBlocks));
+                         (const uint32_t*)F.tileOrder, F.qcount + 192, subShift, sbK, int(genericBlocks), persist);
 #endif
       break;
     }

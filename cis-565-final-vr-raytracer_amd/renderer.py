@@ -11,6 +11,7 @@ from . import abi
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.environ.get("RESTIR_HIP_LIB") or os.path.join(_HERE, "csrc", "librestir_hip.so")  # env override: A/B builds
 _lib = None
+PRIO_FILTER_SHARE = 0.20   # the threshold of rt_render_frame's stream-priority rule (csrc/rt_api.cpp PRIO_FILTER_SHARE; profiles/r06_prio_rule.txt) — for reports and tests
 
 # every symbol include/rt_abi.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_build_accel", "rt_resize", "rt_set_camera",
@@ -84,9 +85,10 @@ def hip_lib():
         L.rt_mgpu_plan_bands.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.rt_set_stream_priorities.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.rt_get_stream_priorities.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.rt_get_streams.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
-        L.rt_get_stream_layout.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int * 3)]
-        L.rt_mgpu_get_stream_layout.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
+        if hasattr(L, "rt_get_streams"):   # (absent from the library round 5 shipped, which scripts/ab_libs2.sh loads through RESTIR_HIP_LIB for same-box A/Bs)
+            L.rt_get_streams.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+            L.rt_get_stream_layout.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int * 3)]
+            L.rt_mgpu_get_stream_layout.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
         L.rt_accel_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
         L.rt_accel_quality.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _lib = L

@@ -273,3 +273,21 @@ def test_cpp_demo_application_matches_python_host(tmp_path):
     assert np.array_equal((d[..., :3] + i[..., :3]).view(np.uint32), hdr.view(np.uint32))
     r.tonemap(abi.Tonemapper(), 0, N - 1)
     assert np.array_equal(r.readback(abi.BUF_LDR).reshape(H, W, 4)[..., :3], ldr)
+
+
+@pytest.mark.parametrize("persist", [1, 2, 3, 5])
+def test_persistent_multibounce_waves_bit_exact(persist, monkeypatch):
+    """Round 6: the multi-bounce tiles of LARGE indirect launches (> 3072 half-res tiles: the three-tiles-per-wave single-bounce body + persistent waves that regenerate a
+    path per lane from their XCD's tile list, csrc/stages.hip indirectMultiBouncePersistent) against the oracle: full frames of 1040 x 784 (65 x 49 half-res tiles), maxDepth 4,
+    temporal reuse under a moving camera, a scene with sky pixels (lanes that pull a pixel without a surface), RESTIR_IND_PERSIST tiles' worth of pixels per wave."""
+    monkeypatch.setenv("RESTIR_IND_PERSIST", str(persist))
+    W, H = 1040, 784
+    sc, env = make_scene(abi.PROC_BISTRO_EXT_REAL, 0.01, 1, (256, 128))
+    st = host.default_state(W, H, sc, env)
+    st.maxDepth = 4
+    o, r = _pair(sc, env, W, H, latency=False)
+    stages = [(abi.STAGE_DIRECT, 0), (abi.STAGE_INDIRECT, 0)]      # (the filters do not depend on how the indirect stage is organised: the traced stages' buffers are compared)
+    bufs = lambda f: [abi.BUF_GBUFFER0 + (f & 1), abi.BUF_MOTION, abi.BUF_DIRECT_RESV0 + (f & 1), abi.BUF_INDIRECT_RESV0 + (f & 1), abi.BUF_DENOISE_IND_A]   # noqa: E731
+    _run(sc, st, o, r, W, H, 3, moving=True, stages=stages, buffers=bufs)
+    img = r.readback(abi.BUF_DENOISE_IND_A).view(np.float32)
+    assert np.isfinite(img).all() and img.max() > 0.0

@@ -33,7 +33,8 @@ def test_probe_frame_rule_decides_and_reports(monkeypatch):
     _, (before, after) = _render(lambda r, st: None)
     assert before["decided"] is False and before["filter_share"] is None
     assert after["decided"] is True and after["filter_share"] is not None and after["filter_share"] > 0
-    assert after["chosen"] == [1, 1 if after["filter_share"] >= 0.14 else 0]
+    from restir_amd.renderer import PRIO_FILTER_SHARE
+    assert after["chosen"] == [1, 1 if after["filter_share"] >= PRIO_FILTER_SHARE else 0]
     # two frames are not enough: the third probe frame decides (warm history), and only then do the two other streams exist
     _, (_, mid) = _render(lambda r, st: None, frames=2)
     assert mid["decided"] is False and mid["filter_share"] is not None
@@ -55,7 +56,8 @@ def test_resize_and_denoise_toggle_reopen_the_decision(monkeypatch):
     st.denoise = 0
     frames(4)
     off = r.stream_priorities()
-    assert off["decided"] and off["filter_share"] < 0.14 and off["chosen"] == [1, 0]      # compose alone is a few percent of the traced stages
+    from restir_amd.renderer import PRIO_FILTER_SHARE
+    assert off["decided"] and off["filter_share"] < PRIO_FILTER_SHARE and off["chosen"] == [1, 0]      # compose alone is a few percent of the traced stages
     st.denoise = 1
     frames(1)
     assert r.stream_priorities()["decided"] is False                                        # re-opened by the toggle: probing again
