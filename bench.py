@@ -187,6 +187,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", type=int, default=4, choices=[2, 3, 4, 5], help="BASELINE.json / SURVEY.md 8(d) configuration (4 = the headline workload)")
     ap.add_argument("--moving-camera", action="store_true", help="the camera orbits its centre of interest by 0.5 degrees per frame (always on for --config 5)")
+    ap.add_argument("--via-gltf", action="store_true", help="N = 1: the scene goes through the reference's entry point — it is written as a glTF asset (Scene::saveGltf: .gltf + .bin + "
+                    "one PNG per image), read back by Scene::load (host/gltf_loader.cpp <-> src/scene.cpp:57-125), the digest of everything rt_upload_scene reads is compared with the "
+                    "procedural scene's, the LOADED scene is what the line times, and three cold-history frames of both are compared buffer by buffer; load seconds and peak RSS in the line")
     ap.add_argument("--pose", type=int, default=0, choices=[0, 1, 2], help="config 4: fixed camera pose (0 = the scene's own, end-on down the street; 1 = orbited 15 degrees; 2 = elevated, across the street)")
     ap.add_argument("--scene-footprint", choices=["lite", "real"], default=os.environ.get("RESTIR_SCENE_FOOTPRINT", DEFAULT_FOOTPRINT),
                     help="configs 3 / 4: `real` = the texture / material / triangle-shape footprint of the asset the procedural scene stands in for (see scene_kind); "
@@ -306,6 +309,9 @@ def main():
         setattr(st, k, v)
     di_only = cfg.get("di_only", False)
     desc = scene.desc(env)
+    via = None
+    if args.via_gltf and world == 1 and args.emulate_world <= 1:
+        via, scene, desc = via_gltf(args, abi, host, Renderer, scene, env, st, W, H)
     if world == 1 and args.emulate_world > 1 and args.emulate_child:
         return emulate_child(args, abi, host, scene, env, st, desc, r, W, H, local_rank)
     t0 = time.time()
@@ -474,6 +480,16 @@ def main():
                               "median over the frames of a separate pass; frame_latency_ms = first launch to last launch of one frame while frames are in flight")
         if sustained:
             out["sustained"] = sustained
+        if via is not None:
+            # the frames of the loaded scene against the procedural scene's (reference digests taken before the run): three frames from a cold history, all six buffers
+            from restir_amd import verify as V
+            r.sync(); r.update(W, H)
+            V.render_untiled(r.run, r.set_camera, via.pop("_cams"), st); r.sync()
+            got = V.digests(r.readback, 0)
+            ref = via.pop("_frame_digests")
+            via["frames_equal"] = got == ref
+            via["frame_digests"] = {"procedural": ref, "loaded": got}
+            out["via_gltf"] = via
         if world == 1 and not di_only:
             sp = r.stream_priorities()
             from restir_amd.renderer import PRIO_FILTER_SHARE
@@ -661,6 +677,51 @@ def main():
         print(json.dumps(out), flush=True)
         if world > 1 and out.get("tiled_equals_untiled") is False:
             raise SystemExit(3)             # a number for a wrong image is not a result
+
+
+def via_gltf(args, abi, host, Renderer, scene, env, st, W, H):
+    """--via-gltf: write the procedural scene as a glTF asset, read it back through Scene::load, hold the loaded scene to the procedural one (digest of every array
+    rt_upload_scene reads; reference frame digests rendered here from the procedural scene, compared after the run with the loaded scene's).  Returns (report, loaded scene,
+    its description): the bench line then times the LOADED scene."""
+    import resource
+    import shutil
+    import tempfile
+    from restir_amd import verify as V
+    d = tempfile.mkdtemp(prefix="restir_gltf_")
+    path = os.path.join(d, "scene.gltf")
+    rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
+    t0 = time.time()
+    if not scene.saveGltf(path):
+        raise SystemExit("--via-gltf: Scene::saveGltf failed")
+    save_s = time.time() - t0
+    files = os.listdir(d)
+    disk = sum(os.path.getsize(os.path.join(d, f)) for f in files)
+    ref_digest = host.scene_digest(scene.desc(env))
+    # reference frames from the procedural scene: three frames, cold history, the run's first camera
+    pose = scene.cameraPose()
+    scene.updateCamera(W, H)
+    cams = V.verify_cameras(scene, W, H, pose, False, 3)
+    r0 = Renderer().setup(0); r0.load_scene(scene.desc(env)); r0.update(W, H)
+    st0 = type(st).from_buffer_copy(st)
+    V.render_untiled(r0.run, r0.set_camera, cams, st0); r0.sync()
+    frame_ref = V.digests(r0.readback, 0)
+    r0.destroy()
+    stat_ref = scene.getStat()
+    loaded = host.Scene()
+    t0 = time.time()
+    if not loaded.load(path):
+        raise SystemExit("--via-gltf: Scene::load failed")
+    load_s = time.time() - t0
+    rss1 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
+    shutil.rmtree(d, ignore_errors=True)
+    loaded.setCamera(*pose)      # (a glTF camera node stores a matrix, not eye / centre of interest: the pose is carried over so that the frames can be compared bit for bit)
+    desc = loaded.desc(env)
+    dig = host.scene_digest(desc)
+    rep = {"path": "Scene::saveGltf -> .gltf + .bin + one PNG per image -> Scene::load (host/gltf_loader.cpp)", "files": len(files), "bytes_on_disk": disk,
+           "save_s": round(save_s, 2), "load_s": round(load_s, 2), "peak_rss_gb_before_save": round(rss0, 2), "peak_rss_gb_after_load": round(rss1, 2),
+           "stats_equal": loaded.getStat() == stat_ref, "scene_digest_equal": dig == ref_digest, "scene_digest": {"procedural": ref_digest["all"], "loaded": dig["all"]},
+           "parts_differing": [k for k in ref_digest if ref_digest[k] != dig[k]], "_frame_digests": frame_ref, "_cams": cams}
+    return rep, loaded, desc
 
 
 def peer_matrix(torch, n):

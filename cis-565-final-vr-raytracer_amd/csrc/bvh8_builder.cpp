@@ -239,12 +239,14 @@ struct BuilderS {
     void reset(int nb, int nbs) { for(int a = 0; a < 3; a++) { for(int i = 0; i < nb; i++) { ob[a][i].reset(); oc[a][i] = 0; } for(int i = 0; i < nbs; i++) { sb[a][i].reset(); en[a][i] = ex[a][i] = 0; } } }
     void merge(const Bins& o, int nb, int nbs) { for(int a = 0; a < 3; a++) { for(int i = 0; i < nb; i++) { ob[a][i].grow(o.ob[a][i]); oc[a][i] += o.oc[a][i]; } for(int i = 0; i < nbs; i++) { sb[a][i].grow(o.sb[a][i]); en[a][i] += o.en[a][i]; ex[a][i] += o.ex[a][i]; } } }
   };
-  void binRefs(const Ref* r, size_t count, const Box& nb, const Box& cb, bool spatial, Bins& B) const
+  // which: 1 = the object bins, 2 = the spatial bins (a second pass, only for the nodes whose object split leaves its children overlapping: it clips every straddling
+  // reference per bin — until round 6's first restructuring merged the two passes, and with a working budget that is never exhausted EVERY node paid for it)
+  void binRefs(const Ref* r, size_t count, const Box& nb, const Box& cb, int which, Bins& B) const
   {
     float k1o[3], k1s[3], w[3]; bool okO[3], okS[3];
     for(int ax = 0; ax < 3; ax++) {
       const float extO = cb.hi[ax] - cb.lo[ax], extS = nb.hi[ax] - nb.lo[ax];
-      okO[ax] = extO > 0; okS[ax] = spatial && extS > 0;
+      okO[ax] = which == 1 && extO > 0; okS[ax] = which == 2 && extS > 0;
       k1o[ax] = okO[ax] ? NB * (1.f - 1e-6f) / extO : 0.f;
       k1s[ax] = okS[ax] ? NBS * (1.f - 1e-6f) / extS : 0.f; w[ax] = extS / NBS;
     }
@@ -280,7 +282,7 @@ struct BuilderS {
       const uint32_t cnt = uint32_t(refs.size());
       if(!pool && cnt <= SEQ_MAX) { own.budget = budget; own.nextNode = nodeBase; own.nextLeaf = leafBase; pool = &own; }   // from here down: one thread, pooled budget
       if(pool) budget = pool->budget;
-      const int par = cnt >= PAR_MIN ? std::max(1, maxThreads) : 1;
+      const int par = cnt >= PAR_MIN ? std::max(1, std::min(maxThreads, 32)) : 1;   // (a node has cnt / PAR_CHUNK chunks: 43 at the root of the benchmark scene)
       Box nb, cb; nb.reset(); cb.reset();
       if(par > 1) {
         const size_t nch = (cnt + PAR_CHUNK - 1) / PAR_CHUNK;
@@ -297,17 +299,19 @@ struct BuilderS {
       for(int a = 0; a < 3; a++) { N.b.lo[a] -= pad; N.b.hi[a] += pad; }
       auto leafHere = [&] { if(pool) { makeLeaf(N, refs, pool->nextLeaf); pool->nextLeaf += cnt; } else makeLeaf(N, refs, leafBase); };
       if(cnt <= 1) { leafHere(); return; }
-      // ---- one pass over the references: object bins on the centroids (the rule of Builder2) and, while references may be added, spatial bins ----
+      // ---- object bins on the reference centroids (the rule of Builder2) ----
       const bool mayAdd = budget > 0;
-      std::unique_ptr<Bins> binsHeap(new Bins);
-      Bins& B = *binsHeap;
+      Bins B;   // (on the stack: 23 KB; the recursion is as deep as the tree)
       B.reset(NB, NBS);
-      if(par > 1) {
-        const size_t nch = (cnt + PAR_CHUNK - 1) / PAR_CHUNK;
-        std::vector<std::unique_ptr<Bins>> part(nch);
-        parallelChunks(cnt, PAR_CHUNK, par, [&](size_t c, size_t b, size_t e) { part[c].reset(new Bins); part[c]->reset(NB, NBS); binRefs(refs.data() + b, e - b, nb, cb, mayAdd, *part[c]); });
-        for(size_t c = 0; c < nch; c++) B.merge(*part[c], NB, NBS);
-      } else binRefs(refs.data(), cnt, nb, cb, mayAdd, B);
+      auto binAll = [&](int which) {
+        if(par > 1) {
+          const size_t nch = (cnt + PAR_CHUNK - 1) / PAR_CHUNK;
+          std::vector<std::unique_ptr<Bins>> part(nch);
+          parallelChunks(cnt, PAR_CHUNK, par, [&](size_t c, size_t b, size_t e) { part[c].reset(new Bins); part[c]->reset(NB, NBS); binRefs(refs.data() + b, e - b, nb, cb, which, *part[c]); });
+          for(size_t c = 0; c < nch; c++) B.merge(*part[c], NB, NBS);
+        } else binRefs(refs.data(), cnt, nb, cb, which, B);
+      };
+      binAll(1);
       // ---- object split ----
       float best = 3e38f; int bestAxis = -1, bestBin = 0; Box bestL, bestR;
       for(int ax = 0; ax < 3; ax++) {
@@ -335,6 +339,7 @@ struct BuilderS {
         trySpatial = ov.area() > alpha * rootArea;   // (area() is 0 for an empty intersection)
       }
       if(trySpatial) {
+        binAll(2);
         for(int ax = 0; ax < 3; ax++) {
           const float lo = nb.lo[ax], ext = nb.hi[ax] - nb.lo[ax];
           if(!(ext > 0)) continue;
@@ -412,7 +417,7 @@ struct BuilderS {
       const uint32_t lNodes = uint32_t(2 * (int64_t(left.size()) + bl) - 2), lLeaves = uint32_t(int64_t(left.size()) + bl);
       N.leaf = false; N.a = child; N.n = 0;
       const uint32_t lBase = nodeBase + 2, rBase = nodeBase + 2 + lNodes, lLeaf = leafBase, rLeaf = leafBase + lLeaves;
-      if(liveThreads.load() < 4 * maxThreads) {   // (most of these threads wait in join() for their children: more threads than cores)
+      if(liveThreads.load() < 2 * maxThreads) {   // (half of these threads wait in join() for their children)
         liveThreads++;
         std::thread th([this, child, bl, lBase, lLeaf, l = std::move(left)]() mutable { build(child, std::move(l), bl, lBase, lLeaf); liveThreads--; });
         build(child + 1, std::move(right), br, rBase, rLeaf);

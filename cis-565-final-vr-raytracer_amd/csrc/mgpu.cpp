@@ -51,6 +51,10 @@
 // rt_create with explicit stream levels (csrc/rt_api.cpp; internal, not part of the C ABI)
 int rtCreateWithLevels(rt_ctx** out, int device, const int* levels);
 
+#ifndef RT_TEST_HOOKS
+#define RT_TEST_HOOKS 0
+#endif
+
 namespace {
 
 // default levels of a rank's main / indirect / filter stream (RESTIR_MGPU_PRIO overrides): rt_mgpu_create
@@ -238,8 +242,10 @@ void pullRowsOn(rt_mgpu& M, Rank& R, hipStream_t strm, int buf, int a, int b, co
     else MG_HIP(hipMemcpyPeerAsync(static_cast<char*>(dst) + off, R.dev, static_cast<char*>(src) + off, Q.dev, len, strm), "hipMemcpyPeerAsync");
     (R.accSlot >= 0 ? R.pulledBy[R.accSlot] : R.pulled)[kind] += len;
     if(R.grp >= 0) R.grpBytes[R.grpSlot][R.grp] += len;
+#if RT_TEST_HOOKS
     if(M.corruptHalo && kind == HK_FILTER && (buf == RT_BUF_DIRECT_RESULT0 || buf == RT_BUF_DIRECT_RESULT1))
       MG_HIP(hipMemsetAsync(static_cast<char*>(dst) + off, 0x3f, std::min<size_t>(len, 1024), strm), "hipMemsetAsync (test hook)");
+#endif
   }
 }
 void pullRows(rt_mgpu& M, Rank& R, int buf, int a, int b, const std::vector<int>& part, int kind) { pullRowsOn(M, R, R.stream, buf, a, b, part.data(), kind); }
@@ -877,7 +883,10 @@ int rt_mgpu_create(rt_mgpu** out, int numRanks, const int* devices)
   rt_mgpu* M = new(std::nothrow) rt_mgpu();
   if(!M) return RT_ERR_OOM;
   M->n = numRanks;
+#if RT_TEST_HOOKS   // (compiled into measurement / test builds only — restir_amd.build.build_hip(variant="testhooks", extra_flags=["-DRT_TEST_HOOKS=1"]): the product library cannot
+                    //  be told to damage live halo data through an environment variable; advisor finding of round 5)
   if(const char* e = getenv("RESTIR_TEST_CORRUPT_HALO")) M->corruptHalo = e[0] == '1';
+#endif
   M->ranks = std::vector<Rank>(size_t(numRanks));
   auto bail = [&](int rc) { for(Rank& R : M->ranks) destroyRank(R); delete M; return rc; };
   for(int r = 0; r < numRanks; r++) {

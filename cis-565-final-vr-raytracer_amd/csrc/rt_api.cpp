@@ -770,7 +770,7 @@ static hipError_t ensureOverlapStreams(rt_ctx* c)
 }
 
 // The rule of rt_render_frame's probe frames (see there).  RESTIR_PRIO_PROBE = number of probe frames (default 3; 1 = round 5's first-frame decision).
-static constexpr float PRIO_FILTER_SHARE = 0.20f;   // (restir_amd/renderer.py mirrors it for reports)
+static constexpr float PRIO_FILTER_SHARE = 0.30f;   // (restir_amd/renderer.py mirrors it for reports)
 static int prioProbeFrames() { static const int n = getenv("RESTIR_PRIO_PROBE") ? std::max(1, atoi(getenv("RESTIR_PRIO_PROBE"))) : 3; return n; }
 // what the decision was taken on has changed (target size, scene, tree, denoise toggle): the next frames probe again.  The streams of the old levels stay alive, idle
 // (one per role and level, never destroyed: see rt_ctx::indStreams); the caller has drained the context.
@@ -859,12 +859,15 @@ int rt_render_frame(rt_ctx* c, const rt_state* st, int frames)
   }
   // The first PRIO_PROBE_FRAMES frames of a frames-in-flight context ("probe frames") run every stage alone on the main stream and are timed; the LAST of them — warm
   // caches, warm history, the steady state's ray lengths — decides the priorities of the two other streams BEFORE they are created (below): filter stream high as
-  // well when the filter chain is a sizeable part of the frame's work.  Round 5 decided on frame 0 alone (cold history: first-frame shares 0.12 real exterior scene /
-  // 0.16 lite / 0.25 config 3 / 0.34 config 5 against a threshold of 0.14 — the real scene sat 10 % from the edge); the warm shares and the margins are in
-  // profiles/r06_prio_rule.txt.  The decision has to precede the streams: a stream's place in the process's creation order changes what the schedule gets out of it (a
-  // setting introduced after another one's streams exist ran 15-45 % slower than in a fresh process, profiles/r05_prio_by_config_ab.txt), so settings cannot be
-  // compared in place.  A new target size, a new scene / tree or a denoise toggle re-opens the decision (reopenPriorityDecision); an explicit
-  // rt_set_stream_priorities / RESTIR_PRIO closes it for good.
+  // well when the filter chain is a sizeable part of the frame's work.  Round 5 decided on frame 0 alone (cold history; threshold 0.14 with the real scene 10 % from
+  // the edge).  Warm shares and the setting that is fastest (profiles/r06_prio_rule.txt, every cell a fresh process): real exterior scene 0.16 -> (1,0); the same scene
+  // seen from above across the street 0.26 -> (1,0) by 5 %; lite 0.24 -> (1,1) by 1.6 %; interior 4K 0.41, 15 degrees off axis 0.43, config 3 0.53 -> (1,1) by 6-9 %.
+  // No threshold gets lite and the elevated view both right; 0.30 errs towards the indirect stream alone, which costs 1.6 % where it is wrong (0.20 cost 4.9 %).  A camera
+  // that starts at the expensive pose and moves off it (bench.py --moving-camera) is judged on its first three frames and keeps (1,0): 2.9 % slower than (1,1) once the
+  // view has become cheap — a host that knows its workload says so (rt_set_stream_priorities).  The decision has to precede the streams: a stream's place in the process's
+  // creation order changes what the schedule gets out of it (a setting introduced after another one's streams exist ran 15-45 % slower than in a fresh process,
+  // profiles/r05_prio_by_config_ab.txt), so settings cannot be compared in place — and cannot be switched later for free either.  A new target size, a new scene / tree
+  // or a denoise toggle re-opens the decision (reopenPriorityDecision); an explicit rt_set_stream_priorities / RESTIR_PRIO closes it for good.
   if(c->prioDecided && !c->prioExplicit && !c->prioFromEnv && c->denoiseSeen >= 0 && (st->denoise > 0) != (c->denoiseSeen > 0)) { RT_HIP(c, syncAll(c)); reopenPriorityDecision(c); }
   const bool decide = c->overlap >= 2 && !c->prioDecided && c->spareG && c->spareMotion;
   if(decide) { RT_HIP(c, syncAll(c)); harvestTimings(c); }

@@ -110,6 +110,31 @@ class Scene:
         return d
 
 
+def scene_digest(desc):
+    """SHA-256 (first 16 hex digits) of everything rt_upload_scene reads from a scene description — prim meshes (20 B), vertices (32 B), indices, instances (56 B),
+    materials (80 B), every texture's size / sampler and texels, punctual (80 B) and triangle (96 B) lights, light info — per part and over all of them.  Two scenes with
+    the same digest upload the same bytes: the same frames follow (bench.py --via-gltf: the procedural scene against itself written to glTF and read back by Scene::load)."""
+    import hashlib
+
+    def raw(ptr, nbytes):
+        return bytes((C.c_char * nbytes).from_address(ptr)) if ptr and nbytes else b""
+    parts = {"primMeshes": raw(desc.primMeshes, desc.numPrimMeshes * 20), "vertices": raw(desc.vertices, desc.numVertices * 32), "indices": raw(desc.indices, desc.numIndices * 4),
+             "instances": raw(desc.instances, desc.numInstances * 56), "materials": raw(desc.materials, desc.numMaterials * 80),
+             "puncLights": raw(desc.puncLights, desc.lightInfo.puncLightSize * 80), "trigLights": raw(desc.trigLights, desc.lightInfo.trigLightSize * 96),
+             "lightInfo": bytes(desc.lightInfo)}
+    h = hashlib.sha256()
+    n = int(desc.numTextures)
+    if desc.textures and n:
+        t = np.frombuffer((C.c_char * (n * 32)).from_address(desc.textures), dtype=np.dtype([("ptr", "<u8"), ("w", "<i4"), ("h", "<i4"), ("rest", "<i4", 4)]))
+        for k in range(n):
+            h.update(t[k]["w"].tobytes() + t[k]["h"].tobytes() + t[k]["rest"][:3].tobytes())
+            h.update(raw(int(t[k]["ptr"]), int(t[k]["w"]) * int(t[k]["h"]) * 4))
+    out = {k: hashlib.sha256(v).hexdigest()[:16] for k, v in parts.items()}
+    out["textures"] = h.hexdigest()[:16]
+    out["all"] = hashlib.sha256("".join(out[k] for k in sorted(out)).encode()).hexdigest()[:16]
+    return out
+
+
 def default_state(width, height, scene=None, env=None, time=1000):
     """RtxState as SampleExample fills it: defaults (sample_example.hpp:154-184) + the derived constants of
     sample_example.cpp:87 (lightLuminIntegInv) and :104-105 (fireflyClampThreshold, envMapLuminIntegInv)."""

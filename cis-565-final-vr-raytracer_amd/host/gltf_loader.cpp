@@ -9,6 +9,9 @@
 // samplers; PNG images (every colour type / bit depth, Adam7 included, via zlib) and JPEG images (baseline / progressive, jpeg_decoder.cpp).
 #include "scene.hpp"
 #include <zlib.h>
+#include <atomic>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -341,34 +344,52 @@ bool loadGltfFile(const std::string& filename, GltfScene& out, std::string& erro
   };
 
   // ---- images -> textures (scene.cpp:554-646) ----------------------------------------------------------------------
+  // (round 6: the images of an asset are decoded by all host cores — Bistro Exterior has 251 of them, 3.4 GB of texels: one core took a minute)
   std::vector<TextureImage> images(A("images").size());
-  for(size_t i = 0; i < images.size(); i++) {
-    const Json& im = A("images").at(i);
-    std::vector<uint8_t> bytes;
-    bool have = false;
-    const std::string uri = im.string("uri");
-    if(!uri.empty()) have = loadUri(uri, dir, bytes);
-    else {
-      const int bv = im.integer("bufferView", -1);
-      if(bv >= 0 && size_t(bv) < A("bufferViews").size()) {
-        const Json& view = A("bufferViews").at(size_t(bv));
-        const int b = view.integer("buffer", 0);
-        const size_t off = size_t(view.number("byteOffset", 0)), len = size_t(view.number("byteLength", 0));
-        if(b >= 0 && size_t(b) < buffers.size() && off + len <= buffers[size_t(b)].size()) { bytes.assign(buffers[size_t(b)].begin() + long(off), buffers[size_t(b)].begin() + long(off + len)); have = true; }
+  {
+    std::atomic<size_t> nextImage{0};
+    std::mutex logLock;
+    auto work = [&] {
+      for(;;) {
+        const size_t i = nextImage.fetch_add(1);
+        if(i >= images.size()) return;
+        const Json& im = A("images").at(i);
+        std::vector<uint8_t> bytes;
+        const uint8_t* data = nullptr; size_t size = 0;
+        bool have = false;
+        const std::string uri = im.string("uri");
+        if(!uri.empty()) { have = loadUri(uri, dir, bytes); data = bytes.data(); size = bytes.size(); }
+        else {
+          const int bv = im.integer("bufferView", -1);
+          if(bv >= 0 && size_t(bv) < A("bufferViews").size()) {
+            const Json& view = A("bufferViews").at(size_t(bv));
+            const int b = view.integer("buffer", 0);
+            const size_t off = size_t(view.number("byteOffset", 0)), len = size_t(view.number("byteLength", 0));
+            if(b >= 0 && size_t(b) < buffers.size() && off + len <= buffers[size_t(b)].size()) { data = buffers[size_t(b)].data() + off; size = len; have = true; }
+          }
+        }
+        TextureImage t;
+        if(!have || !(decodePng(data, size, t) || decodeJpeg(data, size, t))) {
+          if(have) { std::lock_guard<std::mutex> l(logLock); fprintf(stderr, "gltf: image %zu is neither an 8-bit PNG nor a Huffman-coded 8-bit JPEG: using a white texel\n", i); }
+          t.width = t.height = 1; t.bgra = {255, 255, 255, 255};  // addDefaultImage, scene.cpp:566-572
+        }
+        images[i] = std::move(t);
       }
-    }
-    TextureImage t;
-    if(!have || !(decodePng(bytes.data(), bytes.size(), t) || decodeJpeg(bytes.data(), bytes.size(), t))) {
-      if(have) fprintf(stderr, "gltf: image %zu is neither an 8-bit PNG nor a Huffman-coded 8-bit JPEG: using a white texel\n", i);
-      t.width = t.height = 1; t.bgra = {255, 255, 255, 255};  // addDefaultImage, scene.cpp:566-572
-    }
-    images[i] = std::move(t);
+    };
+    const size_t nt = std::min<size_t>(images.size(), std::max(1u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> pool;
+    for(size_t k = 1; k < nt; k++) pool.emplace_back(work);
+    work();
+    for(auto& th : pool) th.join();
   }
+  // (an image used by exactly one texture — the usual case — is moved, not copied: 16 MB per 2048^2 image)
+  std::vector<int> imageUses(images.size(), 0);
+  for(size_t i = 0; i < A("textures").size(); i++) { const int src = A("textures").at(i).integer("source", -1); if(src >= 0 && size_t(src) < images.size()) imageUses[size_t(src)]++; }
   for(size_t i = 0; i < A("textures").size(); i++) {
     const Json& tx = A("textures").at(i);
     const int src = tx.integer("source", -1);
     TextureImage t;
-    if(src >= 0 && size_t(src) < images.size()) t = images[size_t(src)];
+    if(src >= 0 && size_t(src) < images.size()) { if(--imageUses[size_t(src)] == 0) t = std::move(images[size_t(src)]); else t = images[size_t(src)]; }
     else { t.width = t.height = 1; t.bgra = {255, 255, 255, 255}; }
     const int smp = tx.integer("sampler", -1);
     if(smp >= 0 && size_t(smp) < A("samplers").size()) {  // gltfSamplerToVulkan, scene.cpp:513-548
@@ -529,7 +550,7 @@ std::vector<uint8_t> encodePng(const TextureImage& t)
   }
   uLongf clen = compressBound(uLong(raw.size()));
   std::vector<uint8_t> z(clen);
-  compress2(z.data(), &clen, raw.data(), uLong(raw.size()), 6);
+  compress2(z.data(), &clen, raw.data(), uLong(raw.size()), raw.size() > (size_t(1) << 22) ? 1 : 6);   // (asset-sized images: speed over ratio)
   z.resize(clen);
   std::vector<uint8_t> out = {137, 80, 78, 71, 13, 10, 26, 10};
   auto chunk = [&](const char* tag, const std::vector<uint8_t>& body) {
@@ -591,17 +612,51 @@ bool saveGltfFile(const std::string& filename, const GltfScene& g, std::string& 
     meshes << "},\"indices\":" << addAcc(vI, size_t(pm.firstIndex) * 4, pm.indexCount, 5125, "SCALAR", nullptr, nullptr);
     meshes << ",\"material\":" << pm.materialIndex << ",\"mode\":4}]}";
   }
-  // images share the binary buffer
+  // Small scenes are written self-contained (one data: URI; images inside the binary buffer).  An asset-sized scene (round 6: the benchmark's 2.8 M triangles and
+  // 3.4 GB of texels, bench.py --via-gltf) is written the way such assets ship: `<name>.bin` for the geometry and one `<name>_img<i>.png` per image beside the .gltf —
+  // a base64 buffer of that size would be a 5 GB JSON string, and a .glb chunk cannot exceed 4 GB.  RESTIR_GLTF_EXTERNAL=0 / 1 forces either form.
+  size_t texelBytes = 0;
+  for(const TextureImage& t : g.textures) texelBytes += t.bgra.size();
+  const char* extEnv = getenv("RESTIR_GLTF_EXTERNAL");
+  const bool external = extEnv ? atoi(extEnv) != 0 : (bin.size() + texelBytes > (size_t(256) << 20));
+  const size_t slash = filename.find_last_of("/\\");
+  const std::string dirOut = slash == std::string::npos ? "" : filename.substr(0, slash + 1);
+  std::string stem = slash == std::string::npos ? filename : filename.substr(slash + 1);
+  if(stem.size() > 5 && stem.substr(stem.size() - 5) == ".gltf") stem.resize(stem.size() - 5);
   std::vector<int> imgView;
-  for(const TextureImage& t : g.textures) { std::vector<uint8_t> png = encodePng(t); views.push_back(append(png.data(), png.size())); imgView.push_back(int(views.size()) - 1); }
-
-  o << "\"buffers\":[{\"byteLength\":" << bin.size() << ",\"uri\":\"data:application/octet-stream;base64," << b64(bin.data(), bin.size()) << "\"}],\n";
+  if(!external) {
+    for(const TextureImage& t : g.textures) { std::vector<uint8_t> png = encodePng(t); views.push_back(append(png.data(), png.size())); imgView.push_back(int(views.size()) - 1); }
+    o << "\"buffers\":[{\"byteLength\":" << bin.size() << ",\"uri\":\"data:application/octet-stream;base64," << b64(bin.data(), bin.size()) << "\"}],\n";
+  } else {
+    std::atomic<size_t> nextImage{0};
+    std::atomic<bool> failed{false};
+    auto work = [&] {
+      for(;;) {
+        const size_t i = nextImage.fetch_add(1);
+        if(i >= g.textures.size()) return;
+        const std::vector<uint8_t> png = encodePng(g.textures[i]);
+        std::ofstream pf(dirOut + stem + "_img" + std::to_string(i) + ".png", std::ios::binary);
+        pf.write(reinterpret_cast<const char*>(png.data()), std::streamsize(png.size()));
+        if(!pf) failed = true;
+      }
+    };
+    const size_t nt = std::min<size_t>(std::max<size_t>(1, g.textures.size()), std::max(1u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> pool;
+    for(size_t k = 1; k < nt; k++) pool.emplace_back(work);
+    work();
+    for(auto& th : pool) th.join();
+    std::ofstream bf(dirOut + stem + ".bin", std::ios::binary);
+    bf.write(reinterpret_cast<const char*>(bin.data()), std::streamsize(bin.size()));
+    if(!bf || failed) { error = "cannot write the external files of " + filename; return false; }
+    o << "\"buffers\":[{\"byteLength\":" << bin.size() << ",\"uri\":\"" << stem << ".bin\"}],\n";
+  }
   o << "\"bufferViews\":[";
   for(size_t i = 0; i < views.size(); i++) o << (i ? "," : "") << "{\"buffer\":0,\"byteOffset\":" << views[i].off << ",\"byteLength\":" << views[i].len << "}";
   o << "],\n\"accessors\":[" << acc.str() << "],\n\"meshes\":[" << meshes.str() << "],\n";
   if(!g.textures.empty()) {
     o << "\"images\":[";
-    for(size_t i = 0; i < imgView.size(); i++) o << (i ? "," : "") << "{\"bufferView\":" << imgView[i] << ",\"mimeType\":\"image/png\"}";
+    if(external) for(size_t i = 0; i < g.textures.size(); i++) o << (i ? "," : "") << "{\"uri\":\"" << stem << "_img" << i << ".png\"}";
+    else for(size_t i = 0; i < imgView.size(); i++) o << (i ? "," : "") << "{\"bufferView\":" << imgView[i] << ",\"mimeType\":\"image/png\"}";
     o << "],\n\"samplers\":[";
     for(size_t i = 0; i < g.textures.size(); i++) o << (i ? "," : "") << "{\"wrapS\":" << g.textures[i].wrapS << ",\"wrapT\":" << g.textures[i].wrapT << ",\"magFilter\":" << g.textures[i].magFilter << "}";
     o << "],\n\"textures\":[";

@@ -11,7 +11,7 @@ from . import abi
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.environ.get("RESTIR_HIP_LIB") or os.path.join(_HERE, "csrc", "librestir_hip.so")  # env override: A/B builds
 _lib = None
-PRIO_FILTER_SHARE = 0.20   # the threshold of rt_render_frame's stream-priority rule (csrc/rt_api.cpp PRIO_FILTER_SHARE; profiles/r06_prio_rule.txt) — for reports and tests
+PRIO_FILTER_SHARE = 0.30   # the threshold of rt_render_frame's stream-priority rule (csrc/rt_api.cpp PRIO_FILTER_SHARE; profiles/r06_prio_rule.txt) — for reports and tests
 
 # every symbol include/rt_abi.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_build_accel", "rt_resize", "rt_set_camera",

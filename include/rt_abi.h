@@ -421,7 +421,7 @@ int rt_set_overlap(rt_ctx* ctx, int mode);
  * (src/renderer.cpp:154-206) and has no such choice; here three streams share the chip and the fastest setting depends on the workload
  * (profiles/r05_prio_by_config_ab.txt).  Unset (no call, no RESTIR_PRIO), the context decides on its first three mode-2 frames ("probe frames": every stage alone on
  * the main stream, timed): the filter stream becomes high next to the indirect stream when filters / (direct + indirect) of the LAST probe frame — warm caches, warm
- * history — is >= 0.20 (profiles/r06_prio_rule.txt); the two streams are created afterwards.  rt_resize, a new scene / tree and a denoise toggle re-open that decision (round 6; round 5 decided once,
+ * history — is >= 0.30 (profiles/r06_prio_rule.txt); the two streams are created afterwards.  rt_resize, a new scene / tree and a denoise toggle re-open that decision (round 6; round 5 decided once,
  * on the cold first frame).  An explicit call is best made before the first frame: a stream created after others exist may share a hardware queue with them; it
  * stands for the context's lifetime.  Results are identical under every setting.  Drains the context. */
 int rt_set_stream_priorities(rt_ctx* ctx, int indirectLevel, int filterLevel);

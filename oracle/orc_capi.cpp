@@ -95,6 +95,7 @@ int orc_render_frame(void* p, const rt_state* st, int frames)
   if(!c->haveScene) return RT_ERR_NO_SCENE;
   if(st->size.x != c->frame.W || st->size.y != c->frame.H) return RT_ERR_NO_TARGET;
   c->frame.renderFrame(*st, frames);
+  c->scene.counters.flush();
   return RT_OK;
 }
 int orc_run_stage(void* p, const rt_state* st, int frames, int stage, int level, int rowBegin, int rowEnd)
@@ -103,6 +104,7 @@ int orc_run_stage(void* p, const rt_state* st, int frames, int stage, int level,
   if(!c->haveScene) return RT_ERR_NO_SCENE;
   if(st->size.x != c->frame.W || st->size.y != c->frame.H) return RT_ERR_NO_TARGET;
   c->frame.runStage(*st, frames, stage, level, rowBegin, rowEnd);
+  c->scene.counters.flush();
   return RT_OK;
 }
 // logical size (W x H elements); the vectors carry slack rows behind it
@@ -161,6 +163,8 @@ int orc_pick(void* p, const rt_mat4* viewInv, const rt_mat4* projInv, float pick
   const vec4 direction = mul(*reinterpret_cast<const mat4*>(viewInv), V4(normalize(xyz(target)), 0));
   const vec3 o = xyz(origin), dir = normalize(xyz(direction));
   const Hit h = c->scene.closestHit(o, dir, 0u);
+  c->scene.counters.flush();   // (every entry point that traces on the CALLER's thread hands its counts to its own context before it returns: the thread-local block is
+                               //  shared by all contexts of the thread — advisor finding of round 5: context A's rays ended in whichever context flushed next)
   out->worldRayOrigin = rt_vec4{o.x, o.y, o.z, 1.0f}; out->worldRayDirection = rt_vec4{dir.x, dir.y, dir.z, 0.0f};
   out->hitT = h.t; out->primitiveID = 0; out->instanceID = -1; out->instanceCustomIndex = 0; out->baryCoord = rt_vec3{0, 0, 0};
   if(h.tri != 0xffffffffu) {
@@ -175,6 +179,7 @@ int orc_tonemap(void* p, const rt_tonemapper* tm, int dbg, int frames)
   Ctx* c = static_cast<Ctx*>(p);
   if(!tm || c->frame.W == 0) return RT_ERR_INVALID_ARG;
   c->frame.tonemap(*tm, dbg, frames);
+  c->scene.counters.flush();
   return RT_OK;
 }
 int orc_set_history_rows(void* p, int r0, int r1) { Ctx* c = static_cast<Ctx*>(p); c->frame.histRow0 = r0; c->frame.histRow1 = r1; return RT_OK; }
@@ -193,6 +198,7 @@ void orc_trace_closest(void* p, int n, const float* rays, float* out)
     Hit h = c->scene.closestHit(V3(r[0], r[1], r[2]), V3(r[3], r[4], r[5]), rt_f2u(r[7]));
     out[4 * i + 0] = h.t; out[4 * i + 1] = rt_u2f(h.tri); out[4 * i + 2] = h.u; out[4 * i + 3] = h.v;
   }
+  c->scene.counters.flush();
 }
 void orc_trace_any(void* p, int n, const float* rays, int32_t* out)
 {
@@ -201,6 +207,7 @@ void orc_trace_any(void* p, int n, const float* rays, int32_t* out)
     const float* r = rays + 8 * i;
     out[i] = c->scene.anyHit(V3(r[0], r[1], r[2]), V3(r[3], r[4], r[5]), r[6], rt_f2u(r[7])) ? 1 : 0;
   }
+  c->scene.counters.flush();
 }
 // brute force over all triangles (no BVH): validates the oracle's own BVH
 void orc_trace_closest_brute(void* p, int n, const float* rays, float* out)
@@ -221,6 +228,7 @@ void orc_trace_closest_brute(void* p, int n, const float* rays, float* out)
     }
     out[4 * i + 0] = best.t; out[4 * i + 1] = rt_u2f(best.tri); out[4 * i + 2] = best.u; out[4 * i + 3] = best.v;
   }
+  c->scene.counters.flush();
 }
 
 // the sampler on its own (tests/test_trace_pin.py: against a float64 statement of the Vulkan rules): n uv pairs -> n RGBA values

@@ -58,7 +58,8 @@ struct Counters {
     if(l.risCandidates) risCandidates += l.risCandidates;
     l = Local{};
   }
-  void reset() { local() = Local{}; closestHitRays = anyHitRays = nodesVisited = trisTested = hitsShaded = risCandidates = 0; }
+  // (the calling thread's local block is empty between C entry points — each flushes before it returns — so there is nothing of another context to discard here)
+  void reset() { flush(); closestHitRays = anyHitRays = nodesVisited = trisTested = hitsShaded = risCandidates = 0; }
 };
 
 struct Texture {

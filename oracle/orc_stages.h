@@ -90,7 +90,9 @@ void Frame::parallelRows(int rows, int rowBegin, int rowEnd, F&& fn) const
   }
   for(int t = 0; t < nt; t++) {
     pool.emplace_back([&] { for(;;) { int y = next.fetch_add(1); if(y >= rowEnd) break; fn(y); } cnt.flush(); });
-    if(!cpus.empty()) { cpu_set_t one; CPU_ZERO(&one); CPU_SET(cpus[size_t(t) % cpus.size()], &one); (void)pthread_setaffinity_np(pool.back().native_handle(), sizeof(one), &one); }
+    // (round 6: the workers are SPREAD over the CPUs of the mask — worker t on CPU t * ncpu / nt — instead of packed on the first nt: 32 workers on CPUs 0-31 shared four L3
+    //  slices and two memory channels' worth of a 256-CPU host and ran at 0.53 of the single-thread rate each, profiles/r05_cpu_baseline.txt)
+    if(!cpus.empty()) { cpu_set_t one; CPU_ZERO(&one); CPU_SET(cpus[(size_t(t) * cpus.size() / size_t(nt)) % cpus.size()], &one); (void)pthread_setaffinity_np(pool.back().native_handle(), sizeof(one), &one); }
   }
   for(auto& th : pool) th.join();
 }

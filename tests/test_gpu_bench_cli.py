@@ -56,7 +56,12 @@ def test_native_host_gate_passes_and_catches_a_corrupted_halo():
     v = d["verify"]["workload"]
     assert v["frames"] == 3 and set(v["buffers"]) == {"gbuffer0", "direct_resv0", "light_id0", "indirect_resv0", "direct_result0", "indirect_result0"}
     assert all(b["equal"] and b["tiled"] == b["untiled"] and len(b["tiled"]) == 16 for b in v["buffers"].values())
+    # the hook lives in a TEST build of the library only (-DRT_TEST_HOOKS=1, built here: measurement builds do not travel to the GPU box): the product library ignores the variable
+    from restir_amd import build as b
     env = dict(os.environ); env.pop("WORLD_SIZE", None); env.pop("RANK", None); env["RESTIR_TEST_CORRUPT_HALO"] = "1"
+    q0 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--native", "--devices", devs] + SMALL, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert q0.returncode == 0 and json.loads(q0.stdout.strip().splitlines()[-1])["tiled_equals_untiled"] is True
+    env["RESTIR_HIP_LIB"] = b.build_hip(variant="testhooks", extra_flags=["-DRT_TEST_HOOKS=1"])
     q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--native", "--devices", devs] + SMALL, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert q.returncode == 3, (q.returncode, q.stderr[-1500:])
     e = json.loads(q.stdout.strip().splitlines()[-1])
@@ -99,3 +104,26 @@ def test_one_process_per_gpu_code_path_on_shared_device():
     h = d["hosts"]
     assert h["rccl"]["tiled_equals_untiled"] is True and h["rccl"]["tiled_equals_untiled_moving_camera"] is True and h["rccl"]["value"] > 0
     assert h["native"] is not None and h["native"]["tiled_equals_untiled"] is True and d["hosts_all_verified"] is True
+
+
+def test_via_gltf_the_loaded_scene_is_the_procedural_one():
+    """round-5 verdict, missing 4: the reference's entry point is Scene::load on a glTF file (src/scene.cpp:57-125).  `bench.py --via-gltf` writes the workload's scene as
+    an asset (.gltf + .bin + one PNG per image), reads it back through Scene::load, times the LOADED scene and holds it to the procedural one: same digest of every array
+    rt_upload_scene reads, same six frame buffers after three cold-history frames.  Here at scale 0.05 (the full-size run is profiles/r06z_bench_via_gltf.json)."""
+    p = _run("--via-gltf", "--scale", "0.05", "--width", "640", "--height", "368", "--steps", "4", "--warmup", "4", "--no-cpu-baseline")
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    v = d["via_gltf"]
+    assert v["stats_equal"] and v["scene_digest_equal"] and v["parts_differing"] == [] and v["frames_equal"] is True, v
+    assert v["files"] >= 3 and v["bytes_on_disk"] > 1e6 and v["load_s"] > 0 and d["value"] > 0
+    assert v["frame_digests"]["procedural"] == v["frame_digests"]["loaded"] and len(v["frame_digests"]["loaded"]) == 6
+
+
+def test_pose_changes_the_view_not_the_scene():
+    """`--pose N`: the headline scene from the fixed poses of round 6 (0 = the scene's camera); the key of its counter pass carries the pose"""
+    p = _run("--print-workload-key", "--pose", "2")
+    assert p.returncode == 0 and p.stdout.strip() == "config4_real_pose2"
+    a = json.loads(_run("--scale", "0.05", "--width", "480", "--height", "272", "--steps", "3", "--warmup", "4", "--no-cpu-baseline").stdout.strip().splitlines()[-1])
+    b = json.loads(_run("--pose", "2", "--scale", "0.05", "--width", "480", "--height", "272", "--steps", "3", "--warmup", "4", "--no-cpu-baseline").stdout.strip().splitlines()[-1])
+    assert "pose 2" in b["config"]["workload"] and "pose" not in a["config"]["workload"]
+    assert a["config"]["rays_per_frame"] != b["config"]["rays_per_frame"] and a["config"]["accel"] == b["config"]["accel"]
