@@ -58,6 +58,7 @@ struct rt_ctx {
   std::vector<rt_prim_mesh> primMeshes; std::vector<rt_vertex> vertices; std::vector<uint32_t> indices; std::vector<rt_instance> instances;
   std::vector<rt_material> materials; std::vector<DevTexture> devTextures;
   std::vector<std::vector<uint8_t>> hostAlpha;  // alpha channel of every texture (opacity micro-map build)
+  std::vector<std::array<uint64_t, 2>> alphaHash;   // ... and its hash (rt_build_accel's cache key)
   // device allocations of the scene
   std::vector<void*> sceneAllocs, accelAllocs, ovfAllocs;
   DevScene ds{};
@@ -300,8 +301,15 @@ template <class T> static int upload(rt_ctx* c, std::vector<void*>& pool, const 
   return RT_OK;
 }
 static void freePool(std::vector<void*>& pool) { for(void* p : pool) (void)hipFree(p); pool.clear(); }
+// RESTIR_BVH_TIMING=1: where the seconds of rt_upload_scene / rt_build_accel go (stderr)
+struct LoadTimer {
+  const bool on = getenv("RESTIR_BVH_TIMING") && atoi(getenv("RESTIR_BVH_TIMING")) != 0;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(const char* what) { if(!on) return; const auto n = std::chrono::steady_clock::now(); fprintf(stderr, "[scene load] %-34s %.3f s\n", what, std::chrono::duration<double>(n - t).count()); t = n; }
+};
 static int ensureStackOverflow(rt_ctx* c);
 static void reopenPriorityDecision(rt_ctx* c);
+static void hashBytes(const void* p, size_t n, uint64_t& h0, uint64_t& h1);
 static int stackLdsEnv() { static const int v = getenv("RESTIR_STACK_LDS") ? std::max(2, atoi(getenv("RESTIR_STACK_LDS"))) : 0; return v; }
 static int stackLdsMin() { return stackLdsEnv() ? stackLdsEnv() : 6; }   // the shortest LDS stack any schedule uses: sizes the overflow areas
 
@@ -455,6 +463,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
   }
   RT_HIP(c, hipSetDevice(c->device));
   RT_HIP(c, syncAll(c));
+  LoadTimer lt;
   freePool(c->sceneAllocs); freePool(c->accelAllocs);
   c->haveScene = c->haveAccel = false;
   c->ds = DevScene{};
@@ -476,7 +485,9 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
   if(!d->puncLights) c->ds.lightInfo.puncLightSize = 0;
   if(!d->trigLights) c->ds.lightInfo.trigLightSize = 0;
   // textures (BGRA8, LOD 0)
+  lt.lap("geometry copies + uploads");
   c->hostAlpha.clear();
+  std::vector<const uint8_t*> alphaSrc;
   std::vector<DevTexture> texs(std::max<uint32_t>(d->numTextures, 1));
   static const uint8_t white[4] = {255, 255, 255, 255};
   for(uint32_t i = 0; i < uint32_t(texs.size()); i++) {
@@ -486,8 +497,32 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
     if((rc = upload(c, c->sceneAllocs, t.bgra8, size_t(t.width) * t.height * 4, &dp))) return rc;
     texs[i] = DevTexture{dp, t.width, t.height, t.wrapS, t.wrapT, t.magFilter, 0};
     c->hostAlpha.emplace_back(size_t(t.width) * t.height);
-    for(size_t k = 0; k < c->hostAlpha.back().size(); k++) c->hostAlpha.back()[k] = t.bgra8[k * 4 + 3];
+    alphaSrc.push_back(t.bgra8);
   }
+  lt.lap("texture uploads");
+  {  // the alpha planes (opacity micro-map build) and their hashes (rt_build_accel's cache key), one task per texture on the host's cores: 0.87 G byte-strided
+     // copies + a hash of them took 1.1 s of the headline scene's load on one core (round 6)
+    c->alphaHash.assign(c->hostAlpha.size(), {0ull, 0ull});
+    std::atomic<size_t> next{0};
+    auto work = [&] {
+      for(;;) {
+        const size_t i = next.fetch_add(1);
+        if(i >= c->hostAlpha.size()) return;
+        std::vector<uint8_t>& a = c->hostAlpha[i];
+        const uint8_t* src = alphaSrc[i];
+        for(size_t k = 0; k < a.size(); k++) a[k] = src[k * 4 + 3];
+        uint64_t h0 = 0x243F6A8885A308D3ull, h1 = 0x13198A2E03707344ull;
+        hashBytes(a.data(), a.size(), h0, h1);
+        c->alphaHash[i] = {h0, h1};
+      }
+    };
+    const size_t nt = std::min<size_t>(c->hostAlpha.size(), std::max(1u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> pool;
+    for(size_t k = 1; k < nt; k++) pool.emplace_back(work);
+    work();
+    for(auto& th : pool) th.join();
+  }
+  lt.lap("alpha planes + hashes");
   if((rc = upload(c, c->sceneAllocs, texs.data(), texs.size(), &c->ds.textures))) return rc;
   c->devTextures = texs;
   // environment
@@ -536,7 +571,7 @@ static void sceneKey(const rt_ctx* c, uint64_t& h0, uint64_t& h1)
     const DevTexture& t = c->devTextures[i];
     const int meta[5] = {t.w, t.h, t.wrapS, t.wrapT, t.filter};
     hashBytes(meta, sizeof(meta), h0, h1);
-    if(i < c->hostAlpha.size()) RT_HASH_VEC(c->hostAlpha[i]);
+    if(i < c->alphaHash.size()) { const uint64_t n_ = c->hostAlpha[i].size(); hashBytes(&n_, 8, h0, h1); hashBytes(c->alphaHash[i].data(), 16, h0, h1); }   // (hashed per texture at upload, in parallel)
   }
   // the builder's settings are part of what is cached: a host that changes RESTIR_BVH_* between two contexts of one process gets the tree it asked for, not the first
   // one's (advisor finding of round 5)
@@ -550,6 +585,7 @@ static void sceneKey(const rt_ctx* c, uint64_t& h0, uint64_t& h1)
 #undef RT_HASH_VEC
 static int buildHostAccel(rt_ctx* c, HostAccel& out)
 {
+  LoadTimer lt;
   rt_scene_desc d{};
   d.numPrimMeshes = uint32_t(c->primMeshes.size()); d.primMeshes = c->primMeshes.data();
   d.numVertices = c->vertices.size(); d.vertices = c->vertices.data();
@@ -564,6 +600,7 @@ static int buildHostAccel(rt_ctx* c, HostAccel& out)
     if(!buildBvh8(d, bo, threads > 0 ? threads : 1, true)) return fail(c, RT_ERR_INVALID_ARG, "rt_build_accel: BVH8 build failed");
   }
   if(bo.maxDepth > STACK_MAX) return fail(c, RT_ERR_INVALID_ARG, "rt_build_accel: BVH8 deeper than the traversal stack");
+  lt.lap("buildBvh8");
   // alpha records for the triangles that go through HitTest (instances without FORCE_OPAQUE)
   std::vector<AlphaRec>& alpha = out.alpha; alpha.assign(1, AlphaRec{});
   std::vector<int32_t>& alphaTex = out.alphaTex; alphaTex.assign(1, -1);
@@ -603,6 +640,7 @@ static int buildHostAccel(rt_ctx* c, HostAccel& out)
     memcpy(T.omm, it->second.data(), sizeof(T.omm));
     if(!alphaOf.empty()) { alphaOf[T.globalId] = T.alphaIdx; ommOf.resize(alpha.size()); ommOf[T.alphaIdx] = it->second; }
   }
+  lt.lap("alpha records + micro-maps");
   return RT_OK;
 }
 
@@ -617,10 +655,12 @@ int rt_build_accel(rt_ctx* c)
   // Host products (BVH8, alpha records, opacity micro-maps): built once per distinct scene in this process and shared by every context that uploads
   // the same scene — the N ranks of an rt_mgpu context, or an application's contexts on several devices (1.4-1.6 s per build at 2.8 M triangles).
   std::shared_ptr<const HostAccel> ha;
+  LoadTimer lt;
   {
     std::lock_guard<std::mutex> one(g_accelMutex);   // also: one multi-threaded host build at a time
     uint64_t k0, k1;
     sceneKey(c, k0, k1);
+    lt.lap("scene key");
     if(g_accelCache && g_accelCache->key0 == k0 && g_accelCache->key1 == k1) ha = g_accelCache;
     else {
       auto fresh = std::make_shared<HostAccel>();
@@ -630,6 +670,7 @@ int rt_build_accel(rt_ctx* c)
       ha = fresh; g_accelCache = ha;
     }
   }
+  lt.lap("host products (build or cache)");
   const BuildOutput& bo = ha->bo;
   int rc;
   {
@@ -657,6 +698,7 @@ int rt_build_accel(rt_ctx* c)
   c->numNodes = bo.nodes.size(); c->numTris = bo.triRef.size(); c->maxDepth = bo.maxDepth;
   c->numRefs = bo.tris.size(); c->spatialSplits = size_t(bo.spatialSplits); c->sahNodeSteps = bo.sahNodeSteps; c->sahTriSteps = bo.sahTriSteps;
   RT_HIP(c, hipDeviceSynchronize());
+  lt.lap("uploads (tree, alpha records)");
   c->haveAccel = true;
   reopenPriorityDecision(c);
   return ensureStackOverflow(c);
