@@ -14,6 +14,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 #include "../../include/rt_abi.h"
 #include "bvh8_builder.h"
@@ -604,7 +605,10 @@ static int buildHostAccel(rt_ctx* c, HostAccel& out)
   // alpha records for the triangles that go through HitTest (instances without FORCE_OPAQUE)
   std::vector<AlphaRec>& alpha = out.alpha; alpha.assign(1, AlphaRec{});
   std::vector<int32_t>& alphaTex = out.alphaTex; alphaTex.assign(1, -1);
-  std::map<std::array<uint32_t, 12>, std::array<uint32_t, 4>> ommCache;
+  // (a hash map since round 6: 2 M lookups with 48-byte keys in a std::map were a second of the headline scene's load)
+  struct KeyHash { size_t operator()(const std::array<uint32_t, 12>& k) const { uint64_t h = 1469598103934665603ull; for(uint32_t w : k) { h ^= w; h *= 1099511628211ull; } return size_t(h ^ (h >> 29)); } };
+  std::unordered_map<std::array<uint32_t, 12>, std::array<uint32_t, 4>, KeyHash> ommCache;
+  ommCache.reserve(1 << 16);
   std::vector<uint32_t> alphaOf;   // by globalId: the record of a triangle that has several references (spatial splits) is made once
   if(bo.tris.size() > bo.triRef.size()) alphaOf.assign(bo.triRef.size(), 0u);
   std::vector<std::array<uint32_t, 4>> ommOf;
