@@ -129,5 +129,5 @@ def test_pose_changes_the_view_not_the_scene():
     assert p.returncode == 0 and p.stdout.strip() == "config4_real_pose2"
     a = json.loads(_run("--scale", "0.05", "--width", "480", "--height", "272", "--steps", "3", "--warmup", "4", "--no-cpu-baseline").stdout.strip().splitlines()[-1])
     b = json.loads(_run("--pose", "2", "--scale", "0.05", "--width", "480", "--height", "272", "--steps", "3", "--warmup", "4", "--no-cpu-baseline").stdout.strip().splitlines()[-1])
-    assert "pose 2" in b["config"]["workload"] and "pose" not in a["config"]["workload"]
+    assert ", pose 2:" in b["config"]["workload"] and ", pose " not in a["config"]["workload"]      # ("compose" is part of every workload string)
     assert a["config"]["rays_per_frame"] != b["config"]["rays_per_frame"] and a["config"]["accel"] == b["config"]["accel"]
