@@ -49,11 +49,13 @@ struct rt_ctx {
   void* dPick = nullptr;     // rt_pick_result written by k_pick
   rt_sun_and_sky sunAndSky{};
   void* spareG = nullptr; void* spareMotion = nullptr;   // third G-buffer / second motion buffer (rotated per pipelined frame)
+  // overlap 3 (three frames in flight): one more of each, and a third noisy / filtered direct image — direct(f) then only waits for frame f-3 (rt_render_frame)
+  void* spareG2 = nullptr; void* spareMotion2 = nullptr; void* spareDirRes = nullptr;
   // The noisy indirect colour (RT_BUF_DENOISE_IND_A: written by the indirect stage, read and rewritten by its five filter levels) exists twice, by frame parity:
   // indirect(f+1) must not wait for the filters of frame f (round 3: that wait made a rank's period indirect + filters instead of max(direct, indirect)).
   // The boundary id names the buffer of the frame most recently passed to rt_render_frame / rt_run_stage / rt_select_frame.
   void* indA[2] = {nullptr, nullptr};
-  int overlap = 2;           // 0 = one stream; 1 = direct A-Trous beside the indirect stage; 2 = 1 + consecutive frames overlap
+  int overlap = 2;           // 0 = one stream; 1 = direct A-Trous beside the indirect stage; 2 = 1 + consecutive frames overlap; 3 = 2 with a third frame in flight
   std::string err;
   // host copy of the scene (rt_build_accel runs after rt_upload_scene returns; the caller keeps ownership of its arrays)
   std::vector<rt_prim_mesh> primMeshes; std::vector<rt_vertex> vertices; std::vector<uint32_t> indices; std::vector<rt_instance> instances;
@@ -154,7 +156,7 @@ static StageLauncher stageLauncher(const rt_ctx* c, const rt_state& st, int stag
       const int gw = half ? st.size.x / 2 : st.size.x, gh = half ? st.size.y / 2 : st.size.y;
       const int r1 = (rowEnd <= 0 || rowEnd > gh) ? gh : rowEnd, r0 = rowBegin < 0 ? 0 : rowBegin;
       const long tiles = long((gw + 7) / 8) * long((std::max(0, r1 - r0) + 7) / 8);
-      lat = tiles <= (half ? latTilesIndirect(c->overlap == 2) : latTilesDirect(c->overlap == 2));
+      lat = tiles <= (half ? latTilesIndirect(c->overlap >= 2) : latTilesDirect(c->overlap >= 2));
     }
   }
   if(c->ds.sky) return lat ? rt::sky_lat::launchStage : (c->counting ? rt::sky_cnt::launchStage : rt::sky::launchStage);
@@ -389,8 +391,7 @@ int rt_destroy(rt_ctx* c)
   (void)syncAll(c);
   freePool(c->sceneAllocs); freePool(c->accelAllocs); freePool(c->scratchAllocs); freePool(c->ovfAllocs);
   for(int i = 0; i < RT_BUF_COUNT; i++) if(c->bufs[i]) (void)hipFree(c->bufs[i]);
-  if(c->spareG) (void)hipFree(c->spareG);
-  if(c->spareMotion) (void)hipFree(c->spareMotion);
+  for(void* p : {c->spareG, c->spareMotion, c->spareG2, c->spareMotion2, c->spareDirRes}) if(p) (void)hipFree(p);
   for(void* p : c->indA) if(p && p != c->bufs[RT_BUF_DENOISE_IND_A]) (void)hipFree(p);
   for(hipStream_t q : c->padStreams) if(q) (void)hipStreamDestroy(q);
   for(hipStream_t& q : c->indStreams) { if(q) (void)hipStreamDestroy(q); q = nullptr; }
@@ -717,8 +718,7 @@ int rt_resize(rt_ctx* c, int w, int h)
   reopenPriorityDecision(c);
   for(void*& p : c->indA) { if(p && p != c->bufs[RT_BUF_DENOISE_IND_A]) (void)hipFree(p); p = nullptr; }
   for(int i = 0; i < RT_BUF_COUNT; i++) { if(c->bufs[i]) (void)hipFree(c->bufs[i]); c->bufs[i] = nullptr; c->bufBytes[i] = 0; }
-  if(c->spareG) { (void)hipFree(c->spareG); c->spareG = nullptr; }
-  if(c->spareMotion) { (void)hipFree(c->spareMotion); c->spareMotion = nullptr; }
+  for(void** p : {&c->spareG, &c->spareMotion, &c->spareG2, &c->spareMotion2, &c->spareDirRes}) if(*p) { (void)hipFree(*p); *p = nullptr; }
   c->W = c->H = 0;
   const size_t n = size_t(w) * h, nh = size_t(w / 2) * (h / 2);
   for(int i = 0; i < RT_BUF_COUNT; i++) {
@@ -733,9 +733,14 @@ int rt_resize(rt_ctx* c, int w, int h)
       RT_HIP(c, hipMemset(c->indA[1], 0, alloc));
     }
     if(i == RT_BUF_GBUFFER0 || i == RT_BUF_MOTION) {  // rotation partners for frames in flight (rt_render_frame, overlap 2)
-      void** spare = (i == RT_BUF_MOTION) ? &c->spareMotion : &c->spareG;
-      RT_HIP(c, hipMalloc(spare, alloc));
-      RT_HIP(c, hipMemset(*spare, 0, alloc));
+      for(void** spare : {(i == RT_BUF_MOTION) ? &c->spareMotion : &c->spareG, (i == RT_BUF_MOTION) ? &c->spareMotion2 : &c->spareG2}) {
+        RT_HIP(c, hipMalloc(spare, alloc));
+        RT_HIP(c, hipMemset(*spare, 0, alloc));
+      }
+    }
+    if(i == RT_BUF_DIRECT_RESULT0) {   // overlap 3: the direct image of frame f-3 is the one direct(f) overwrites
+      RT_HIP(c, hipMalloc(&c->spareDirRes, alloc));
+      RT_HIP(c, hipMemset(c->spareDirRes, 0, alloc));
     }
   }
   // internal scratch
@@ -773,7 +778,7 @@ static int ensureStackOverflow(rt_ctx* c)
 {
   freePool(c->ovfAllocs);
   c->ds.stackOvf = c->ds.stackOvfInd = nullptr; c->ds.stackOvfThreads = 0;
-  if(!(stackLdsEnv() || c->overlap == 2)) return RT_OK;
+  if(!(stackLdsEnv() || c->overlap >= 2)) return RT_OK;
   if(!c->haveAccel || c->W <= 0 || c->ds.stackTotal <= stackLdsMin()) return RT_OK;
   const size_t tilesX = size_t(c->W + 7) / 8, tilesY = size_t(c->H + 7) / 8;
   const size_t blocks = std::max<size_t>(16384, tilesX * tilesY + 8 * tilesX + 1024);   // >= any traced grid: tileGrid() of the full frame; 4 waves per half-res tile; persistent launches
@@ -833,7 +838,7 @@ static DevFrame makeFrame(rt_ctx* c, int frames)
   selectFrame(c, frames);
   const int cur = frames & 1, last = (frames + 1) & 1;  // m_descSet[(frames+1)%2]: this = [!i] (renderer.cpp:157, 346-356)
   DevFrame F{};
-  F.stackLds = stackLdsEnv() ? stackLdsEnv() : (c->overlap == 2 ? 6 : 0);
+  F.stackLds = stackLdsEnv() ? stackLdsEnv() : (c->overlap >= 2 ? 6 : 0);
   F.thisG = static_cast<uint4*>(c->bufs[RT_BUF_GBUFFER0 + cur]); F.lastG = static_cast<const uint4*>(c->bufs[RT_BUF_GBUFFER0 + last]);
   F.motion = static_cast<short2*>(c->bufs[RT_BUF_MOTION]);
   F.thisDirectResv = static_cast<rt_direct_reservoir*>(c->bufs[RT_BUF_DIRECT_RESV0 + cur]);
@@ -926,8 +931,16 @@ int rt_render_frame(rt_ctx* c, const rt_state* st, int frames)
     // Rotate the G-buffer (3 physical buffers) and the motion buffer (2): direct(f+1) must not overwrite what indirect(f)
     // still reads (its own G-buffer + motion, and G(f-1) for temporal reprojection).  The boundary ids keep their meaning:
     // RT_BUF_GBUFFER0 + (frames & 1) / RT_BUF_MOTION are this frame's buffers once the call returns.
-    std::swap(c->bufs[RT_BUF_GBUFFER0 + (frames & 1)], c->spareG);
-    std::swap(c->bufs[RT_BUF_MOTION], c->spareMotion);
+    // Mode 3 (three frames in flight): one more buffer of each kind, taken oldest first, and the direct image (noisy, filtered in place, composed) three deep —
+    // direct(f) then overwrites G(f-4), motion(f-3) and the direct image of f-3 and has nothing to wait for in frame f-2 (below).
+    if(c->overlap >= 3 && c->spareG2 && c->spareMotion2 && c->spareDirRes) {
+      void*& g = c->bufs[RT_BUF_GBUFFER0 + (frames & 1)]; void* t = g; g = c->spareG; c->spareG = c->spareG2; c->spareG2 = t;
+      void*& m = c->bufs[RT_BUF_MOTION]; t = m; m = c->spareMotion; c->spareMotion = c->spareMotion2; c->spareMotion2 = t;
+      std::swap(c->bufs[RT_BUF_DIRECT_RESULT0 + (frames & 1)], c->spareDirRes);
+    } else {
+      std::swap(c->bufs[RT_BUF_GBUFFER0 + (frames & 1)], c->spareG);
+      std::swap(c->bufs[RT_BUF_MOTION], c->spareMotion);
+    }
   } else {
     RT_HIP(c, joinInFlight(c));
   }
@@ -958,11 +971,14 @@ int rt_render_frame(rt_ctx* c, const rt_state* st, int frames)
     // Buffer reuse across frames is ordered explicitly:
     //   direct(f) overwrites G(f-3) [read by indirect(f-2)], motion(f-2) [indirect(f-2)] and the result image of f-2 [compose(f-2)];
     //   indirect(f) overwrites the noisy-indirect buffer of its parity, which the indirect A-Trous of f-2 read (two buffers: no wait for f-1's filters).
+    // Mode 3: with the deeper rotation above the same three hazards are those of frame f-3.  Mode 2's wait closes a loop direct(f-2) -> filters(f-2) -> direct(f):
+    // two periods cannot be shorter than a direct stage plus the whole filter chain of one frame, and in flight that chain is stretched to the length of a frame.
     const uint64_t s = c->seq;
     const int r = int(s & 3);
-    if(s >= 2) {
-      RT_HIP(c, hipStreamWaitEvent(c->stream, c->evI[(s - 2) & 3], 0));
-      RT_HIP(c, hipStreamWaitEvent(c->stream, c->evDone[(s - 2) & 3], 0));
+    const uint64_t depth = (c->overlap >= 3 && c->spareG2 && c->spareMotion2 && c->spareDirRes) ? 3u : 2u;
+    if(s >= depth) {
+      RT_HIP(c, hipStreamWaitEvent(c->stream, c->evI[(s - depth) & 3], 0));
+      RT_HIP(c, hipStreamWaitEvent(c->stream, c->evDone[(s - depth) & 3], 0));
     }
     RT_HIP(c, mark(c->stream, lastMain));
     if((rc = run(c->stream, RT_STAGE_DIRECT, 0))) return rc;
@@ -1214,12 +1230,12 @@ int rt_tonemap(rt_ctx* c, const rt_tonemapper* tm, int debugging_mode, int frame
 
 int rt_set_overlap(rt_ctx* c, int mode)
 {
-  if(!c || mode < 0 || mode > 2) return RT_ERR_INVALID_ARG;
+  if(!c || mode < 0 || mode > 3) return RT_ERR_INVALID_ARG;
   RT_HIP(c, hipSetDevice(c->device));
   RT_HIP(c, syncAll(c));
-  const bool hadShort = c->overlap == 2;
+  const bool hadShort = c->overlap >= 2;
   c->overlap = mode;
-  if((mode == 2) != hadShort) return ensureStackOverflow(c);   // the short LDS stacks of frames in flight spill into an HBM area that serial schedules do not hold
+  if((mode >= 2) != hadShort) return ensureStackOverflow(c);   // the short LDS stacks of frames in flight spill into an HBM area that serial schedules do not hold
   return RT_OK;
 }
 

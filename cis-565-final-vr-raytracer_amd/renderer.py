@@ -223,7 +223,7 @@ class Renderer:
         self._chk(hip_lib().rt_select_frame(self._h, int(frames)), "rt_select_frame")
 
     def set_overlap(self, mode):
-        """0 = serial launches, 1 = direct A-Trous beside the indirect stage, 2 = 1 + frames in flight (default)."""
+        """0 = serial launches, 1 = direct A-Trous beside the indirect stage, 2 = 1 + frames in flight (default), 3 = 2 with a third frame in flight."""
         self._chk(hip_lib().rt_set_overlap(self._h, int(mode)), "rt_set_overlap")
 
     def history_miss_stage(self, stage):

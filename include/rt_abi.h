@@ -413,9 +413,11 @@ int rt_set_sun_and_sky(rt_ctx* ctx, const rt_sun_and_sky* ss);
  *   2 = (default) 1 + frames in flight: the call returns after enqueueing and the next frame's direct stage runs beside
  *       this frame's indirect stage and filters (internally triple-buffered G-buffer, double-buffered motion vectors).
  *       Throughput mode of a renderer that keeps submitting; one frame's latency is higher than in mode 1.
- * rt_sync / rt_readback / rt_get_counters wait for everything in flight.  In mode 2, rt_device_ptr results for the
- * G-buffers and the motion buffer are invalidated by rt_render_frame (rt_run_stage never rotates buffers).
- * Also settable with RESTIR_OVERLAP=0|1|2 before rt_create. */
+ *   3 = 2 with a third frame in flight (four G-buffers, three motion buffers, three direct images): direct(f) waits for frame f-3 instead of f-2, which takes
+ *       the filter chain of frame f-2 off the path to direct(f).  Measured, not the default (profiles/r06_three_frames_ab.txt).
+ * rt_sync / rt_readback / rt_get_counters wait for everything in flight.  In modes 2 and 3, rt_device_ptr results for the
+ * G-buffers and the motion buffer (mode 3: and the direct result images) are invalidated by rt_render_frame (rt_run_stage never rotates buffers).
+ * Also settable with RESTIR_OVERLAP=0|1|2|3 before rt_create. */
 int rt_set_overlap(rt_ctx* ctx, int mode);
 /* Priorities of the indirect-stage stream and the filter stream of mode 2 (levels: -1 low, 0 normal, +1 high).  The reference submits its dispatches to ONE queue
  * (src/renderer.cpp:154-206) and has no such choice; here three streams share the chip and the fastest setting depends on the workload

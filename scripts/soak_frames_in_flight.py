@@ -31,7 +31,7 @@ def run(overlap):
     return dig, dt / N * 1e3
 
 
-a, ta = run(2); b, tb = run(2); c, tc = run(0)
-bad = [k for k in a if not (a[k] == b[k] == c[k])]
-print(f"{N} frames: in flight {ta:.3f} / {tb:.3f} ms per frame, serial {tc:.3f}; buffers compared {len(a)}, differing {len(bad)} {bad}")
+a, ta = run(2); b, tb = run(2); c, tc = run(0); d, td = run(3)      # (round 6: + three frames in flight, rt_set_overlap 3)
+bad = [k for k in a if not (a[k] == b[k] == c[k] == d[k])]
+print(f"{N} frames: in flight {ta:.3f} / {tb:.3f} ms per frame, three in flight {td:.3f}, serial {tc:.3f}; buffers compared {len(a)}, differing {len(bad)} {bad}")
 sys.exit(1 if bad else 0)

@@ -59,26 +59,30 @@ def test_band_parity_vs_oracle_and_determinism(bistro):
 
 def test_frames_in_flight_equal_serial_frames(bistro, monkeypatch):
     """rt_render_frame keeps consecutive frames in flight (direct(f+1) beside indirect(f) and the filters of f, rotated
-    G-buffer / motion buffers).  Eight back-to-back frames with a moving camera must leave exactly the buffers that the same
-    frames leave when every stage runs alone on one stream (RESTIR_OVERLAP=0)."""
+    G-buffer / motion buffers).  Twelve back-to-back frames with a moving camera must leave exactly the buffers that the same
+    frames leave when every stage runs alone on one stream (RESTIR_OVERLAP=0) — with two frames in flight (the default) and with three
+    (RESTIR_OVERLAP=3: four G-buffers, three motion buffers and three direct images in rotation; the first three frames are the serial probe frames,
+    so nine frames run through the rotation)."""
     sc, env, st, cam0 = bistro
     eye, center, up, fov = sc.cameraPose()
     cams = []
-    for f in range(8):
+    for f in range(12):
         sc.setCamera(eye + np.array([0.05 * f, 0.01 * f, -0.04 * f], dtype=np.float32), center, up, fov)
         sc.updateCamera(W, H); cams.append(sc.getCamera())
     sc.setCamera(eye, center, up, fov); sc.updateCamera(W, H); sc.updateCamera(W, H)
     out = {}
-    for mode in ("2", "0"):
+    for mode in ("2", "3", "0"):
         monkeypatch.setenv("RESTIR_OVERLAP", mode)
         r = _renderer(sc, env)
         for f, cam in enumerate(cams):
             st.time = 7000 + f
             r.set_camera(cam); r.run(st, f)            # no readback / sync between frames
-        out[mode] = {b: r.readback(b) for b in frame_buffers(7) + [abi.BUF_GBUFFER0, abi.BUF_DIRECT_RESV0, abi.BUF_INDIRECT_RESV0, abi.BUF_INDIRECT_RESULT0]}
+        out[mode] = {b: r.readback(b) for b in frame_buffers(11) + [abi.BUF_GBUFFER0, abi.BUF_GBUFFER1, abi.BUF_MOTION, abi.BUF_DIRECT_RESV0, abi.BUF_INDIRECT_RESV0,
+                                                                     abi.BUF_DIRECT_RESULT0, abi.BUF_INDIRECT_RESULT0]}
         r.destroy()
-    for b in out["0"]:
-        assert np.array_equal(out["2"][b], out["0"][b]), abi.BUFFER_NAMES[b]
+    for mode in ("2", "3"):
+        for b in out["0"]:
+            assert np.array_equal(out[mode][b], out["0"][b]), (mode, abi.BUFFER_NAMES[b])
 
 
 class ThreadComm:
