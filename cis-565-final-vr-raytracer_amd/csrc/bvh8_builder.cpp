@@ -12,6 +12,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
+#include <new>
 #include <thread>
 
 // Defaults of the tree-quality passes, from profiles/r05_bvh_quality_ab.txt (same-box A/Bs on the real-footprint exterior scene, the lite scene, configs 3 and 5):
@@ -40,17 +42,79 @@ struct Box {
 struct Prim { Box b; float c[3]; };
 struct N2 { Box b; uint32_t a, n; bool leaf; };  // internal: children a, a+1; leaf: prims [a, a+n)
 
+// Memory of the build (round 6).  Inside bench.py the BVH2 phase took 3-4.7 s where the same build (same tree hash) took 1.3 s in a process that had just freed a
+// gigabyte (scripts/r06_build_in_process.sh, profiles/r06_bvh_build.txt section 5): the split builder hands every node's references down in fresh vectors — 2.2 GB
+// allocated, touched once and returned over the depth of the tree, from up to 512 threads — and what that costs is the process's address space (mmap / munmap / page faults
+// under one lock, slower still once the HIP runtime has registered its notifiers on it), not the builder's arithmetic.  Two allocators take the operating system out of it:
+//  * BlockPool / PoolAlloc: blocks of power-of-two size on per-size free lists, reused for the whole build and released when the last build in flight ends;
+//  * NoInitAlloc: the 600 MB of BVH2 records are filled by all threads (first touch) instead of by vector::assign on one.
+// Under ASan / TSan the pool passes through to operator new so that the sanitizers keep seeing every list's lifetime.
+struct BlockPool {
+  static constexpr int MINLOG = 16, MAXLOG = 44;   // (64 KB and up: what glibc would take to mmap sooner or later; smaller lists stay in the calling thread's malloc arena)
+  std::mutex mu[MAXLOG + 1];
+  std::vector<void*> fr[MAXLOG + 1];
+  std::mutex muUsers; int users = 0;
+  static BlockPool& get() { static BlockPool P; return P; }
+  static int cls(size_t bytes) { int k = MINLOG; while(k < MAXLOG && (size_t(1) << k) < bytes) k++; return k; }
+  static bool pooled(size_t bytes)
+  {
+#if defined(__SANITIZE_ADDRESS__) || defined(__SANITIZE_THREAD__)
+    (void)bytes; return false;
+#else
+    return bytes >= (size_t(1) << MINLOG) && bytes <= (size_t(1) << MAXLOG);
+#endif
+  }
+  void* alloc(size_t bytes)
+  {
+    if(!pooled(bytes)) return ::operator new(bytes);
+    const int k = cls(bytes);
+    { std::lock_guard<std::mutex> g(mu[k]); if(!fr[k].empty()) { void* p = fr[k].back(); fr[k].pop_back(); return p; } }
+    return ::operator new(size_t(1) << k);
+  }
+  void free(void* p, size_t bytes)
+  {
+    if(!pooled(bytes)) { ::operator delete(p); return; }
+    const int k = cls(bytes);
+    std::lock_guard<std::mutex> g(mu[k]); fr[k].push_back(p);
+  }
+  void enter() { std::lock_guard<std::mutex> g(muUsers); users++; }
+  void leave()   // the last build in flight returns the cached blocks (every list of a build is gone before its scope ends)
+  {
+    std::lock_guard<std::mutex> g(muUsers);
+    if(--users > 0) return;
+    for(int k = 0; k <= MAXLOG; k++) { std::lock_guard<std::mutex> h(mu[k]); for(void* p : fr[k]) ::operator delete(p); fr[k].clear(); fr[k].shrink_to_fit(); }
+  }
+  struct Scope { Scope() { BlockPool::get().enter(); } ~Scope() { BlockPool::get().leave(); } };
+};
+template <class T> struct PoolAlloc {
+  using value_type = T;
+  PoolAlloc() = default;
+  template <class U> PoolAlloc(const PoolAlloc<U>&) {}
+  T* allocate(size_t n) { return static_cast<T*>(BlockPool::get().alloc(n * sizeof(T))); }
+  void deallocate(T* p, size_t n) { BlockPool::get().free(p, n * sizeof(T)); }
+  template <class U> bool operator==(const PoolAlloc<U>&) const { return true; }
+  template <class U> bool operator!=(const PoolAlloc<U>&) const { return false; }
+};
+template <class T> struct NoInitAlloc : std::allocator<T> {   // resize(n) leaves trivially constructible elements untouched
+  template <class U> struct rebind { using other = NoInitAlloc<U>; };
+  NoInitAlloc() = default;
+  template <class U> NoInitAlloc(const NoInitAlloc<U>&) {}
+  template <class U> void construct(U* p) { ::new(static_cast<void*>(p)) U; }
+  template <class U, class... A> void construct(U* p, A&&... a) { ::new(static_cast<void*>(p)) U(std::forward<A>(a)...); }
+};
+using N2Vec = std::vector<N2, NoInitAlloc<N2>>;
+
 struct Builder2 {
   const std::vector<Prim>& prims;
   std::vector<uint32_t>& idx;
-  std::vector<N2> nodes;
-  std::atomic<uint32_t> nodeCount{1};
-  std::atomic<int> liveThreads{0};
-  int maxThreads;
+  N2Vec nodes;
+  alignas(64) std::atomic<uint32_t> nodeCount{1};   // (a line of its own: every node of every thread draws from it)
+  alignas(64) std::atomic<int> liveThreads{0};
+  alignas(64) int maxThreads;
   // (read per build, not once per process: the settings are part of rt_build_accel's cache key)
   const int envNB = getenv("RESTIR_BVH_BINS") ? std::min(64, std::max(4, atoi(getenv("RESTIR_BVH_BINS")))) : 16;
   const float leafSlotCost = getenv("RESTIR_BVH_SLOTCOST") ? float(atof(getenv("RESTIR_BVH_SLOTCOST"))) : 0.25f;  // measured: 0.25 beats 0.5 by 2 % on the Bistro-class scene, bins 16 vs 32 vs 64 make no difference
-  Builder2(const std::vector<Prim>& p, std::vector<uint32_t>& i, int threads) : prims(p), idx(i), nodes(std::max<size_t>(2, 2 * p.size() + 2)), maxThreads(threads) {}
+  Builder2(const std::vector<Prim>& p, std::vector<uint32_t>& i, int threads) : prims(p), idx(i), nodes(std::max<size_t>(2, 2 * p.size() + 2), N2{}), maxThreads(threads) {}
 
   void build(uint32_t node, uint32_t b, uint32_t e)
   {
@@ -131,6 +195,7 @@ struct Builder2 {
 // Results do not depend on it: the verdict of a candidate is a function of (ray, triangle), the closest hit the minimum over (t, id) — testing
 // a triangle twice changes neither; every point of a triangle lies in the (padded) box of at least one of its references.
 struct Ref { Box b; uint32_t tri; };   // b: UNPADDED bounds of the part of triangle `tri` this reference stands for
+using RefVec = std::vector<Ref, PoolAlloc<Ref>>;   // (reference lists come from the build's block pool: see BlockPool)
 
 // fixed-size chunks of [0, n) dealt to at most `threads` threads; f(chunk, begin, end).  The chunking never depends on the thread count, and every use below merges the
 // per-chunk results in chunk order (or with min / max / integer sums, which do not care), so what is built is a function of the input alone.
@@ -160,11 +225,16 @@ template <class F> void parallelChunks(size_t n, size_t chunk, int threads, F f)
 struct BuilderS {
   const std::vector<Tri48>& flat;
   const float pad;
-  std::vector<N2> nodes;
+  N2Vec nodes;
   std::vector<uint32_t> leafTris;
-  std::atomic<int> liveThreads{0};
-  std::atomic<uint64_t> spatialSplits{0}, leafRefs{0};   // statistics (integer sums: the order of the additions does not matter)
-  int64_t rootBudget;
+  // Statistics (integer sums: the order of the additions does not matter).  On lines of their own, and a sequential subtree counts in its Pool and adds ONCE when it is done:
+  // until the end of round 6 every leaf of every subtree did `leafRefs += n` on a line it shared with `nodes` / `leafTris` / `flat` — 2.7 M read-modify-writes from ~300
+  // threads on the line every other access of the builder starts from.  The 289 sequential subtrees of the headline scene (20 ms of work each) took 1.4-2.1 s EACH, 415-620
+  // CPU seconds in all, and the phase 1.2 s or 5 s depending on where the scheduler had put the threads (scripts/r06_build_profile.sh, profiles/r06_bvh_build.txt section 5).
+  alignas(64) std::atomic<int> liveThreads{0};
+  alignas(64) std::atomic<uint64_t> spatialSplits{0};
+  alignas(64) std::atomic<uint64_t> leafRefs{0};
+  alignas(64) int64_t rootBudget;
   int maxThreads;
   float rootArea = 1.f, alpha = 1e-5f;
   int NB = 16, NBS = 16;   // bins of the object / of the spatial split search
@@ -178,12 +248,31 @@ struct BuilderS {
   // (SEQ_MAX 100 000 left sequential subtrees of up to 3 s each — the ones dense with thin triangles — and the build did not scale past 16 threads: 4.8 s on the 256
   //  threads of the GPU box's host; with 16 384 the longest one is a few tenths of a second, profiles/r06_bvh_build.txt)
   const size_t SEQ_MAX = getenv("RESTIR_BVH_SEQ_MAX") ? size_t(std::max(16, atoi(getenv("RESTIR_BVH_SEQ_MAX")))) : 16384;
-  struct Pool { int64_t budget; uint32_t nextNode, nextLeaf; };     // what a sequential subtree still owns
+  struct Pool { int64_t budget; uint32_t nextNode, nextLeaf; uint64_t leafRefs = 0, splits = 0; };     // what a sequential subtree still owns, and what it has counted
+  // RESTIR_BVH_TIMING: where the wall time of this phase goes — the own work (bounds, bins, partition) of the nodes above the sequential subtrees by size class, when the
+  // last of them was done, and the sequential subtrees (count, CPU seconds, the longest, when the last one ended).  Microseconds since the builder was constructed.
+  const bool prof = getenv("RESTIR_BVH_TIMING") && atoi(getenv("RESTIR_BVH_TIMING")) != 0;
+  const std::chrono::steady_clock::time_point profT0 = std::chrono::steady_clock::now();
+  alignas(64) std::atomic<int64_t> cutUs[32] = {}, cutMaxUs[32] = {}, cutEndUs[32] = {}; std::atomic<int> cutN[32] = {};
+  alignas(64) std::atomic<int64_t> seqUs{0}, seqMaxUs{0}, seqEndUs{0}, seqFirstUs{int64_t(1) << 60}; std::atomic<int> seqN{0};
+  int64_t nowUs() const { return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - profT0).count(); }
+  static void amax(std::atomic<int64_t>& a, int64_t v) { int64_t o = a.load(); while(o < v && !a.compare_exchange_weak(o, v)) {} }
+  static void amin(std::atomic<int64_t>& a, int64_t v) { int64_t o = a.load(); while(o > v && !a.compare_exchange_weak(o, v)) {} }
+  void report() const
+  {
+    if(!prof) return;
+    for(int k = 31; k >= 0; k--) if(cutN[k].load())
+      fprintf(stderr, "[bvh8 build]   nodes of 2^%d..2^%d references above the sequential subtrees: %5d, own work %.3f s in all, the longest %.3f s, the last one done at %.3f s\n", k, k + 1,
+              cutN[k].load(), cutUs[k].load() * 1e-6, cutMaxUs[k].load() * 1e-6, cutEndUs[k].load() * 1e-6);
+    fprintf(stderr, "[bvh8 build]   sequential subtrees: %d, %.3f CPU s, the longest %.3f s, first started at %.3f s, last ended at %.3f s\n", seqN.load(), seqUs.load() * 1e-6, seqMaxUs.load() * 1e-6,
+            seqFirstUs.load() * 1e-6, seqEndUs.load() * 1e-6);
+  }
   BuilderS(const std::vector<Tri48>& f, float pad_, size_t n, double budgetFrac, int threads)
     : flat(f), pad(pad_), rootBudget(int64_t(double(n) * budgetFrac)), maxThreads(threads)
   {
     N2 empty; empty.b.reset(); empty.a = 0; empty.n = 0; empty.leaf = true;
-    nodes.assign(2 * (n + size_t(rootBudget)) + 16, empty);
+    nodes.resize(2 * (n + size_t(rootBudget)) + 16);     // (NoInitAlloc: untouched; filled — and first touched — by all threads)
+    parallelChunks(nodes.size(), size_t(1) << 18, std::max(1, threads), [&](size_t, size_t b, size_t e) { for(size_t i = b; i < e; i++) nodes[i] = empty; });
     leafTris.assign(n + size_t(rootBudget) + 16, 0u);
   }
 
@@ -225,11 +314,11 @@ struct BuilderS {
     return true;
   }
 
-  void makeLeaf(N2& N, const std::vector<Ref>& refs, uint32_t leafBase)
+  void makeLeaf(N2& N, const RefVec& refs, uint32_t leafBase, Pool* pool)
   {
     for(size_t k = 0; k < refs.size(); k++) leafTris[leafBase + k] = refs[k].tri;
     N.leaf = true; N.a = leafBase; N.n = uint32_t(refs.size());
-    leafRefs += refs.size();
+    if(pool) pool->leafRefs += refs.size(); else leafRefs += refs.size();
   }
 
   static constexpr int NBMAX = 64;
@@ -274,13 +363,21 @@ struct BuilderS {
 
   // subtree of `refs` rooted at record `node`; its descendants use the records [nodeBase, nodeBase + 2 (|refs| + budget) - 2), its leaves the entries
   // [leafBase, leafBase + |refs| + budget)
-  void build(uint32_t node, std::vector<Ref> refs, int64_t budget, uint32_t nodeBase, uint32_t leafBase, Pool* pool = nullptr)
+  void build(uint32_t node, RefVec refs, int64_t budget, uint32_t nodeBase, uint32_t leafBase, Pool* pool = nullptr)
   {
     Pool own;
     for(;;) {
       N2& N = nodes[node];
       const uint32_t cnt = uint32_t(refs.size());
-      if(!pool && cnt <= SEQ_MAX) { own.budget = budget; own.nextNode = nodeBase; own.nextLeaf = leafBase; pool = &own; }   // from here down: one thread, pooled budget
+      if(!pool && cnt <= SEQ_MAX) {   // from here down: one thread, pooled budget — the subtree as one call on its own pool, its counts added when it returns
+        own.budget = budget; own.nextNode = nodeBase; own.nextLeaf = leafBase;
+        const int64_t t0 = prof ? nowUs() : 0;
+        build(node, std::move(refs), budget, nodeBase, leafBase, &own);
+        leafRefs += own.leafRefs; if(own.splits) spatialSplits += own.splits;
+        if(prof) { const int64_t t1 = nowUs(); seqN++; seqUs += t1 - t0; amax(seqMaxUs, t1 - t0); amax(seqEndUs, t1); amin(seqFirstUs, t0); }
+        return;
+      }
+      const int64_t profStart = (prof && !pool) ? nowUs() : 0;
       if(pool) budget = pool->budget;
       const int par = cnt >= PAR_MIN ? std::max(1, std::min(maxThreads, 32)) : 1;   // (a node has cnt / PAR_CHUNK chunks: 43 at the root of the benchmark scene)
       Box nb, cb; nb.reset(); cb.reset();
@@ -297,7 +394,7 @@ struct BuilderS {
         for(const Ref& r : refs) { nb.grow(r.b); const float c[3] = {0.5f * (r.b.lo[0] + r.b.hi[0]), 0.5f * (r.b.lo[1] + r.b.hi[1]), 0.5f * (r.b.lo[2] + r.b.hi[2])}; cb.grow(c); }
       N.b = nb;
       for(int a = 0; a < 3; a++) { N.b.lo[a] -= pad; N.b.hi[a] += pad; }
-      auto leafHere = [&] { if(pool) { makeLeaf(N, refs, pool->nextLeaf); pool->nextLeaf += cnt; } else makeLeaf(N, refs, leafBase); };
+      auto leafHere = [&] { if(pool) { makeLeaf(N, refs, pool->nextLeaf, pool); pool->nextLeaf += cnt; } else makeLeaf(N, refs, leafBase, nullptr); };
       if(cnt <= 1) { leafHere(); return; }
       // ---- object bins on the reference centroids (the rule of Builder2) ----
       const bool mayAdd = budget > 0;
@@ -313,7 +410,7 @@ struct BuilderS {
       };
       binAll(1);
       // ---- object split ----
-      float best = 3e38f; int bestAxis = -1, bestBin = 0; Box bestL, bestR;
+      float best = 3e38f; int bestAxis = -1, bestBin = 0; Box bestL, bestR; uint32_t bestNL = 0, bestNR = 0;
       for(int ax = 0; ax < 3; ax++) {
         const float ext = cb.hi[ax] - cb.lo[ax];
         if(!(ext > 0)) continue;
@@ -326,7 +423,7 @@ struct BuilderS {
           acc.grow(bb[i]); c += bc[i];
           if(c == 0 || rc[i + 1] == 0) continue;
           const float cost = acc.area() * c + rb[i + 1].area() * rc[i + 1];
-          if(cost < best) { best = cost; bestAxis = ax; bestBin = i; bestL = acc; bestR = rb[i + 1]; }
+          if(cost < best) { best = cost; bestAxis = ax; bestBin = i; bestL = acc; bestR = rb[i + 1]; bestNL = c; bestNR = rc[i + 1]; }
         }
       }
       const float pa = std::max(nb.area(), 1e-30f);
@@ -362,7 +459,7 @@ struct BuilderS {
       if(cnt <= 3) {
         if((bestAxis < 0 && !spatial) || leafSlotCost * pa + chosen >= float(cnt) * pa) { leafHere(); return; }
       }
-      std::vector<Ref> left, right;
+      RefVec left, right;
       if(spatial) {
         left.reserve(sNL); right.reserve(sNR);
         Box L = sL, R = sR; uint32_t nl = sNL, nr = sNR;   // running estimates for the unsplitting rule (Stich et al., 4.4)
@@ -384,10 +481,11 @@ struct BuilderS {
         }
         // no progress, or more references than this subtree may add (cannot happen: the unsplitting rule only lowers the binned estimate checked above): the object split
         if(left.empty() || right.empty() || left.size() >= cnt || right.size() >= cnt || int64_t(left.size() + right.size()) - int64_t(cnt) > budget) { left.clear(); right.clear(); }
-        else spatialSplits++;
+        else if(pool) pool->splits++; else spatialSplits++;
       }
       if(left.empty()) {
         if(bestAxis >= 0) {
+          left.reserve(bestNL); right.reserve(bestNR);   // (the bin counts of the chosen split: one allocation per list)
           const float ext = cb.hi[bestAxis] - cb.lo[bestAxis], k1 = NB * (1.f - 1e-6f) / ext, lo = cb.lo[bestAxis];
           for(const Ref& r : refs) {
             const int bi = std::min(NB - 1, std::max(0, int((0.5f * (r.b.lo[bestAxis] + r.b.hi[bestAxis]) - lo) * k1)));
@@ -398,7 +496,7 @@ struct BuilderS {
           left.assign(refs.begin(), refs.begin() + cnt / 2); right.assign(refs.begin() + cnt / 2, refs.end());
         }
       }
-      std::vector<Ref>().swap(refs);
+      RefVec().swap(refs);
       const int64_t rest = budget - (int64_t(left.size() + right.size()) - int64_t(cnt));
       if(pool) {   // sequential subtree: the two child records from the pool, the left child first; what it leaves of the budget is the right child's
         pool->budget = rest;
@@ -415,6 +513,7 @@ struct BuilderS {
       const int64_t bl = std::min<int64_t>(rest, std::max<int64_t>(0, int64_t(double(rest) * (wl / (wl + wr))))), br = rest - bl;
       const uint32_t child = nodeBase;
       const uint32_t lNodes = uint32_t(2 * (int64_t(left.size()) + bl) - 2), lLeaves = uint32_t(int64_t(left.size()) + bl);
+      if(prof) { int k = 0; while((uint32_t(2) << k) <= cnt && k < 31) k++; const int64_t t1 = nowUs(); cutN[k]++; cutUs[k] += t1 - profStart; amax(cutMaxUs[k], t1 - profStart); amax(cutEndUs[k], t1); }
       N.leaf = false; N.a = child; N.n = 0;
       const uint32_t lBase = nodeBase + 2, rBase = nodeBase + 2 + lNodes, lLeaf = leafBase, rLeaf = leafBase + lLeaves;
       if(liveThreads.load() < 2 * maxThreads) {   // (half of these threads wait in join() for their children)
@@ -436,7 +535,7 @@ struct BuilderS {
 // subtree by index, so an exchange is a swap of two records.  RESTIR_BVH_ROTATE = number of passes (0 = off).
 inline Box unite(const Box& x, const Box& y) { Box r = x; r.grow(y); return r; }
 // the best exchange at internal record n, applied; false: none improves
-inline bool rotateAt(std::vector<N2>& N, uint32_t n, bool gg)
+inline bool rotateAt(N2Vec& N, uint32_t n, bool gg)
 {
   N2& P = N[n];
   if(P.leaf) return false;
@@ -489,7 +588,7 @@ inline bool rotateAt(std::vector<N2>& N, uint32_t n, bool gg)
 // of which the pass has already visited, so the order taken at the start of the pass stays bottom-up.  Parallel (round 6): the tree is cut ROT_CUT levels below the
 // root; the subtrees under the cut are independent — one task each — and the few records above it follow serially.  Which thread runs a subtree changes nothing in it:
 // the result is the sequential pass's, for any thread count.
-uint64_t rotatePass(std::vector<N2>& N, bool gg, int threads)
+uint64_t rotatePass(N2Vec& N, bool gg, int threads)
 {
   constexpr int ROT_CUT = 9;   // up to 512 subtrees
   std::vector<uint32_t> top, roots;
@@ -525,11 +624,11 @@ uint64_t rotatePass(std::vector<N2>& N, bool gg, int threads)
 // a branch-and-bound search from the root.  Records carry their subtree by index (children are the adjacent records a, a + 1), so removal and insertion move
 // three records and refit the boxes on two root paths.  RESTIR_BVH_REINSERT = passes (0 = off), each over the worst 2 % of the internal nodes.
 struct Reinserter {
-  std::vector<N2>& N;
+  N2Vec& N;
   uint32_t count;
   std::vector<int32_t> parent;
   uint64_t moved = 0;
-  Reinserter(std::vector<N2>& n, uint32_t c) : N(n), count(c), parent(c, -1)
+  Reinserter(N2Vec& n, uint32_t c) : N(n), count(c), parent(c, -1)
   {
     for(uint32_t i = 0; i < c; i++) if(!N[i].leaf) { parent[N[i].a] = int32_t(i); parent[N[i].a + 1] = int32_t(i); }
   }
@@ -734,7 +833,8 @@ bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads, bool plai
     // does not is the build redone with shares of the cap itself, which bound the total by construction.  Both attempts are deterministic.
     const size_t RCH = size_t(1) << 16;
     Box root; root.reset();
-    std::vector<Ref> refs0(n);
+    BlockPool::Scope poolScope;
+    RefVec refs0(n);
     {
       std::vector<Box> rootOf((n + RCH - 1) / RCH);
       parallelChunks(n, RCH, std::max(1, threads), [&](size_t c, size_t b0, size_t e0) {
@@ -755,14 +855,15 @@ bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads, bool plai
       const bool strict = attempt == 1 || workBudget <= splitBudget;
       BS.reset();   // (release the first attempt's arrays before the second one allocates)
       BS.reset(new BuilderS(flat, pad, n, strict ? splitBudget : workBudget, std::max(1, threads)));
-      std::vector<Ref> refs = refs0;
-      if(strict) std::vector<Ref>().swap(refs0);
+      RefVec refs = refs0;
+      if(strict) RefVec().swap(refs0);
       BS->rootArea = std::max(root.area(), 1e-30f); BS->alpha = splitAlpha;
       BS->NB = getenv("RESTIR_BVH_BINS") ? std::min(64, std::max(4, atoi(getenv("RESTIR_BVH_BINS")))) : 16;
       BS->NBS = getenv("RESTIR_BVH_SBINS") ? std::min(64, std::max(4, atoi(getenv("RESTIR_BVH_SBINS")))) : 16;
       BS->leafSlotCost = getenv("RESTIR_BVH_SLOTCOST") ? float(atof(getenv("RESTIR_BVH_SLOTCOST"))) : 0.25f;
       BS->areaRule = getenv("RESTIR_BVH_BUDGET_RULE") && strcmp(getenv("RESTIR_BVH_BUDGET_RULE"), "area") == 0;
       BS->build(0, std::move(refs), BS->rootBudget, 1u, 0u);
+      BS->report();
       n2count = uint32_t(BS->nodes.size());   // (record ranges are handed out per subtree: the records in use are not contiguous)
       out.references = BS->leafRefs.load(); out.spatialSplits = BS->spatialSplits.load();
       if(strict || double(out.references - n) <= double(n) * splitBudget) break;
@@ -777,7 +878,7 @@ bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads, bool plai
   {
     const bool dp = plainTree;   // (plain tree: no quality passes.  The SAH-optimal collapse takes its bottom-up order from the tree itself since round 5, so the passes may run before it)
     const int rotate = dp ? 0 : (getenv("RESTIR_BVH_ROTATE") ? atoi(getenv("RESTIR_BVH_ROTATE")) : RT_BVH_ROTATE_DEFAULT);
-    std::vector<N2>& M = BS ? BS->nodes : B2->nodes;
+    N2Vec& M = BS ? BS->nodes : B2->nodes;
     const bool rotateGG = getenv("RESTIR_BVH_ROTATE_GG") && atoi(getenv("RESTIR_BVH_ROTATE_GG")) != 0;
     const int reins = dp ? 0 : (getenv("RESTIR_BVH_REINSERT") ? atoi(getenv("RESTIR_BVH_REINSERT")) : RT_BVH_REINSERT_DEFAULT);
     if(reins > 0) {
@@ -788,7 +889,7 @@ bool buildBvh8(const rt_scene_desc& sc, BuildOutput& out, int threads, bool plai
     for(int pass = 0; pass < rotate; pass++) { const uint64_t k = rotatePass(M, rotateGG, std::max(1, threads)); out.rotations += k; if(k == 0) break; }
   }
   timer.lap("rotations / reinsertion");
-  const std::vector<N2>& N = BS ? BS->nodes : B2->nodes;
+  const N2Vec& N = BS ? BS->nodes : B2->nodes;
   const std::vector<uint32_t>& leafTris = BS ? BS->leafTris : idx;
 
   // ---- 3a. which BVH2 nodes become wide nodes: SAH-optimal collapse (Ylitie, Karras, Laine 2017, §3.1) -------------------------

@@ -89,10 +89,17 @@ void Frame::parallelRows(int rows, int rowBegin, int rowEnd, F&& fn) const
     if(sched_getaffinity(0, sizeof(set), &set) == 0) for(int c = 0; c < CPU_SETSIZE; c++) if(CPU_ISSET(c, &set)) cpus.push_back(c);
   }
   for(int t = 0; t < nt; t++) {
-    pool.emplace_back([&] { for(;;) { int y = next.fetch_add(1); if(y >= rowEnd) break; fn(y); } cnt.flush(); });
     // (round 6: the workers are SPREAD over the CPUs of the mask — worker t on CPU t * ncpu / nt — instead of packed on the first nt: 32 workers on CPUs 0-31 shared four L3
-    //  slices and two memory channels' worth of a 256-CPU host and ran at 0.53 of the single-thread rate each, profiles/r05_cpu_baseline.txt)
-    if(!cpus.empty()) { cpu_set_t one; CPU_ZERO(&one); CPU_SET(cpus[(size_t(t) * cpus.size() / size_t(nt)) % cpus.size()], &one); (void)pthread_setaffinity_np(pool.back().native_handle(), sizeof(one), &one); }
+    //  slices and two memory channels' worth of a 256-CPU host and ran at 0.53 of the single-thread rate each, profiles/r05_cpu_baseline.txt.)
+    // A worker pins ITSELF.  Until the end of round 6 the spawning thread pinned worker t through its handle after creating it — and glibc's pthread_setaffinity_np on a
+    // thread that has already exited (a worker that found no row left: short stages, more threads than rows) is sched_setaffinity(0, ...): it pinned the CALLER to that one
+    // CPU.  From then on `cpus` had one entry and every later worker — inheriting the caller's mask when not pinned — ran on that CPU: 128 / 256 threads measured 1.00 CPUs
+    // busy (scripts/r06_oracle_scaling.py, profiles/r06_cpu_baseline.txt).  That, not the allocator, is why the baseline "peaked at 32 threads" in rounds 4-6.
+    pool.emplace_back([&, t] {
+      if(!cpus.empty()) { cpu_set_t one; CPU_ZERO(&one); CPU_SET(cpus[(size_t(t) * cpus.size() / size_t(nt)) % cpus.size()], &one); (void)pthread_setaffinity_np(pthread_self(), sizeof(one), &one); }
+      for(;;) { int y = next.fetch_add(1); if(y >= rowEnd) break; fn(y); }
+      cnt.flush();
+    });
   }
   for(auto& th : pool) th.join();
 }
