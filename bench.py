@@ -1222,16 +1222,37 @@ def emulate_child(args, abi, host, scene, env, st, desc, single, W, H, device):
     return None
 
 
+def cpu_quota():
+    """CPUs the container's cgroup quota allows (cgroup v2 cpu.max / v1 cfs quota, rounded up), or None — include/rt_cpus.h is the C side of this"""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else max(1, -(-int(q) // int(p)))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return max(1, -(-q // p)) if q > 0 and p > 0 else None
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(abi, host, scene, env, st, desc, W, H, frame0, di_only=False):
-    """The CPU oracle (naive binary BVH + scalar C++, std::thread workers) on bounded samples of the SAME frame, built to repeat (round-4 verdict, weak 7: four
-    driver runs gave 0.36 .. 1.12 Mrays/s): workers are pinned to the CPUs of the process's affinity mask, every point is the BEST of its passes (a pass can
-    only be slowed by whatever else the host runs, never sped up), and the rate is reported at three thread counts — 1, 32 and all — each on a band sized to
-    ~2-6 s of work (rows around the image centre, cold temporal history, the full 12-dispatch frame; config 2: its direct stage), with the per-thread rate and
-    the host's load average beside it.  `value` is the all-threads point."""
+    """The CPU oracle (naive binary BVH + scalar C++, std::thread workers) on bounded samples of the SAME frame: rows around the image centre, cold temporal history, the full
+    12-dispatch frame (config 2: its direct stage), every point the BEST of its passes (a pass can only be slowed by whatever else the host runs), the host's load average
+    beside it.
+    Round 6 found what had shaped this leg since round 4 (profiles/r06_cpu_baseline.txt).  (1) The box's container may use SIXTEEN of the machine's 256 hardware threads
+    (cgroup cpu.max): 16-19 CPUs were busy whatever the thread count, so "cores: 128" described the request, not the resource.  (2) The oracle pinned a worker through its
+    handle after creating it, and doing that to a worker that had already exited pinned the CALLER: from some dispatch on, every worker of the 128- and 256-thread points ran on
+    one CPU (fixed in oracle/orc_stages.h).  Now: `cores` = the CPUs the process can keep busy (affinity mask and cgroup quota), thread counts 1 / cores / 2 x cores / 4 x cores,
+    workers pinned only where there is no quota (a pinned worker cannot move off a CPU another tenant is using, and under a quota the scheduler's choice measured 40 % better);
+    `value` is the best point."""
     from oracle.binding import Oracle
     o = Oracle(0)
     o.upload_scene(desc)
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = cpu_quota()
+    cores = max(1, min(ncpu, quota) if quota else ncpu)
+    pin = quota is None or quota >= ncpu
     load0 = os.getloadavg()
     st.time = 1000 + frame0
 
@@ -1239,7 +1260,7 @@ def cpu_baseline(abi, host, scene, env, st, desc, W, H, frame0, di_only=False):
         h0, h1 = y0 // 2, y1 // 2
         o.resize(W, H); o.set_camera(scene.getCamera())          # (re-allocates the screen buffers: cold history every pass)
         o.reset_counters()
-        t0 = time.perf_counter()
+        t0, c0 = time.perf_counter(), time.process_time()
         o.run_stage(st, frame0, abi.STAGE_DIRECT, 0, y0, y1)
         if not di_only:
             o.run_stage(st, frame0, abi.STAGE_INDIRECT, 0, h0, h1)
@@ -1248,35 +1269,34 @@ def cpu_baseline(abi, host, scene, env, st, desc, W, H, frame0, di_only=False):
             for l in range(5):
                 o.run_stage(st, frame0, abi.STAGE_DENOISE_INDIRECT, l, h0, h1)
             o.run_stage(st, frame0, abi.STAGE_COMPOSE, 0, y0, y1)
-        dt = time.perf_counter() - t0
+        dt, cpu = time.perf_counter() - t0, time.process_time() - c0
         c = o.counters()
-        return c.closestHitRays + c.anyHitRays, dt
+        return c.closestHitRays + c.anyHitRays, dt, cpu
 
     mid = (H // 2 // 16) * 16
 
     def point(threads, rows, passes, budget_s):
         """best of up to `passes` passes (at least 2, until budget_s is spent) over `rows` rows around the image centre"""
-        o.set_threads(threads, pin=True)
+        o.set_threads(threads, pin=pin)
         y0, y1 = max(0, mid - rows // 2), min(H, mid + rows // 2)
         got, spent = [], 0.0
         while len(got) < passes and (len(got) < 2 or spent < budget_s):
-            rays, dt = band(y0, y1)
-            got.append((rays / dt, rays, dt)); spent += dt
+            rays, dt, cpu = band(y0, y1)
+            got.append((rays / dt, rays, dt, cpu)); spent += dt
         best = max(got)
         return {"threads": threads, "rows": [y0, y1], "mrays_s": round(best[0] / 1e6, 4), "per_thread_mrays_s": round(best[0] / 1e6 / threads, 5), "passes": len(got),
-                "spread": [round(min(g[0] for g in got) / 1e6, 4), round(best[0] / 1e6, 4)], "rays": int(best[1]), "seconds_best": round(best[2], 3), "cpu_seconds": round(spent, 1)}
+                "spread": [round(min(g[0] for g in got) / 1e6, 4), round(best[0] / 1e6, 4)], "rays": int(best[1]), "seconds_best": round(best[2], 3),
+                "cpus_busy": round(best[3] / max(best[2], 1e-9), 1), "wall_s_all_passes": round(spent, 1)}
 
-    o.set_threads(min(ncpu, 32), pin=True)
+    o.set_threads(cores, pin=pin)
     band(max(0, mid - 16), min(H, mid + 16))                      # warm-up (page cache, BVH in the host caches), not reported
-    # rows per point: whole multiples of the thread count keep the dynamic row scheduler balanced (one thread per row leaves the slowest row as the pass time)
-    # Thread counts 1, 32, 128 and all; every point on >= 4 rows per thread (the row scheduler is dynamic: with one row per thread a pass lasts as long as its
-    # slowest row) and the best of >= 3 passes.  `value` is the BEST point, not the all-threads one: on a shared host (load average 40-100 on the pool's boxes) the
-    # all-threads point moves by 2x with the neighbours' load while the middle points and the per-thread rate repeat.
-    def rows_for(t):
-        return min(H - H % 16, max(16, (4 * t + 15) // 16 * 16))
-    counts = sorted({1, min(ncpu, 32), min(ncpu, 128), ncpu})
-    pts = [point(t, 8 if t == 1 else rows_for(t), 3, 3.0 if t > 1 else 0.0) for t in counts]
-    allp = max(pts, key=lambda q: q["mrays_s"])
+    # Every point but the single thread runs the SAME band (comparable rays), >= 4 rows per thread of the largest count (the row scheduler is dynamic: with one row per thread a
+    # pass lasts as long as its slowest row); the single thread takes 8 rows of its middle — the horizon rows, the dearest rays of the frame: its rate is a lower bound, which is
+    # why no "parallel efficiency" is derived from it any more.
+    counts = sorted({t for t in (cores, 2 * cores, 4 * cores) if t <= max(cores, 1024)})
+    rows_all = min(H - H % 16, max(16, (4 * counts[-1] + 15) // 16 * 16, 512 if not di_only else 64))
+    pts = [point(1, 8, 2, 0.0)] + [point(t, rows_all, 3, 3.0) for t in counts]
+    allp = max(pts[1:], key=lambda q: q["mrays_s"])
     # the best thread count once more at the end of the leg (the neighbours' load moves within seconds): the better of its two visits is the point
     again = point(allp["threads"], allp["rows"][1] - allp["rows"][0], 4, 4.0)
     if again["mrays_s"] > allp["mrays_s"]:
@@ -1286,13 +1306,15 @@ def cpu_baseline(abi, host, scene, env, st, desc, W, H, frame0, di_only=False):
         allp["passes"] += again["passes"]; allp["spread"] = [min(again["spread"][0], allp["spread"][0]), allp["spread"][1]]
     load1 = os.getloadavg()
     y0, y1 = allp["rows"]
-    return {"value": allp["mrays_s"], "unit": "Mrays/s", "cores": allp["threads"], "host_cpus": ncpu, "threads_used": allp["threads"], "per_thread": allp["per_thread_mrays_s"], "kind": "port",
-            "single_thread": pts[0]["mrays_s"], "pinned": True, "statistic": "best pass of each point; value = the best point", "scaling": pts,
-            "parallel_efficiency_vs_1": round(allp["per_thread_mrays_s"] / max(1e-12, pts[0]["per_thread_mrays_s"]), 3),
+    return {"value": allp["mrays_s"], "unit": "Mrays/s", "cores": min(cores, allp["threads"]), "host_cpus": ncpu, "cpu_quota": quota, "threads_used": allp["threads"],
+            "cpus_busy": allp["cpus_busy"], "per_core": round(allp["mrays_s"] / max(1, min(cores, allp["threads"])), 5), "kind": "port",
+            "single_thread": pts[0]["mrays_s"], "single_thread_rows": pts[0]["rows"], "pinned": pin, "statistic": "best pass of each point; value = the best point", "scaling": pts,
             "host_loadavg_before_after": [round(load0[0], 2), round(load1[0], 2)],
-            "sample": f"rows {y0}..{y1} of one {W}x{H} frame ({'direct stage' if di_only else 'all 12 dispatches'}, cold temporal history) on {allp['threads']} pinned threads: best of "
-                      f"{allp['passes']} passes ({allp['spread'][0]}..{allp['spread'][1]} Mrays/s), {allp['rays']} rays in {allp['seconds_best']:.2f} s => "
-                      f"{allp['seconds_best'] * H / max(1, y1 - y0) * 1e3:.0f} ms/frame extrapolated; the other thread counts ({', '.join(str(q['threads']) for q in pts)}) in `scaling`"}
+            "sample": f"rows {y0}..{y1} of one {W}x{H} frame ({'direct stage' if di_only else 'all 12 dispatches'}, cold temporal history) on {allp['threads']} threads"
+                      f"{' (pinned)' if pin else ''} of a process that may use {cores} of the host's {ncpu} CPUs ({'cgroup quota' if quota and quota < ncpu else 'affinity mask'}; "
+                      f"{allp['cpus_busy']} busy on average): best of {allp['passes']} passes ({allp['spread'][0]}..{allp['spread'][1]} Mrays/s), {allp['rays']} rays in "
+                      f"{allp['seconds_best']:.2f} s => {allp['seconds_best'] * H / max(1, y1 - y0) * 1e3:.0f} ms/frame extrapolated; the other thread counts "
+                      f"({', '.join(str(q['threads']) for q in pts)}) in `scaling`"}
 
 
 if __name__ == "__main__":

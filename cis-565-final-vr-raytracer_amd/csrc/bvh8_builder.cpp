@@ -4,6 +4,7 @@
 // closest hit is a function of the triangle set only, never of the tree.
 #include "bvh8_builder.h"
 #include "dev_math.h"
+#include "../../include/rt_cpus.h"
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -264,7 +265,7 @@ struct BuilderS {
     for(int k = 31; k >= 0; k--) if(cutN[k].load())
       fprintf(stderr, "[bvh8 build]   nodes of 2^%d..2^%d references above the sequential subtrees: %5d, own work %.3f s in all, the longest %.3f s, the last one done at %.3f s\n", k, k + 1,
               cutN[k].load(), cutUs[k].load() * 1e-6, cutMaxUs[k].load() * 1e-6, cutEndUs[k].load() * 1e-6);
-    fprintf(stderr, "[bvh8 build]   sequential subtrees: %d, %.3f CPU s, the longest %.3f s, first started at %.3f s, last ended at %.3f s\n", seqN.load(), seqUs.load() * 1e-6, seqMaxUs.load() * 1e-6,
+    fprintf(stderr, "[bvh8 build]   sequential subtrees: %d, %.3f thread-seconds (wall), the longest %.3f s, first started at %.3f s, last ended at %.3f s\n", seqN.load(), seqUs.load() * 1e-6, seqMaxUs.load() * 1e-6,
             seqFirstUs.load() * 1e-6, seqEndUs.load() * 1e-6);
   }
   BuilderS(const std::vector<Tri48>& f, float pad_, size_t n, double budgetFrac, int threads)
@@ -1176,7 +1177,7 @@ extern "C" int rt_bvh8_selfcheck(const rt_scene_desc* scene, int samplesPerTri, 
   if(!scene || !out || !outF) return -1;
   rt::BuildOutput bo;
   const auto t0 = std::chrono::steady_clock::now();
-  const int threads = std::max(1, int(std::thread::hardware_concurrency()));
+  const int threads = rt_cpu_budget();
   if(!rt::buildBvh8(*scene, bo, threads)) return -2;
   outF[2] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   outF[0] = bo.sahNodeSteps; outF[1] = bo.sahTriSteps; outF[3] = bo.sahNodeStepsQ; outF[4] = bo.sahTriStepsQ;

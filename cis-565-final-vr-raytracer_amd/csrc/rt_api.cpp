@@ -17,6 +17,7 @@
 #include <unordered_map>
 #include <vector>
 #include "../../include/rt_abi.h"
+#include "../../include/rt_cpus.h"
 #include "bvh8_builder.h"
 #include "stages.h"
 
@@ -518,7 +519,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
         c->alphaHash[i] = {h0, h1};
       }
     };
-    const size_t nt = std::min<size_t>(c->hostAlpha.size(), std::max(1u, std::thread::hardware_concurrency()));
+    const size_t nt = std::min<size_t>(c->hostAlpha.size(), size_t(rt_cpu_budget()));
     std::vector<std::thread> pool;
     for(size_t k = 1; k < nt; k++) pool.emplace_back(work);
     work();
@@ -594,7 +595,7 @@ static int buildHostAccel(rt_ctx* c, HostAccel& out)
   d.numIndices = c->indices.size(); d.indices = c->indices.data();
   d.numInstances = uint32_t(c->instances.size()); d.instances = c->instances.data();
   BuildOutput& bo = out.bo;
-  int threads = int(std::thread::hardware_concurrency());
+  int threads = rt_cpu_budget();   // (the cgroup quota, not the machine: include/rt_cpus.h)
   if(!buildBvh8(d, bo, threads > 0 ? threads : 1)) return fail(c, RT_ERR_INVALID_ARG, "rt_build_accel: BVH8 build failed");
   if(bo.maxDepth > STACK_MAX) {
     // rotations and spatial splits can deepen a tree: before giving up, the tree of rounds 1-4 (object splits only), which would have built (advisor finding of round 5)

@@ -8,6 +8,7 @@
 // KHR_materials_transmission, KHR_materials_ior, KHR_materials_emissive_strength; KHR_lights_punctual; perspective cameras;
 // samplers; PNG images (every colour type / bit depth, Adam7 included, via zlib) and JPEG images (baseline / progressive, jpeg_decoder.cpp).
 #include "scene.hpp"
+#include "../../include/rt_cpus.h"
 #include <zlib.h>
 #include <atomic>
 #include <mutex>
@@ -376,7 +377,7 @@ bool loadGltfFile(const std::string& filename, GltfScene& out, std::string& erro
         images[i] = std::move(t);
       }
     };
-    const size_t nt = std::min<size_t>(images.size(), std::max(1u, std::thread::hardware_concurrency()));
+    const size_t nt = std::min<size_t>(images.size(), size_t(rt_cpu_budget()));
     std::vector<std::thread> pool;
     for(size_t k = 1; k < nt; k++) pool.emplace_back(work);
     work();
@@ -640,7 +641,7 @@ bool saveGltfFile(const std::string& filename, const GltfScene& g, std::string& 
         if(!pf) failed = true;
       }
     };
-    const size_t nt = std::min<size_t>(std::max<size_t>(1, g.textures.size()), std::max(1u, std::thread::hardware_concurrency()));
+    const size_t nt = std::min<size_t>(std::max<size_t>(1, g.textures.size()), size_t(rt_cpu_budget()));
     std::vector<std::thread> pool;
     for(size_t k = 1; k < nt; k++) pool.emplace_back(work);
     work();

@@ -4,6 +4,7 @@
 // BASELINE.json config gets a generator with the same triangle count class, material/texture mix, emissive-mesh
 // count and alpha-masked foliage fraction.  Everything is a function of (kind, scale, seed).
 #include "scene.hpp"
+#include "../../include/rt_cpus.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -302,7 +303,7 @@ void fillTextures(Builder& B, const std::vector<TexJob>& jobs)
       fillTextureRows(B.g.textures[size_t(J.index)], J.kind, J.seed, J.tint, chunks[c].y0, chunks[c].y1, J.variant);
     }
   };
-  const unsigned nt = std::max(1u, std::min(256u, std::thread::hardware_concurrency()));
+  const unsigned nt = unsigned(std::min(256, rt_cpu_budget()));
   std::vector<std::thread> pool;
   for(unsigned i = 1; i < nt; i++) pool.emplace_back(work);
   work();

@@ -1,6 +1,7 @@
 // orc_capi.cpp — ctypes-facing C entry points of the CPU oracle (liboracle.so).
 // TEST INFRASTRUCTURE: loaded only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
 #include "orc_stages.h"
+#include "../include/rt_cpus.h"
 #include <cstdio>
 #include <thread>
 
@@ -59,7 +60,7 @@ extern "C" {
 void* orc_create(int threads)
 {
   Ctx* c = new Ctx();
-  if(threads <= 0) threads = int(std::thread::hardware_concurrency());
+  if(threads <= 0) threads = rt_cpu_budget();
   c->frame.threads = threads > 0 ? threads : 1;
   c->frame.scene = &c->scene;
   return c;
@@ -70,7 +71,7 @@ int orc_threads(void* p) { return static_cast<Ctx*>(p)->frame.threads; }
 void orc_set_threads(void* p, int threads, int pin)
 {
   Ctx* c = static_cast<Ctx*>(p);
-  if(threads <= 0) threads = int(std::thread::hardware_concurrency());
+  if(threads <= 0) threads = rt_cpu_budget();
   c->frame.threads = threads > 0 ? threads : 1; c->frame.pin = pin != 0;
 }
 int orc_upload_scene(void* p, const rt_scene_desc* d)

@@ -48,10 +48,10 @@ def test_header_is_valid_c_and_cpp(tmp_path):
     """include/rt_abi.h and include/rt_detmath.h are the boundary: they must compile as plain C11 and as C++17 on their own."""
     import subprocess
     inc = os.path.join(ROOT, "include")
-    (tmp_path / "t.c").write_text('#include "rt_abi.h"\n#include "rt_detmath.h"\nint main(void) { rt_state s; (void)s; return (int)(rt_exp(0.0f) != 1.0f) + (int)(sizeof(rt_tonemapper) != 48); }\n')
+    (tmp_path / "t.c").write_text('#include "rt_abi.h"\n#include "rt_detmath.h"\n#include "rt_cpus.h"\nint main(void) { rt_state s; (void)s; return (int)(rt_exp(0.0f) != 1.0f) + (int)(sizeof(rt_tonemapper) != 48) + (int)(rt_cpu_budget() < 1); }\n')
     subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", inc, str(tmp_path / "t.c"), "-o", str(tmp_path / "tc"), "-lm"])
     assert subprocess.call([str(tmp_path / "tc")]) == 0
-    (tmp_path / "t.cpp").write_text('#include "rt_abi.h"\n#include "rt_detmath.h"\nint main() { rt_scene_desc d{}; (void)d; return rt_sin(0.0f) != 0.0f; }\n')
+    (tmp_path / "t.cpp").write_text('#include "rt_abi.h"\n#include "rt_detmath.h"\n#include "rt_cpus.h"\nint main() { rt_scene_desc d{}; (void)d; return (rt_sin(0.0f) != 0.0f) + (rt_cpu_budget() < 1) + (rt_cpu_quota() < 0); }\n')
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", inc, str(tmp_path / "t.cpp"), "-o", str(tmp_path / "tcpp")])
     assert subprocess.call([str(tmp_path / "tcpp")]) == 0
 
