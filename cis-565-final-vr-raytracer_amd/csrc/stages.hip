@@ -62,6 +62,19 @@ namespace RT_VARIANT {
 #ifndef RT_DIRECT_LB
 #define RT_DIRECT_LB 5
 #endif
+// Register cap of the traced kernels below what the launch bounds give (96 at 5 waves per SIMD).  Why one would: 5 x 96 = 480 of a SIMD's 512 registers — the 32 left
+// hold no wave of the filter chain (k_denoise_lds: 50-57), which therefore only gets a slot when a traversal wave retires and stretches 6x with frames in flight;
+// 5 x 88 + 56 = 496 would fit one.  Measured in round 6: profiles/r06_vgpr_room_ab.txt.
+#ifdef RT_DIRECT_VGPR
+#define RT_DIRECT_VGPR_ATTR __attribute__((amdgpu_num_vgpr((RT_DIRECT_VGPR) / 2)))   // (gfx90a and later: the backend doubles the attribute — unified VGPR / AGPR file)
+#else
+#define RT_DIRECT_VGPR_ATTR
+#endif
+#ifdef RT_INDIRECT_VGPR
+#define RT_INDIRECT_VGPR_ATTR __attribute__((amdgpu_num_vgpr((RT_INDIRECT_VGPR) / 2)))
+#else
+#define RT_INDIRECT_VGPR_ATTR
+#endif
 // ReSTIRDirect (direct_stage.comp:150-270) cut at its one shadow ray, so that the ray can be traced by whatever the build uses (the lane's own
 // traversal loop in the throughput build, the workgroup's ray pool in the latency build) while both builds share every line of shading:
 //   directPre   primary hit -> G-buffer, motion vector, M-candidate RIS (or the single DirectLight sample); returns whether a shadow ray is needed
@@ -276,7 +289,7 @@ __global__ __launch_bounds__(512, RT_LAT_DIRECT_WAVES) void k_direct_stage(DevSc
 #endif
 }
 #else
-__global__ __launch_bounds__(64, RT_DIRECT_LB) void k_direct_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY)
+__global__ __launch_bounds__(64, RT_DIRECT_LB) RT_DIRECT_VGPR_ATTR void k_direct_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY)
 {
   extern __shared__ uint2 s_stack[];
 #if RT_WAVEPROF
@@ -867,7 +880,7 @@ RT_DEV void indirectMultiBouncePersistent(const DevScene& S, const DevFrame& F, 
 __global__ __launch_bounds__(512, 4) void k_indirect_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY, int cap,
                                                        const uint32_t* lists, uint32_t* counts, int subShift, int sbK, int genericBlocks, int persist)
 #else
-__global__ __launch_bounds__(64, RT_INDIRECT_LB) void k_indirect_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY, int cap,
+__global__ __launch_bounds__(64, RT_INDIRECT_LB) RT_INDIRECT_VGPR_ATTR void k_indirect_stage(DevScene S, DevFrame F, rt_state st, rt_scene_camera cam, int rowBegin, int rowEnd, int tilesX, int tilesY, int cap,
                                                           const uint32_t* lists, uint32_t* counts, int subShift, int sbK, int genericBlocks, int persist)
 #endif
 {
