@@ -72,6 +72,51 @@ def test_frame_is_deterministic_and_thread_independent():
         assert np.array_equal(a, b)
 
 
+def test_pinned_workers_leave_the_callers_affinity_alone():
+    """Round 6: the spawning thread used to pin worker t through its handle — and glibc's pthread_setaffinity_np on a worker that had ALREADY EXITED (more threads than
+    rows, short stages) is sched_setaffinity(0, ...): it pinned the CALLER to one CPU, and every later worker with it (bench.py's 128- / 256-thread points ran on one CPU,
+    profiles/r06_cpu_baseline.txt).  Workers pin themselves now: a pinned run with far more threads than rows must leave the calling thread's mask as it was."""
+    import os
+    if not hasattr(os, "sched_getaffinity") or len(os.sched_getaffinity(0)) < 2:
+        pytest.skip("needs an affinity mask of at least two CPUs")
+    before = os.sched_getaffinity(0)
+    W, H = 64, 32
+    sc, env = make_scene(abi.PROC_HELMET, 0.02, env_size=(64, 32))
+    st = host.default_state(W, H, sc, env)
+    o = Oracle(1); o.upload_scene(sc.desc(env)); o.resize(W, H)
+    sc.updateCamera(W, H); o.set_camera(sc.getCamera())
+    try:
+        o.set_threads(64, pin=True)              # 64 workers for 32 (16 half-resolution) rows: most of them find no row and exit at once
+        for f in range(3):
+            st.time = 5 + f; o.render_frame(st, f)
+            assert os.sched_getaffinity(0) == before, f"frame {f}: the caller's affinity mask changed from {len(before)} to {len(os.sched_getaffinity(0))} CPUs"
+        for k in range(300):                     # the shortest stage there is, again and again: a worker is done before the spawning loop has reached the next one
+            o.run_stage(st, 2, abi.STAGE_COMPOSE, 0, 0, H)
+            assert os.sched_getaffinity(0) == before, f"compose pass {k}: the caller's affinity mask changed from {len(before)} to {len(os.sched_getaffinity(0))} CPUs"
+    finally:
+        os.sched_setaffinity(0, before)
+
+
+def test_cpu_budget_follows_the_override_and_the_mask():
+    """include/rt_cpus.h (the default thread count of the oracle, the builder and the loaders): RESTIR_CPUS overrides; otherwise never more than the affinity mask"""
+    import os, subprocess, sys, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "t.cpp")
+        open(src, "w").write('#include "rt_cpus.h"\n#include <cstdio>\nint main() { std::printf("%d %d\\n", rt_cpu_budget(), rt_cpu_quota()); return 0; }\n')
+        exe = os.path.join(d, "t")
+        subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(root, "include"), src, "-o", exe])
+        env = {k: v for k, v in os.environ.items() if k != "RESTIR_CPUS"}
+        budget, quota = map(int, subprocess.check_output([exe], env=env).split())
+        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+        assert 1 <= budget <= ncpu and (quota == 0 or budget <= quota)
+        assert int(subprocess.check_output([exe], env=dict(env, RESTIR_CPUS="7")).split()[0]) == 7
+        if ncpu >= 2 and hasattr(os, "sched_setaffinity"):
+            one = subprocess.check_output(["taskset", "-c", str(sorted(os.sched_getaffinity(0))[0]), exe], env=env).split() if subprocess.call(["which", "taskset"], stdout=subprocess.DEVNULL) == 0 else None
+            if one is not None:
+                assert int(one[0]) == 1
+
+
 def test_reservoir_invariants_over_frames():
     W = H = 48
     sc, _ = make_scene(abi.PROC_CORNELL)
