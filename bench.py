@@ -506,6 +506,12 @@ def main():
         out["roofline"], out["cpu_baseline"] = di_only_roofline(r, abi, st, W, H, first_timed, n_count, elapsed / args.steps * 1e3), None
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(abi, host, scene, env, st, desc, W, H, first_timed, di_only=True)
+    if world == 1 and timing.framesTimed > 0 and args.profile_run and not di_only:
+        # (round 6) the profiled command's own HIP-event figures: `rocprofv3 --kernel-trace --stats` and the events then describe the SAME launches of the SAME process —
+        # the profiler shifts how the kernels of the frames in flight share the chip, so a trace of one process and the events of another differ by more than their error
+        out["events_in_this_run"] = {"stage_ms_per_frame": {n: round(timing.stageMs[i] / max(1, timing.framesTimed), 4) for i, n in enumerate(STAGE_NAMES[:5])},
+                                     "frames": int(timing.framesTimed), "note": "HIP events on the stream of each launch over the timed frames (rt_get_counters); "
+                                     "direct_stage = one k_direct_stage launch: compare with the AverageNs of the kernel stats of this run"}
     if world == 1 and timing.framesTimed > 0 and not args.profile_run and not di_only:
         stage_ms = [timing.stageMs[i] / max(1, timing.framesTimed) for i in range(5)]
         frame_latency_ms = timing.frameMs / max(1, timing.framesTimed)
