@@ -229,6 +229,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1 and not args.native and not os.environ.get("RESTIR_CPUS"):
+        # one process per GPU on ONE host: the ranks generate their scenes and build their trees at the same time, so each takes its share of the CPUs the container may use
+        # (include/rt_cpus.h reads RESTIR_CPUS; round 6: eight ranks x 512 builder threads on a 16-CPU quota)
+        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        os.environ["RESTIR_CPUS"] = str(max(2, min(ncpu, cpu_quota() or ncpu) // max(1, local_world)))
+        os.environ["RESTIR_CPUS_SHARED"] = "1"      # (ours, not the user's: the native host rank 0 starts afterwards in a child process gets the whole budget again)
 
     import torch
     import restir_amd  # noqa: F401
@@ -806,7 +813,8 @@ def both_hosts(args, rccl_line):
     keep += (["--width", str(args.width)] if args.width else []) + (["--height", str(args.height)] if args.height else [])
     keep += (["--devices", args.devices] if getattr(args, "devices", "") else [])
     env = {k: v for k, v in os.environ.items() if not (k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE",
-                                                               "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS") or k.startswith(("TORCHELASTIC_", "NCCL_ASYNC", "TORCH_NCCL")))}
+                                                               "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS", "RESTIR_CPUS_SHARED") or k.startswith(("TORCHELASTIC_", "NCCL_ASYNC", "TORCH_NCCL"))
+                                                          or (k == "RESTIR_CPUS" and os.environ.get("RESTIR_CPUS_SHARED") == "1"))}
     nat, err = None, None
     try:
         time.sleep(2.0)     # the other ranks are leaving: let their contexts go before the native host times anything
