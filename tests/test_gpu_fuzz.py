@@ -101,7 +101,10 @@ KNOBS = ["RESTIR_IND_SUB=0", "RESTIR_IND_SUB=1", "RESTIR_IND_SUB=2 RESTIR_COOP=6
          # two LDS stack entries: nearly every ray keeps part of its traversal stack in the HBM overflow area
          "RESTIR_STACK_LDS=2", "RESTIR_STACK_LDS=64",
          # latency build: gang mode off / as soon as one ray slot of a wave idles (the sweep draws either traversal build per case)
-         "RESTIR_GANG=0", "RESTIR_GANG=7"]
+         "RESTIR_GANG=0", "RESTIR_GANG=7",
+         # frames in flight from the first frame (with the stream levels given, no serial probe frames: the three frames of a case then run through the buffer rotation
+         # of two / three frames in flight instead of one by one)
+         "RESTIR_OVERLAP=2 RESTIR_PRIO=2", "RESTIR_OVERLAP=3 RESTIR_PRIO=1"]
 
 
 @pytest.mark.gpu
